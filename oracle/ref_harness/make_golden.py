@@ -1,0 +1,535 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN CODE (build container only).
+
+    python oracle/ref_harness/make_golden.py          # rewrites tests/golden/*.npz
+
+The reference package is imported from /root/reference through bootstrap.install()
+(inert gym/pygame/turtle stubs + the numpy GEOS shim in ./shim).  Every expected value
+stored below is produced by a reference function:
+    G1 dynamics   Vessel.step                    objects/vessel/vessel.py:226-247
+    G2 path/nav   Path.__init__, Vessel.navigate objects/path.py:19-40, vessel.py:461-541
+    G3 lidar      Vessel.perceive                vessel.py:249-368, sensor.py:22-159
+    G4 reward     ColavRewarder / PathFollowRewarder.calculate, BaseEnvironment._isdone
+                                                 rewarder.py:78-241, environment.py:375-384
+    G5 rollouts   BaseEnvironment.reset/step     environment.py:176-366
+Each fixture records dt / min_goal_distance / use_lidar explicitly.
+GEOS primitives come from the shim, so GEOS numerics are "parity unpinned" (DESIGN.md).
+"""
+import contextlib
+import copy
+import io
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import bootstrap  # noqa: E402
+
+gym_auv = bootstrap.install()
+
+from gym_auv.objects.vessel import Vessel  # noqa: E402
+from gym_auv.objects.path import Path, RandomCurveThroughOrigin  # noqa: E402
+from gym_auv.objects.obstacles import CircularObstacle, PolygonObstacle, VesselObstacle  # noqa: E402
+from gym_auv.objects.rewarder import ColavRewarder, PathFollowRewarder  # noqa: E402
+from gym_auv.objects.vessel.sensor import _find_limit_angle_rays  # noqa: E402
+import gym_auv.envs.movingobstacles as mo  # noqa: E402
+import gym_auv.envs.testscenario as ts  # noqa: E402
+import shapely.geometry  # noqa: E402  (the shim)
+
+from gym_auv_amd.worldspec import WorldSpec, MoverSpec, pack_world  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+quiet = lambda: contextlib.redirect_stdout(io.StringIO())  # noqa: E731
+
+
+def make_cfg(dt=0.5, min_goal_distance=0.1, use_lidar=True, n_sectors=9, n_per_sector=20):
+    cfg = copy.deepcopy(gym_auv.DEFAULT_CONFIG)  # deep copy: un-alias the shared sub-configs
+    cfg.simulation.t_step_size = dt
+    cfg.episode.min_goal_distance = min_goal_distance
+    cfg.vessel.use_lidar = use_lidar
+    cfg.vessel.n_sectors = n_sectors
+    cfg.vessel.n_sensors_per_sector = n_per_sector
+    return cfg
+
+
+def cfg_scalars(cfg):
+    return np.array([cfg.simulation.t_step_size, cfg.episode.min_goal_distance,
+                     float(cfg.vessel.use_lidar), cfg.vessel.n_sectors,
+                     cfg.vessel.n_sensors_per_sector, cfg.episode.max_timesteps,
+                     cfg.episode.min_cumulative_reward, cfg.episode.min_path_progress,
+                     cfg.vessel.sensor_range, cfg.vessel.vessel_width,
+                     cfg.vessel.look_ahead_distance,
+                     cfg.vessel.sensor_interval_load_obstacles], dtype=np.float64)
+
+
+CFG_KEYS = ["dt", "min_goal_distance", "use_lidar", "n_sectors", "n_sensors_per_sector",
+            "max_timesteps", "min_cumulative_reward", "min_path_progress", "sensor_range",
+            "vessel_width", "look_ahead_distance", "sensor_interval_load_obstacles"]
+
+
+def mover_spec(o):
+    vel = np.asarray(o.trajectory_velocities, dtype=np.float64)
+    if np.abs(vel - vel[0]).max() < 1e-9:
+        vel_tab = vel[:1].copy()
+    else:
+        vel_tab = vel
+    return MoverSpec(width=float(o.width), pos0=np.array(o.trajectory[0][1], dtype=np.float64),
+                     vel=vel_tab, n_vel=len(vel), pos=np.array(o.position, dtype=np.float64),
+                     heading=float(o.heading), counter=float(o.waypoint_counter))
+
+
+def world_from_env(env, name=""):
+    circles, polys, movers = [], [], []
+    for o in env.obstacles:
+        if isinstance(o, CircularObstacle):
+            circles.append([o.position[0], o.position[1], o.radius])
+        elif isinstance(o, PolygonObstacle):
+            polys.append(np.asarray(o.points, dtype=np.float64))
+        elif isinstance(o, VesselObstacle):
+            movers.append(mover_spec(o))
+        else:
+            raise TypeError(type(o))
+    return WorldSpec(waypoints=np.asarray(env.path.init_waypoints, dtype=np.float64),
+                     vessel_init=np.array(env.vessel._state[:3], dtype=np.float64),
+                     circles=np.asarray(circles, dtype=np.float64).reshape(-1, 3),
+                     polygons=polys, movers=movers, name=name)
+
+
+# =============================================================================== G1
+def gen_dynamics():
+    rs = np.random.RandomState(1001)
+    n = 4096
+    st = np.empty((n, 6))
+    st[:, 0:2] = rs.uniform(-1500, 1500, (n, 2))
+    st[:, 2] = rs.uniform(-np.pi, np.pi, n)
+    st[:64, 2] = np.pi - rs.uniform(0, 1e-3, 64)          # near +pi (wrap)
+    st[64:128, 2] = -np.pi + rs.uniform(0, 1e-3, 64)      # near -pi
+    st[:, 3] = rs.uniform(-0.5, 2.0, n)
+    st[:, 4] = rs.uniform(-0.5, 0.5, n)
+    st[:, 5] = rs.uniform(-0.6, 0.6, n)
+    st[128:160, 3:] = 0.0                                  # at rest
+    act = rs.uniform(-1.5, 1.5, (n, 2))                    # beyond the clip bounds on purpose
+    act[160:192] = [[1.0, 0.15]]
+    act[192:224] = [[0.0, 0.0]]
+    dts = np.where(np.arange(n) % 2 == 0, 0.5, 1.0)
+    out = np.empty_like(st)
+    vs = {dt: Vessel(make_cfg(dt=dt), np.zeros(3)) for dt in (0.5, 1.0)}
+    for i in range(n):
+        v = vs[dts[i]]
+        v.reset(st[i, :3])
+        v._state = st[i].copy()
+        v.step(act[i])
+        out[i] = v._state
+    # chained trajectory from the reference test pose (free-running, 50 steps, dt 0.5)
+    v = Vessel(make_cfg(dt=0.5), np.array([5, -5, np.deg2rad(45)]))
+    chain = [v._state.copy()]
+    for _ in range(50):
+        v.step(np.array([0.5, 0.6]))
+        chain.append(v._state.copy())
+    np.savez_compressed(os.path.join(OUT, "g1_dynamics.npz"), state=st, action=act, dt=dts,
+                        next_state=out, chain=np.array(chain), chain_action=np.array([0.5, 0.6]))
+    print("G1 dynamics:", n, "cases; chain end", chain[-1])
+
+
+# =============================================================================== G2
+def nav_record(v, path):
+    v.navigate(path)
+    d = v._last_navi_state_dict
+    return [d["vessel_arclength"], d["path_direction"], d["cross_track_error"],
+            d["look_ahead_heading_error"], d["heading_error"], d["target_arclength"],
+            d["goal_distance"], v._progress, float(v._reached_goal),
+            d["look_ahead_path_direction"], d["target_heading"]]
+
+
+NAV_KEYS = ["vessel_arclength", "path_direction", "cross_track_error(/100)",
+            "look_ahead_heading_error", "heading_error", "target_arclength", "goal_distance",
+            "progress", "reached_goal", "look_ahead_path_direction", "target_heading"]
+
+
+def gen_path():
+    cfg = make_cfg(dt=0.5, min_goal_distance=0.1)
+    out = {"cfg": cfg_scalars(cfg), "cfg_keys": np.array(CFG_KEYS), "nav_keys": np.array(NAV_KEYS)}
+    paths = []
+    for seed in range(8):
+        rng, _ = bootstrap.np_random(seed)
+        nw = int(np.floor(4 * rng.rand() + 2))
+        paths.append(("rand%d" % seed, RandomCurveThroughOrigin(rng, nw, length=800)))
+    paths.append(("straight1100", Path([[0, 1100], [0, 1100]])))
+    paths.append(("straight500", Path(np.vstack([[0, 0], [0, 500]]).T)))
+    wp = []
+    for t in range(500):
+        wp.append([t * np.cos(t / 100), 2 * t])
+    paths.append(("testscenario2", Path(np.vstack(wp).T)))
+    out["names"] = np.array([n for n, _ in paths])
+    rs = np.random.RandomState(2002)
+    for k, (name, p) in enumerate(paths):
+        pre = "p%d_" % k
+        out[pre + "waypoints"] = np.asarray(p.init_waypoints, dtype=np.float64)
+        out[pre + "length"] = np.float64(p.length)
+        out[pre + "npoints"] = np.int64(len(p._points))
+        out[pre + "knots_s"] = np.asarray(p._arclengths)
+        out[pre + "knots_xy"] = np.asarray(p._waypoints)
+        out[pre + "points_sub"] = p._points[::61].copy()
+        out[pre + "points_last"] = p._points[-1].copy()
+        out[pre + "points_sum"] = p._points.sum(axis=0)
+        out[pre + "start"] = np.asarray(p.start)
+        out[pre + "end"] = np.asarray(p.end)
+        ss = np.concatenate([rs.uniform(-20, p.length + 20, 24), [0.0, p.length, p.length * 0.5]])
+        out[pre + "eval_s"] = ss
+        out[pre + "eval_xy"] = np.array([p(s) for s in ss])
+        out[pre + "eval_dir"] = np.array([p.get_direction(s) for s in ss])
+        # navigation queries through the real Vessel.navigate
+        nq = 48
+        q = np.empty((nq, 3))
+        sq = rs.uniform(0, p.length, nq)
+        base = np.array([p(s) for s in sq])
+        q[:, :2] = base + rs.normal(0, 25, (nq, 2))
+        q[:8, :2] = base[:8] + rs.normal(0, 0.5, (8, 2))          # very close to the path
+        q[8:12, :2] = np.asarray(p.end) + rs.normal(0, 0.05, (4, 2))  # at the goal
+        q[12:16, :2] = np.asarray(p.start) + rs.normal(0, 40, (4, 2))  # around/before the start
+        q[16:20, :2] = rs.uniform(-900, 900, (4, 2))                 # far away
+        q[:, 2] = rs.uniform(-np.pi, np.pi, nq)
+        v = Vessel(cfg, np.zeros(3))
+        rec = []
+        for i in range(nq):
+            v.reset(q[i])
+            v._max_progress = 0
+            rec.append(nav_record(v, p))
+        out[pre + "nav_query"] = q
+        out[pre + "nav_out"] = np.array(rec, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g2_path.npz"), **out)
+    print("G2 path:", len(paths), "paths; lengths", [round(p.length, 3) for _, p in paths])
+
+
+# =============================================================================== G3
+def star_polygon(rs, centre, rad, k):
+    ang = np.sort(rs.uniform(0, 2 * np.pi, k))
+    rr = rad * rs.uniform(0.45, 1.0, k)
+    return np.stack([centre[0] + rr * np.cos(ang), centre[1] + rr * np.sin(ang)], axis=1)
+
+
+def scene_record(cfg, pose, obstacles):
+    """Run the reference perceive() on a fresh Vessel; returns dict or None if the reference
+    raised (the b~-2pi IndexError corner, sensor.py:93-95)."""
+    v = Vessel(cfg, np.asarray(pose, dtype=np.float64))
+    try:
+        clos, _ = v.perceive(obstacles)
+    except IndexError:
+        return None
+    p0 = shapely.geometry.Point(*v.position)
+    lim = []
+    for o in obstacles:
+        lim.append(_find_limit_angle_rays(o.enclosing_circle, p0, v.heading, v._d_sensor_angle))
+    nearby = np.array([any(o is q for q in v._nearby_obstacles) for o in obstacles])
+    ec = np.array([[o.enclosing_circle.center.x, o.enclosing_circle.center.y,
+                    o.enclosing_circle.radius] for o in obstacles]).reshape(-1, 3)
+    return dict(d=np.asarray(v._last_sensor_dist_measurements, dtype=np.float64),
+                closeness=np.asarray(clos, dtype=np.float64), collision=bool(v._collision),
+                limits=np.asarray(lim, dtype=np.int64).reshape(-1, 2), nearby=nearby, cull=ec)
+
+
+def obstacles_to_arrays(obstacles):
+    circles, polys, movers = [], [], []
+    order = []
+    for o in obstacles:
+        if isinstance(o, CircularObstacle):
+            order.append((0, len(circles)))
+            circles.append([o.position[0], o.position[1], o.radius])
+        elif isinstance(o, PolygonObstacle):
+            order.append((1, len(polys)))
+            polys.append(np.asarray(o.points, dtype=np.float64))
+        else:
+            order.append((2, len(movers)))
+            movers.append([o.width, o.position[0], o.position[1], o.heading])
+    return circles, polys, movers, order
+
+
+def gen_lidar():
+    out = {"cfg_keys": np.array(CFG_KEYS)}
+    scenes = []   # (name, cfg, pose, obstacles)
+    rs = np.random.RandomState(3003)
+    SCFG = {64: make_cfg(n_sectors=8, n_per_sector=8), 180: make_cfg(),
+            256: make_cfg(n_sectors=16, n_per_sector=16)}
+
+    # (a) the reference's own test scene (tests/test_hierarchical_collision_detector.py:10-24)
+    scenes.append(("reftest", SCFG[180], [5, -5, np.deg2rad(45)],
+                   [CircularObstacle(np.array([0, -9.5]), 1.5)]))
+    # (b) circle boundary tables for a sweep of radii (A4 thresholds)
+    radii = [0.1, 0.2, 0.31, 0.9, 1.0, 1.03, 1.5, 3.9, 4.0, 10.0, 15.6, 15.7, 25.0, 30.0, 62.0, 63.0, 120.0]
+    ring_n = []
+    for r in radii:
+        ring_n.append(len(CircularObstacle(np.array([3.0, -7.0]), r).boundary.coords))
+    out["ring_radii"] = np.array(radii)
+    out["ring_ncoords"] = np.array(ring_n)
+    ring30 = CircularObstacle(np.array([3.0, -7.0]), 30.0).boundary.coords
+    out["ring30_coords"] = np.array(list(ring30))
+    # (c) TestScenario1/3/4 worlds at several poses, S = 180
+    for cls, nm in ((ts.TestScenario1, "ts1"), (ts.TestScenario3, "ts3"), (ts.TestScenario4, "ts4")):
+        with quiet():
+            env = cls(env_config=SCFG[180], renderer=None)
+        for j in range(6):
+            if nm == "ts1":
+                s = rs.uniform(0, 600)
+                pose = [s / np.sqrt(2) + rs.normal(0, 15), s / np.sqrt(2) + rs.normal(0, 15),
+                        rs.uniform(-np.pi, np.pi)]
+            else:
+                pose = [rs.normal(0, 60), rs.normal(40, 60), rs.uniform(-np.pi, np.pi)]
+            scenes.append(("%s_%d" % (nm, j), SCFG[180], pose, list(env.obstacles)))
+    # (d) random MovingObstaclesNoRules worlds at the reset pose and at probing poses
+    for seed in range(12):
+        S = (64, 180, 256)[seed % 3]
+        with quiet():
+            np.random.seed(500 + seed)
+            env = mo.MovingObstaclesNoRules(env_config=SCFG[S], renderer=None)
+            env.seed(500 + seed)
+            np.random.seed(500 + seed)
+            env.reset()
+        obst = list(env.obstacles)
+        scenes.append(("mo%d_reset" % seed, SCFG[S], env.vessel._state[:3].copy(), obst))
+        for j in range(5):
+            o = obst[rs.randint(len(obst))]
+            ec = o.enclosing_circle
+            rad = ec.radius
+            dist = rad * rs.uniform(0.2, 4.0) + rs.uniform(0, 20)
+            ang = rs.uniform(-np.pi, np.pi)
+            pose = [ec.center.x + dist * np.cos(ang), ec.center.y + dist * np.sin(ang),
+                    rs.uniform(-np.pi, np.pi)]
+            scenes.append(("mo%d_probe%d" % (seed, j), SCFG[S], pose, obst))
+    # (e) synthetic filled-polygon worlds (config 2 shape), incl. vessel inside a polygon
+    for seed in range(6):
+        S = (180, 64, 256)[seed % 3]
+        polys = []
+        for _ in range(12):
+            c = rs.normal(0, 120, 2)
+            polys.append(PolygonObstacle(star_polygon(rs, c, max(3, rs.poisson(30)), rs.randint(6, 17))))
+        for j in range(5):
+            if j == 0:
+                c = polys[0].boundary.centroid
+                pose = [c.x, c.y, rs.uniform(-np.pi, np.pi)]     # inside polygon 0
+            else:
+                pose = [rs.normal(0, 100), rs.normal(0, 100), rs.uniform(-np.pi, np.pi)]
+            scenes.append(("poly%d_%d" % (seed, j), SCFG[S], pose, polys))
+
+    kept, skipped = 0, 0
+    names = []
+    for name, cfg, pose, obst in scenes:
+        rec = scene_record(cfg, pose, obst)
+        if rec is None:
+            skipped += 1
+            continue
+        pre = "s%d_" % kept
+        circles, polys, movers, order = obstacles_to_arrays(obst)
+        out[pre + "cfg"] = cfg_scalars(cfg)
+        out[pre + "pose"] = np.asarray(pose, dtype=np.float64)
+        out[pre + "circles"] = np.asarray(circles, dtype=np.float64).reshape(-1, 3)
+        out[pre + "poly_pts"] = np.concatenate(polys) if polys else np.zeros((0, 2))
+        out[pre + "poly_off"] = np.cumsum([0] + [len(p) for p in polys]).astype(np.int64)
+        out[pre + "movers_now"] = np.asarray(movers, dtype=np.float64).reshape(-1, 4)
+        out[pre + "order"] = np.asarray(order, dtype=np.int64).reshape(-1, 2)
+        for k, val in rec.items():
+            out[pre + k] = np.asarray(val)
+        names.append(name)
+        kept += 1
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g3_lidar.npz"), **out)
+    ncoll = sum(bool(out["s%d_collision" % i]) for i in range(kept))
+    nhit = sum(int((out["s%d_d" % i] < 150).sum() > 0) for i in range(kept))
+    print("G3 lidar:", kept, "scenes (", skipped, "skipped: reference IndexError);",
+          nhit, "with hits;", ncoll, "collisions; ring coords", dict(zip(radii, ring_n)))
+
+
+# =============================================================================== G4
+def gen_reward():
+    rs = np.random.RandomState(4004)
+    out = {}
+    for S, cfg in ((180, make_cfg()), (64, make_cfg(n_sectors=8, n_per_sector=8))):
+        n = 512
+        v = Vessel(cfg, np.zeros(3))
+        col = ColavRewarder(v, False)
+        pf = PathFollowRewarder(v, False)
+        rec_in = np.empty((n, 8))
+        rec_d = np.empty((n, S))
+        rec_out = np.empty((n, 2))
+        for i in range(n):
+            u, vv, r = rs.uniform(-0.2, 1.0), rs.uniform(-0.2, 0.2), rs.uniform(-0.3, 0.3)
+            if i % 7 == 0:
+                u, vv = rs.uniform(0, 0.05), rs.uniform(0, 0.02)       # slow-speed branch
+            cte = rs.normal(0, 0.3)
+            he = rs.uniform(-np.pi, np.pi)
+            prog = rs.uniform(0, 1)
+            maxprog = prog if i % 2 == 0 else prog + rs.uniform(0, 0.1)
+            collision = (i % 11 == 0)
+            d = np.full(S, 150.0)
+            m = rs.rand(S) < 0.3
+            d[m] = rs.uniform(0, 150, m.sum())
+            v._state = np.array([0, 0, 0, u, vv, r], dtype=np.float64)
+            v._last_navi_state_dict = {"cross_track_error": cte, "heading_error": he}
+            v._last_sensor_dist_measurements = d
+            v._last_sensor_speed_measurements = np.zeros((2, S))
+            v._collision = collision
+            v._progress = prog
+            v._max_progress = maxprog
+            rec_in[i] = [u, vv, r, cte, he, prog, maxprog, float(collision)]
+            rec_d[i] = d
+            rec_out[i] = [col.calculate(), pf.calculate()]
+        out["S%d_in" % S] = rec_in
+        out["S%d_d" % S] = rec_d
+        out["S%d_reward" % S] = rec_out
+    out["in_keys"] = np.array(["u", "v", "r", "cross_track_error(/100)", "heading_error",
+                               "progress", "max_progress", "collision"])
+    out["reward_keys"] = np.array(["colav", "pathfollow"])
+    # done logic through the real BaseEnvironment._isdone
+    with quiet():
+        env = ts.EmptyScenario(env_config=make_cfg(use_lidar=False), renderer=None)
+    cases = []
+    for collision in (False, True):
+        for goal in (False, True):
+            for t_step in (0, 9997, 9998, 9999, 10000):
+                for cum in (-1999.9, -2000.0, -2000.1, 50.0):
+                    for test_mode in (False, True):
+                        env.collision, env.reached_goal = collision, goal
+                        env.t_step, env.cumulative_reward, env.test_mode = t_step, cum, test_mode
+                        cases.append([collision, goal, t_step, cum, test_mode, env._isdone()])
+    out["done_cases"] = np.array(cases, dtype=np.float64)
+    out["done_keys"] = np.array(["collision", "reached_goal", "t_step", "cumulative_reward",
+                                 "test_mode", "done"])
+    out["done_cfg"] = cfg_scalars(env.config)
+    out["cfg_keys"] = np.array(CFG_KEYS)
+    np.savez_compressed(os.path.join(OUT, "g4_reward.npz"), **out)
+    print("G4 reward: 2x512 cases;", len(cases), "done cases")
+
+
+# =============================================================================== G5
+def pilot(env, rs, k):
+    """Look-ahead pilot + noise; step 7 feeds a NaN action (environment.py:314-315)."""
+    he = env.vessel._last_navi_state_dict["heading_error"]
+    a = np.array([np.clip(0.8 + 0.4 * rs.randn(), -1, 1), np.clip(0.15 * he + 0.03 * rs.randn(), -0.2, 0.2)])
+    if k == 7:
+        a = np.array([np.nan, 0.1])
+    return a
+
+
+def rollout(env, n_steps, rs, teleport=None, act_fn=pilot):
+    """Returns dict of per-step arrays. The env has been reset by the caller."""
+    world = world_from_env(env)
+    obs0 = np.asarray(env.observe_cache, dtype=np.float64)
+    if teleport is not None:
+        env.vessel._state[:3] = teleport[:3]
+        env.vessel._state[3:] = teleport[3:]
+    start_state = env.vessel._state.copy()
+    A, ST, OBS, REW, DONE, INFO, D, MV = [], [], [], [], [], [], [], []
+    for k in range(n_steps):
+        a = act_fn(env, rs, k)
+        with quiet():
+            obs, rew, done, info = env.step(a)
+        A.append(a)
+        ST.append(env.vessel._state.copy())
+        OBS.append(np.asarray(obs, dtype=np.float64))
+        REW.append(rew)
+        DONE.append(done)
+        INFO.append([float(info["collision"]), float(info["reached_goal"]),
+                     float(info["goal_distance"]), float(info["progress"]),
+                     env.cumulative_reward, env.vessel._max_progress])
+        D.append(np.asarray(env.vessel._last_sensor_dist_measurements, dtype=np.float64))
+        MV.append([[o.position[0], o.position[1], o.heading, o.waypoint_counter]
+                   for o in env.obstacles if isinstance(o, VesselObstacle)])
+        if done:
+            break
+    return world, dict(obs0=obs0, start_state=start_state, action=np.array(A), state=np.array(ST),
+                       obs=np.array(OBS), reward=np.array(REW), done=np.array(DONE),
+                       info=np.array(INFO), d=np.array(D),
+                       movers=np.array(MV, dtype=np.float64).reshape(len(A), -1, 4))
+
+
+def gen_rollouts():
+    out = {"cfg_keys": np.array(CFG_KEYS),
+           "info_keys": np.array(["collision", "reached_goal", "goal_distance", "progress",
+                                  "cumulative_reward", "max_progress"])}
+    runs = []
+
+    def make(cls, cfg, seed):
+        with quiet():
+            np.random.seed(seed)
+            random.seed(seed)
+            env = cls(env_config=cfg, renderer=None)
+            env.seed(seed)
+            np.random.seed(seed)
+            random.seed(seed)
+            env.observe_cache = env.reset()
+        return env
+
+    rs = np.random.RandomState(5005)
+    # r0-r2: MovingObstaclesNoRules, lidar on, S=180, dt 0.5, free pilot
+    for seed in (11, 12, 13):
+        cfg = make_cfg()
+        env = make(mo.MovingObstaclesNoRules, cfg, seed)
+        runs.append(("mo_seed%d" % seed, cfg, "colav") + rollout(env, 120, rs))
+    # r3: same world family, vessel teleported next to a static circle, heading at it -> collision
+    cfg = make_cfg()
+    env = make(mo.MovingObstaclesNoRules, cfg, 21)
+    circ = [o for o in env.obstacles if isinstance(o, CircularObstacle)][0]
+    ang = 0.7
+    start = circ.position + (circ.radius + 9.0) * np.array([np.cos(ang), np.sin(ang)])
+    tp = np.array([start[0], start[1], ang + np.pi, 0.4, 0.0, 0.0])
+    full = lambda env, rs, k: np.array([1.0, 0.0])  # noqa: E731
+    runs.append(("mo_collision", cfg, "colav") + rollout(env, 80, rs, teleport=tp, act_fn=full))
+    # r4: teleported near the goal -> reached_goal via progress >= 0.99
+    cfg = make_cfg()
+    env = make(mo.MovingObstaclesNoRules, cfg, 22)
+    L = env.path.length
+    s0 = 0.985 * L
+    p = env.path(s0)
+    tp = np.array([p[0], p[1], env.path.get_direction(s0), 0.5, 0.0, 0.0])
+    runs.append(("mo_goal", cfg, "colav") + rollout(env, 80, rs, teleport=tp, act_fn=full))
+    # r5: PathFollowNoObstacles (lidar off, PathFollowRewarder), dt 1.0 / min_goal_distance 5
+    cfg = make_cfg(dt=1.0, min_goal_distance=5.0, use_lidar=False)
+    env = make(mo.PathFollowNoObstacles, cfg, 31)
+    runs.append(("pathfollow", cfg, "pathfollow") + rollout(env, 100, rs))
+    # r6: TestScenario1 static circles, S=64
+    cfg = make_cfg(n_sectors=8, n_per_sector=8)
+    env = make(ts.TestScenario1, cfg, 41)
+    runs.append(("testscenario1", cfg, "colav") + rollout(env, 100, rs))
+    # r7: TestHeadOn (one moving obstacle, width 30, closing head-on), S=180
+    cfg = make_cfg()
+    env = make(ts.TestHeadOn, cfg, 51)
+    runs.append(("headon", cfg, "colav") + rollout(env, 100, rs))
+    # r8: DebugScenario (10 movers on non-constant velocity tables), S=256
+    cfg = make_cfg(n_sectors=16, n_per_sector=16)
+    env = make(ts.DebugScenario, cfg, 61)
+    runs.append(("debug", cfg, "colav") + rollout(env, 60, rs))
+
+    out["names"] = np.array([r[0] for r in runs])
+    out["rewarder"] = np.array([r[2] for r in runs])
+    for k, (name, cfg, rew, world, rec) in enumerate(runs):
+        pre = "r%d_" % k
+        out[pre + "cfg"] = cfg_scalars(cfg)
+        out.update(pack_world(pre + "w_", world))
+        for key, val in rec.items():
+            out[pre + key] = val
+        print("  rollout", name, "steps", len(rec["reward"]), "done", bool(rec["done"][-1]),
+              "collision", bool(rec["info"][-1, 0]), "goal", bool(rec["info"][-1, 1]),
+              "min d", rec["d"].min().round(3), "reward sum", rec["reward"].sum().round(2))
+    np.savez_compressed(os.path.join(OUT, "g5_rollouts.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    if "g1" in which:
+        gen_dynamics()
+    if "g2" in which:
+        gen_path()
+    if "g3" in which:
+        gen_lidar()
+    if "g4" in which:
+        gen_reward()
+    if "g5" in which:
+        gen_rollouts()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
