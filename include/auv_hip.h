@@ -1,0 +1,191 @@
+/* auv_hip.h — C ABI of the MI355X-native batched gym-auv step() path.
+ *
+ * The reference (krisbrud/gym-auv) is pure Python and has NO FFI layer of its own; the
+ * boundary it offers for this path is the gym.Env surface
+ *   reset()            gym_auv/environment.py:176-245
+ *   step(action)       gym_auv/environment.py:292-366
+ *   observe()          gym_auv/environment.py:247-290
+ * so every entry point below cites the reference method whose per-environment work it
+ * performs for a whole batch of N independent environments.  Plain pointers and sizes
+ * only (no torch types); the Python side binds it with ctypes.
+ *
+ * Conventions
+ *   - return 0 on success, negative AUV_E* on failure; text via auv_last_error().
+ *   - "dev" pointers are device (HBM) pointers owned by the CALLER (e.g. torch tensors);
+ *     the handle owns environment state, world bank and scratch.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  auv_step and the
+ *     per-kernel entry points are stream-ordered: no allocation, no host sync, hipGraph
+ *     capturable.
+ *   - one handle per GPU, one host thread per handle (the reference env is single-threaded
+ *     and non-re-entrant; nothing stronger is promised).
+ *   - all arithmetic is IEEE fp64 ("f64"); obs/reward are additionally emitted as fp32
+ *     because observation_space.dtype is float32 (environment.py:139-143).
+ */
+#ifndef AUV_HIP_H
+#define AUV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUV_ABI_VERSION 1
+
+enum {
+  AUV_OK = 0,
+  AUV_EINVAL = -1,   /* bad argument / shape mismatch            */
+  AUV_EHIP = -2,     /* a HIP runtime call failed                */
+  AUV_ESTATE = -3,   /* call order violated (e.g. no worlds yet) */
+  AUV_ENOMEM = -4
+};
+
+enum { AUV_REWARD_COLAV = 0, AUV_REWARD_PATHFOLLOW = 1 };       /* rewarder.py:143, :56 */
+enum { AUV_CULL_REFERENCE = 0, AUV_CULL_EXACT = 1 };            /* sensor.py:74-97 vs :100-137 */
+enum { AUV_OBS_RING = 0, AUV_OBS_FILLED = 1, AUV_OBS_MOVER = 2 };
+enum { AUV_F32 = 0, AUV_F64 = 1 };
+
+/* Mirrors the fields of gym_auv/config.py that step() reads. */
+typedef struct auv_config {
+  double dt;                      /* SimulationConfig.t_step_size        config.py:28  */
+  double min_goal_distance;       /* EpisodeConfig.min_goal_distance     config.py:20  */
+  double min_path_progress;       /* EpisodeConfig.min_path_progress     config.py:23  */
+  double min_cumulative_reward;   /* EpisodeConfig.min_cumulative_reward config.py:16  */
+  double sensor_range;            /* VesselConfig.sensor_range           config.py:65  */
+  double vessel_width;            /* VesselConfig.vessel_width           config.py:41  */
+  double look_ahead_distance;     /* VesselConfig.look_ahead_distance    config.py:45  */
+  double thrust_max;              /* VesselConfig.thrust_max_auv         config.py:39  */
+  double moment_max;              /* VesselConfig.moment_max_auv         config.py:40  */
+  int32_t max_timesteps;          /* EpisodeConfig.max_timesteps         config.py:19  */
+  int32_t n_sensors;              /* n_sectors * n_sensors_per_sector    config.py:75  */
+  int32_t sensor_interval_load_obstacles;                             /* config.py:56  */
+  int32_t use_lidar;              /* VesselConfig.use_lidar              config.py:52  */
+  int32_t sensor_log_transform;   /* VesselConfig.sensor_log_transform   config.py:66  */
+  int32_t rewarder;               /* AUV_REWARD_*                                      */
+  int32_t test_mode;              /* BaseEnvironment(test_mode=)   environment.py:32   */
+  int32_t cull_mode;              /* AUV_CULL_*                                        */
+  int32_t auto_reset;             /* VecEnv semantics: a done env restarts on its next
+                                     world of the bank inside the same step            */
+  int32_t reserved;
+} auv_config_t;
+
+/* World bank: W pre-generated scenario instances in CSR form (host pointers; copied to HBM
+ * by auv_load_worlds).  Built by gym_auv_amd.world from WorldSpec, i.e. from what the
+ * reference's _generate() hands to Path/Vessel/obstacles (envs/movingobstacles.py:28-95).
+ *
+ *  path      dense polyline of Path._points (path.py:38-40) + cumulative arclength (the
+ *            measure GEOS LineString.project walks), and the final PCHIP as per-interval
+ *            power-basis coefficients (path.py:26-27).
+ *  obstacles per obstacle {kind, seg_off, nseg, mover_idx} + static cull circle
+ *            (obstacles.py:108-113, :125-127); static boundary segments (obstacles.py:
+ *            101-106, :122-123) as (ax, ay, bx, by).
+ *  movers    VesselObstacle parameters and reset-time state (obstacles.py:144-215).
+ */
+typedef struct auv_world_bank {
+  int32_t n_worlds;
+  /* path */
+  const int64_t* poly_off;    /* [W+1]  vertex offsets                                  */
+  const double* poly_xy;      /* [sum P][2]                                             */
+  const double* poly_cum;     /* [sum P]   cum[j] = arclength at vertex j               */
+  const int64_t* knot_off;    /* [W+1]  knot offsets (n_k knots -> n_k-1 intervals)     */
+  const double* knot_s;       /* [sum n]                                                */
+  const double* knot_coef;    /* [sum n][8] x:c0..c3 (highest power first), y:c0..c3;
+                                  row i describes interval [s_i, s_{i+1}); last row of
+                                  each world unused                                     */
+  const double* world_scalar; /* [W][8] L, end_x, end_y, init_x, init_y, init_psi, 0, 0 */
+  /* obstacles */
+  const int64_t* obs_off;     /* [W+1]                                                  */
+  const int32_t* obs_meta;    /* [sum K][4] kind, seg_off (into seg, absolute), nseg,
+                                  mover index within the world (or -1)                  */
+  const double* obs_cull;     /* [sum K][3] cx, cy, rho (static obstacles)              */
+  int64_t n_seg;
+  const double* seg;          /* [n_seg][4] ax, ay, bx, by                              */
+  /* movers */
+  const int64_t* mv_off;      /* [W+1]                                                  */
+  const double* mv_param;     /* [sum M][4] width, pos0_x, pos0_y, n_vel                */
+  const double* mv_init;      /* [sum M][4] pos_x, pos_y, heading, counter at reset     */
+  const int64_t* mv_vtab_off; /* [sum M + 1] offsets into mv_vtab                       */
+  const double* mv_vtab;      /* [.][2] per-tick velocities (length 1 = constant)       */
+} auv_world_bank_t;
+
+typedef struct auv_handle auv_handle_t;
+
+/* Field ids for auv_read / auv_write (handle-owned device buffers, all fp64 unless noted):
+ * copies between the handle and a caller buffer, stream-ordered.  Test/debug surface. */
+enum {
+  AUV_FIELD_STATE = 0,       /* [6][N]  x, y, psi, u, v, r   (Vessel._state, SoA)          */
+  AUV_FIELD_LIDAR_D = 1,     /* [N][S]  Vessel._last_sensor_dist_measurements              */
+  AUV_FIELD_OBS64 = 2,       /* [N][6+S] observation before the float32 cast               */
+  AUV_FIELD_REWARD64 = 3,    /* [N]                                                        */
+  AUV_FIELD_INFO64 = 4,      /* [N][8] collision, reached_goal, goal_distance, progress,
+                                 cumulative_reward, max_progress, vessel_arclength, spare   */
+  AUV_FIELD_WORLD_IDX = 5,   /* [N] int32                                                  */
+  AUV_FIELD_COUNTERS = 6,    /* [N][4] int32: t_step, vessel step_counter, episodes, pad   */
+  AUV_FIELD_MOVER_STATE = 7, /* [N][Mmax][4] pos_x, pos_y, heading, counter                */
+  AUV_FIELD_NEARBY = 8,      /* [N][Kmax] uint8  cached Vessel._nearby_obstacles mask      */
+  AUV_FIELD_EPISODE = 9,     /* [N][4] last finished episode: return, length, collision,
+                                 reached_goal (fp64)                                        */
+  AUV_FIELD_CULL_LIMITS = 10,/* [N][Kmax][2] int32 idx_min_ray, idx_max_ray (sensor.py:58-69)
+                                 of the last sweep; INT32_MIN where not evaluated           */
+  AUV_FIELD_NAV64 = 11,      /* [N][8] unclipped Vessel.navigate outputs: u, v, r,
+                                 look_ahead_heading_error, heading_error, cross_track_error/100,
+                                 path_direction, target_arclength        (vessel.py:518-536) */
+  AUV_FIELD_COLLISION = 12   /* [N] uint8  Vessel._collision                                */
+};
+
+/* Create an environment batch of n_envs on device `device_id`.            (environment.py:29-164) */
+int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_handle_t** out);
+int auv_destroy(auv_handle_t* h);
+
+/* Upload a world bank (replaces any previous one).                 (BaseEnvironment._generate) */
+int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* bank);
+
+/* reset(): for every env whose mask byte is non-zero (mask_dev == NULL: all) bind it to
+ * world_idx_dev[e] (NULL: keep current binding; initial binding is e % W), restore vessel /
+ * mover state and counters, then compute the first observation.          (environment.py:176-245) */
+int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx_dev,
+              float* obs_dev, void* stream);
+
+/* step(): _update -> vessel.step -> observe -> reward -> done, for all N envs.
+ * actions_dev: [N][2] (thrust, rudder) of action_dtype AUV_F32/AUV_F64.
+ * obs_dev [N][6+S] f32, reward_dev [N] f32, done_dev [N] u8.             (environment.py:292-366) */
+int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
+             float* reward_dev, uint8_t* done_dev, void* stream);
+
+/* The three kernels of step(), individually launchable (per-kernel parity tests):        */
+/* K1  Vessel.step: clip -> RKF45 of the 3-DOF model -> wrap psi.  (vessel.py:226-247,561-578) */
+int auv_step_dynamics(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, void* stream);
+/* K2  _update (movers) + Vessel.perceive: LiDAR sweep.   (environment.py:386-392, vessel.py:249-368)
+ *     advance_movers = 0 skips the mover update (observe() at reset time).                 */
+int auv_lidar(auv_handle_t* h, int32_t advance_movers, void* stream);
+/* K3  Vessel.navigate + rewarder.calculate + _isdone + observation assembly.
+ *     (vessel.py:461-541, rewarder.py:78-241, environment.py:263-280, 325-347, 375-384)
+ *     mode 0: full; 1: navigation + observation only (reset path), no reward/done;
+ *     2: reward/done only, from NAV64 / INFO64 / LIDAR_D / COLLISION as they stand (test hook). */
+int auv_nav_reward(auv_handle_t* h, int32_t mode, float* obs_dev, float* reward_dev,
+                   uint8_t* done_dev, void* stream);
+
+/* Stream-ordered copies between handle-owned buffers and caller DEVICE buffers.           */
+int auv_read(auv_handle_t* h, int32_t field, void* dst_dev, size_t bytes, void* stream);
+int auv_write(auv_handle_t* h, int32_t field, const void* src_dev, size_t bytes, void* stream);
+/* Size in bytes of a field for this handle (0 if unknown).                                 */
+size_t auv_field_bytes(const auv_handle_t* h, int32_t field);
+
+/* Capture one auv_step into a hipGraph bound to the given I/O pointers and replay it.     */
+int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_dtype,
+                      float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+int auv_graph_launch(auv_handle_t* h, void* stream);
+
+/* Mean duration (ms) of each kernel of the last auv_step_timed call, measured with HIP
+ * events on `stream` around every launch: out_ms[0..3] = K1, K2, K3, reset-pass.           */
+int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
+                   float* reward_dev, uint8_t* done_dev, void* stream, float* out_ms4);
+
+int32_t auv_abi_version(void);
+const char* auv_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUV_HIP_H */

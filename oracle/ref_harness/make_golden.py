@@ -461,6 +461,11 @@ def gen_rollouts():
             env.seed(seed)
             np.random.seed(seed)
             random.seed(seed)
+            # First-episode semantics: scenarios whose _generate() does not build a rewarder
+            # (envs/testscenario.py) only get one on the FIRST reset (environment.py:219-224) and
+            # afterwards keep rewarding the first episode's stale Vessel object.  Clearing it makes
+            # this seeded reset behave like a fresh environment's first episode.
+            env.rewarder = None
             env.observe_cache = env.reset()
         return env
 
