@@ -1,0 +1,215 @@
+"""BatchedAuvEnv — N independent gym-auv environments advanced per call by three HIP kernels.
+
+VecEnv-shaped surface (what the reference's callers use through stable-baselines' VecEnv,
+/root/reference/scripts/run.py:293-296): `reset() -> obs[N, D]`,
+`step(actions[N, 2]) -> (obs[N, D], reward[N], done[N], info)`, auto-reset of finished
+episodes.  All tensors are torch tensors on the env's GPU; nothing is copied to the host
+inside `step`.  The per-environment semantics are those of BaseEnvironment.reset/step
+(/root/reference/gym_auv/environment.py:176-366).
+
+The HIP extension is mandatory: importing this module dlopens gym_auv_amd/csrc/libauv_hip.so
+and raises `AuvLibraryError` if it is missing.  There is no CPU or eager-PyTorch fallback.
+"""
+import ctypes as C
+from typing import Dict, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import FIELD_DTYPES, FIELDS, AuvLibraryError, load_library, make_bank_struct, make_config
+from .config import Config
+from .spaces import Box
+from .world import BuiltWorld, build_world, pack_bank
+from .worldspec import WorldSpec
+
+_LIB = load_library()   # fail loudly at import time
+
+_TORCH_DTYPES = {np.float64: torch.float64, np.int32: torch.int32, np.uint8: torch.uint8}
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, _LIB.auv_last_error().decode()))
+
+
+class BatchedAuvEnv:
+    def __init__(self, config: Config, worlds: Union[Dict[str, np.ndarray], Sequence[Union[WorldSpec, BuiltWorld]]],
+                 n_envs: int, device: Union[str, torch.device] = "cuda:0", rewarder: str = "colav",
+                 test_mode: bool = False, cull: str = "reference", auto_reset: bool = True):
+        if not torch.cuda.is_available():
+            raise AuvLibraryError("BatchedAuvEnv needs a GPU (torch.cuda.is_available() is False); "
+                                  "there is no CPU fallback")
+        self.config = config
+        self.device = torch.device(device)
+        self.n_envs = int(n_envs)
+        self.n_sensors = config.vessel.n_sensors
+        self.obs_dim = 6 + (self.n_sensors if config.vessel.use_lidar else 0)
+        self._cfg_struct = make_config(config, rewarder=rewarder, test_mode=test_mode, cull=cull,
+                                       auto_reset=auto_reset)
+        if isinstance(worlds, dict):
+            bank = worlds
+        else:
+            bank = pack_bank([w if isinstance(w, BuiltWorld) else build_world(w) for w in worlds])
+        self.n_worlds = int(bank["n_worlds"])
+        self.k_max = max(1, int(bank["k_max"]))
+        self.m_max = max(1, int(bank["m_max"]))
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _check(_LIB.auv_create(C.byref(self._cfg_struct), self.n_envs, idx, C.byref(self._h)), "auv_create")
+        bs, keep = make_bank_struct(bank)
+        _check(_LIB.auv_load_worlds(self._h, C.byref(bs)), "auv_load_worlds")
+        del keep
+        # observation_space / action_space exactly as environment.py:101-106, :139-143
+        self.action_space = Box(low=np.array([-1, -0.15]), high=np.array([1, 0.15]), dtype=np.float32)
+        self.observation_space = Box(low=np.array([-1] * self.obs_dim), high=np.array([1] * self.obs_dim),
+                                     dtype=np.float32)
+        with torch.cuda.device(self.device):
+            self.obs = torch.zeros((self.n_envs, self.obs_dim), dtype=torch.float32, device=self.device)
+            self.reward = torch.zeros((self.n_envs,), dtype=torch.float32, device=self.device)
+            self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
+        self._graph_actions = None
+
+    # ------------------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _act(self, actions: torch.Tensor):
+        if actions.device != self.device:
+            actions = actions.to(self.device)
+        if actions.dtype not in (torch.float32, torch.float64):
+            actions = actions.to(torch.float32)
+        actions = actions.contiguous()
+        if tuple(actions.shape) != (self.n_envs, 2):
+            raise ValueError("actions must have shape (%d, 2), got %s" % (self.n_envs, tuple(actions.shape)))
+        return actions, (_capi.AUV_F64 if actions.dtype == torch.float64 else _capi.AUV_F32)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _LIB.auv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------ gym-like API
+    def reset(self, mask: Optional[torch.Tensor] = None, world_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            assert m.numel() == self.n_envs
+        wi = None
+        if world_idx is not None:
+            wi = torch.as_tensor(world_idx).to(device=self.device, dtype=torch.int32).contiguous()
+            assert wi.numel() == self.n_envs
+            assert int(wi.min()) >= 0 and int(wi.max()) < self.n_worlds, "world index out of range"
+        _check(_LIB.auv_reset(self._h, None if m is None else C.c_void_p(m.data_ptr()),
+                              None if wi is None else C.c_void_p(wi.data_ptr()),
+                              C.c_void_p(self.obs.data_ptr()), self._stream()), "auv_reset")
+        return self.obs
+
+    def step(self, actions: torch.Tensor):
+        a, dt = self._act(actions)
+        _check(_LIB.auv_step(self._h, C.c_void_p(a.data_ptr()), dt, C.c_void_p(self.obs.data_ptr()),
+                             C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                             self._stream()), "auv_step")
+        return self.obs, self.reward, self.done, self._lazy_info()
+
+    def _lazy_info(self):
+        return _LazyInfo(self)
+
+    # per-kernel entry points (parity tests)
+    def step_dynamics(self, actions: torch.Tensor):
+        a, dt = self._act(actions)
+        _check(_LIB.auv_step_dynamics(self._h, C.c_void_p(a.data_ptr()), dt, self._stream()), "auv_step_dynamics")
+
+    def lidar(self, advance_movers: bool = True):
+        _check(_LIB.auv_lidar(self._h, int(advance_movers), self._stream()), "auv_lidar")
+
+    def nav_reward(self, mode: int = 0):
+        _check(_LIB.auv_nav_reward(self._h, int(mode), C.c_void_p(self.obs.data_ptr()),
+                                   C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                                   self._stream()), "auv_nav_reward")
+        return self.done
+
+    # hipGraph: capture once (fixed action buffer), replay per step
+    def capture_graph(self, dtype=torch.float32):
+        self._graph_actions = torch.zeros((self.n_envs, 2), dtype=dtype, device=self.device)
+        dt = _capi.AUV_F64 if dtype == torch.float64 else _capi.AUV_F32
+        torch.cuda.synchronize(self.device)
+        _check(_LIB.auv_graph_capture(self._h, C.c_void_p(self._graph_actions.data_ptr()), dt,
+                                      C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
+                                      C.c_void_p(self.done.data_ptr()), self._stream()), "auv_graph_capture")
+        return self._graph_actions
+
+    def step_graph(self, actions: Optional[torch.Tensor] = None):
+        if self._graph_actions is None:
+            raise RuntimeError("capture_graph() first")
+        if actions is not None:
+            self._graph_actions.copy_(actions)
+        _check(_LIB.auv_graph_launch(self._h, self._stream()), "auv_graph_launch")
+        return self.obs, self.reward, self.done, self._lazy_info()
+
+    def step_timed(self, actions: torch.Tensor):
+        """One step with HIP events around each kernel; returns ms for (K1, K2, K3, reset pass)."""
+        a, dt = self._act(actions)
+        ms = (C.c_float * 4)()
+        _check(_LIB.auv_step_timed(self._h, C.c_void_p(a.data_ptr()), dt, C.c_void_p(self.obs.data_ptr()),
+                                   C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                                   self._stream(), ms), "auv_step_timed")
+        return [float(x) for x in ms]
+
+    # ------------------------------------------------------------------------------ field access
+    def field_shape(self, name: str):
+        n, S = self.n_envs, self.n_sensors
+        return dict(STATE=(6, n), LIDAR_D=(n, S), OBS64=(n, 6 + S), REWARD64=(n,), INFO64=(n, 8),
+                    WORLD_IDX=(n,), COUNTERS=(n, 4), MOVER_STATE=(n, self.m_max, 4), NEARBY=(n, self.k_max),
+                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,))[name]
+
+    def read(self, name: str) -> torch.Tensor:
+        t = torch.empty(self.field_shape(name), dtype=_TORCH_DTYPES[FIELD_DTYPES[name]], device=self.device)
+        nbytes = t.numel() * t.element_size()
+        _check(_LIB.auv_read(self._h, FIELDS[name], C.c_void_p(t.data_ptr()), nbytes, self._stream()),
+               "auv_read(%s)" % name)
+        return t
+
+    def write(self, name: str, value):
+        t = torch.as_tensor(value).to(device=self.device, dtype=_TORCH_DTYPES[FIELD_DTYPES[name]]).contiguous()
+        t = t.reshape(self.field_shape(name))
+        nbytes = t.numel() * t.element_size()
+        _check(_LIB.auv_write(self._h, FIELDS[name], C.c_void_p(t.data_ptr()), nbytes, self._stream()),
+               "auv_write(%s)" % name)
+        torch.cuda.current_stream(self.device).synchronize()   # `t` may be a temporary
+
+    def episode_stats(self) -> Dict[str, torch.Tensor]:
+        ep = self.read("EPISODE")
+        cnt = self.read("COUNTERS")
+        return dict(episode_return=ep[:, 0], episode_length=ep[:, 1], collision=ep[:, 2], reached_goal=ep[:, 3],
+                    episodes=cnt[:, 2])
+
+
+class _LazyInfo(dict):
+    """info of the batched step: tensors fetched from the device only when a key is read
+    (keys as environment.py:336-340)."""
+    _KEYS = {"collision": 0, "reached_goal": 1, "goal_distance": 2, "progress": 3,
+             "cumulative_reward": 4, "max_progress": 5, "vessel_arclength": 6}
+
+    def __init__(self, env):
+        super().__init__()
+        self._env = env
+        self._info = None
+
+    def __missing__(self, key):
+        if key not in self._KEYS:
+            raise KeyError(key)
+        if self._info is None:
+            self._info = self._env.read("INFO64")
+        v = self._info[:, self._KEYS[key]]
+        self[key] = v
+        return v
+
+    def keys(self):
+        return self._KEYS.keys()

@@ -1,0 +1,365 @@
+// auv_capi.hip — host side of the C ABI declared in include/auv_hip.h.
+// Owns device memory (environment state, world bank), launches K1/K2/K3 on the caller's
+// stream, and exposes hipGraph capture and per-kernel HIP-event timing.  No exceptions cross
+// the ABI; errors are reported by code + auv_last_error().
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "auv_device.h"
+
+void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st);
+void auv_launch_k2(const AuvDev& d, int advance_movers, int only_fresh, hipStream_t st);
+void auv_launch_k3(const AuvDev& d, int mode, int only_fresh, float* obs, float* reward, uint8_t* done,
+                   hipStream_t st);
+void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, hipStream_t st);
+size_t auv_k2_lds_bytes(const AuvDev& d);
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) return fail(AUV_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                      __FILE__, __LINE__);                                    \
+  } while (0)
+
+struct auv_handle {
+  AuvDev d;
+  int device;
+  bool worlds_loaded;
+  std::vector<void*> env_allocs, bank_allocs;
+  hipStream_t cap_stream;
+  hipGraph_t graph;
+  hipGraphExec_t graph_exec;
+  hipEvent_t ev[6];
+};
+
+template <typename T>
+static int dev_alloc(std::vector<void*>& pool, T** out, size_t count) {
+  void* p = nullptr;
+  size_t bytes = (count ? count : 1) * sizeof(T);
+  HIP_TRY(hipMalloc(&p, bytes));
+  HIP_TRY(hipMemset(p, 0, bytes));
+  pool.push_back(p);
+  *out = (T*)p;
+  return AUV_OK;
+}
+
+template <typename T, typename U>
+static int dev_upload(std::vector<void*>& pool, const T** out, const U* host, size_t count_T) {
+  T* p = nullptr;
+  int rc = dev_alloc(pool, &p, count_T);
+  if (rc) return rc;
+  if (count_T) HIP_TRY(hipMemcpy(p, host, count_T * sizeof(T), hipMemcpyHostToDevice));
+  *out = p;
+  return AUV_OK;
+}
+
+static void free_pool(std::vector<void*>& pool) {
+  for (void* p : pool) (void)hipFree(p);
+  pool.clear();
+}
+
+extern "C" {
+
+int32_t auv_abi_version(void) { return AUV_ABI_VERSION; }
+const char* auv_last_error(void) { return g_err; }
+
+int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_handle_t** out) {
+  if (!cfg || !out || n_envs <= 0) return fail(AUV_EINVAL, "auv_create: bad arguments");
+  if (cfg->n_sensors < 0 || cfg->n_sensors > 4096) return fail(AUV_EINVAL, "n_sensors out of range");
+  if (cfg->sensor_interval_load_obstacles <= 0) return fail(AUV_EINVAL, "sensor_interval_load_obstacles <= 0");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(AUV_EINVAL, "device %d not present (%d visible)", device_id, ndev);
+  HIP_TRY(hipSetDevice(device_id));
+  auv_handle* h = new auv_handle();
+  memset(&h->d, 0, sizeof(h->d));
+  h->d.cfg = *cfg;
+  h->d.n = n_envs;
+  h->device = device_id;
+  h->worlds_loaded = false;
+  h->graph = nullptr;
+  h->graph_exec = nullptr;
+  h->cap_stream = nullptr;
+  for (auto& e : h->ev) e = nullptr;
+  *out = h;
+  return AUV_OK;
+}
+
+int auv_destroy(auv_handle_t* h) {
+  if (!h) return AUV_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  free_pool(h->env_allocs);
+  free_pool(h->bank_allocs);
+  delete h;
+  return AUV_OK;
+}
+
+int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
+  if (!h || !b || b->n_worlds <= 0) return fail(AUV_EINVAL, "auv_load_worlds: bad arguments");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  free_pool(h->bank_allocs);
+  free_pool(h->env_allocs);
+  AuvDev& d = h->d;
+  const int W = b->n_worlds;
+  const size_t n = (size_t)d.n, S = (size_t)d.cfg.n_sensors;
+  // host-side validation of every offset the kernels will trust
+  int k_max = 1, m_max = 1;
+  const int64_t nP = b->poly_off[W], nK = b->knot_off[W], nO = b->obs_off[W], nM = b->mv_off[W];
+  for (int w = 0; w < W; w++) {
+    int64_t P = b->poly_off[w + 1] - b->poly_off[w], kn = b->knot_off[w + 1] - b->knot_off[w];
+    int64_t K = b->obs_off[w + 1] - b->obs_off[w], M = b->mv_off[w + 1] - b->mv_off[w];
+    if (P < 2 || kn < 2 || K < 0 || M < 0) return fail(AUV_EINVAL, "world %d: degenerate path/obstacle tables", w);
+    if (!(b->world_scalar[8 * (size_t)w] > 0.0)) return fail(AUV_EINVAL, "world %d: path length <= 0", w);
+    if (K > k_max) k_max = (int)K;
+    if (M > m_max) m_max = (int)M;
+    for (int64_t k = b->obs_off[w]; k < b->obs_off[w + 1]; k++) {
+      const int32_t* meta = b->obs_meta + 4 * k;
+      if (meta[0] == AUV_OBS_MOVER) {
+        if (meta[3] < 0 || meta[3] >= M || meta[2] != AUV_MOVER_NSEG) return fail(AUV_EINVAL, "world %d: bad mover meta", w);
+      } else if (meta[0] == AUV_OBS_RING || meta[0] == AUV_OBS_FILLED) {
+        if (meta[1] < 0 || meta[2] < 1 || (int64_t)meta[1] + meta[2] > b->n_seg)
+          return fail(AUV_EINVAL, "world %d: segment range out of bounds", w);
+      } else {
+        return fail(AUV_EINVAL, "world %d: unknown obstacle kind %d", w, meta[0]);
+      }
+    }
+  }
+  for (int64_t m = 0; m < nM; m++) {
+    if (b->mv_vtab_off[m + 1] - b->mv_vtab_off[m] < 1) return fail(AUV_EINVAL, "mover %lld: empty velocity table", (long long)m);
+    if (!(b->mv_param[4 * m + 3] >= 2.0)) return fail(AUV_EINVAL, "mover %lld: n_vel < 2", (long long)m);
+  }
+  d.n_worlds = W;
+  d.k_max = k_max;
+  d.m_max = m_max;
+  int rc = 0;
+  auto& bp = h->bank_allocs;
+  rc |= dev_upload(bp, &d.poly_off, b->poly_off, (size_t)W + 1);
+  rc |= dev_upload(bp, &d.poly_xy, b->poly_xy, (size_t)nP);
+  rc |= dev_upload(bp, &d.poly_cum, b->poly_cum, (size_t)nP);
+  rc |= dev_upload(bp, &d.knot_off, b->knot_off, (size_t)W + 1);
+  rc |= dev_upload(bp, &d.knot_s, b->knot_s, (size_t)nK);
+  rc |= dev_upload(bp, &d.knot_coef, b->knot_coef, (size_t)nK * 8);
+  rc |= dev_upload(bp, &d.world_scalar, b->world_scalar, (size_t)W * 8);
+  rc |= dev_upload(bp, &d.obs_off, b->obs_off, (size_t)W + 1);
+  rc |= dev_upload(bp, &d.obs_meta, b->obs_meta, (size_t)nO);
+  rc |= dev_upload(bp, &d.obs_cull, b->obs_cull, (size_t)nO * 3);
+  rc |= dev_upload(bp, &d.seg, b->seg, (size_t)b->n_seg);
+  rc |= dev_upload(bp, &d.mv_off, b->mv_off, (size_t)W + 1);
+  rc |= dev_upload(bp, &d.mv_param, b->mv_param, (size_t)nM);
+  rc |= dev_upload(bp, &d.mv_init, b->mv_init, (size_t)nM);
+  rc |= dev_upload(bp, &d.mv_vtab_off, b->mv_vtab_off, (size_t)nM + 1);
+  rc |= dev_upload(bp, &d.mv_vtab, b->mv_vtab, (size_t)b->mv_vtab_off[nM]);
+  if (rc) return AUV_EHIP;
+  auto& ep = h->env_allocs;
+  rc |= dev_alloc(ep, &d.state, 6 * n);
+  rc |= dev_alloc(ep, &d.world_idx, n);
+  rc |= dev_alloc(ep, &d.counters, n);
+  rc |= dev_alloc(ep, &d.lidar_d, n * S);
+  rc |= dev_alloc(ep, &d.obs64, n * (6 + S));
+  rc |= dev_alloc(ep, &d.reward64, n);
+  rc |= dev_alloc(ep, &d.info64, n * 8);
+  rc |= dev_alloc(ep, &d.nav64, n * 8);
+  rc |= dev_alloc(ep, &d.mover, n * m_max);
+  rc |= dev_alloc(ep, &d.nearby, n * k_max);
+  rc |= dev_alloc(ep, &d.episode, n * 4);
+  rc |= dev_alloc(ep, &d.limits, n * k_max);
+  rc |= dev_alloc(ep, &d.collision, n);
+  if (rc) return AUV_EHIP;
+  std::vector<int32_t> wi(n);
+  for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(e % (size_t)W);
+  HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds 160 KiB", auv_k2_lds_bytes(d));
+  if (h->graph_exec) {
+    (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+  }
+  h->worlds_loaded = true;
+  return AUV_OK;
+}
+
+#define REQUIRE_READY(h)                                                          \
+  do {                                                                            \
+    if (!(h)) return fail(AUV_EINVAL, "null handle");                             \
+    if (!(h)->worlds_loaded) return fail(AUV_ESTATE, "auv_load_worlds not called"); \
+  } while (0)
+
+int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx_dev, float* obs_dev, void* stream) {
+  REQUIRE_READY(h);
+  hipStream_t st = (hipStream_t)stream;
+  auv_launch_reset(h->d, mask_dev, world_idx_dev, st);
+  auv_launch_k2(h->d, 0, 1, st);
+  auv_launch_k3(h->d, 1, 1, obs_dev, nullptr, nullptr, st);
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+static void enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, float* obs, float* reward, uint8_t* done,
+                         hipStream_t st) {
+  auv_launch_k1(h->d, actions, dtype, st);
+  auv_launch_k2(h->d, 1, 0, st);
+  auv_launch_k3(h->d, 0, 0, obs, reward, done, st);
+  if (h->d.cfg.auto_reset) {
+    auv_launch_k2(h->d, 0, 1, st);
+    auv_launch_k3(h->d, 1, 1, obs, nullptr, nullptr, st);
+  }
+}
+
+int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
+             uint8_t* done_dev, void* stream) {
+  REQUIRE_READY(h);
+  if (!actions_dev) return fail(AUV_EINVAL, "auv_step: null actions");
+  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_step: bad action dtype");
+  enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_step_dynamics(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, void* stream) {
+  REQUIRE_READY(h);
+  if (!actions_dev) return fail(AUV_EINVAL, "auv_step_dynamics: null actions");
+  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "bad action dtype");
+  auv_launch_k1(h->d, actions_dev, action_dtype, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_lidar(auv_handle_t* h, int32_t advance_movers, void* stream) {
+  REQUIRE_READY(h);
+  auv_launch_k2(h->d, advance_movers ? 1 : 0, 0, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_nav_reward(auv_handle_t* h, int32_t mode, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
+  REQUIRE_READY(h);
+  if (mode < 0 || mode > 2) return fail(AUV_EINVAL, "auv_nav_reward: mode must be 0, 1 or 2");
+  auv_launch_k3(h->d, mode, 0, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
+  if (mode == 0 && h->d.cfg.auto_reset) {
+    auv_launch_k2(h->d, 0, 1, (hipStream_t)stream);
+    auv_launch_k3(h->d, 1, 1, obs_dev, nullptr, nullptr, (hipStream_t)stream);
+  }
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+static void* field_ptr(const auv_handle_t* h, int32_t field, size_t* bytes) {
+  const AuvDev& d = h->d;
+  const size_t n = (size_t)d.n, S = (size_t)d.cfg.n_sensors;
+  switch (field) {
+    case AUV_FIELD_STATE: *bytes = 8 * 6 * n; return d.state;
+    case AUV_FIELD_LIDAR_D: *bytes = 8 * n * S; return d.lidar_d;
+    case AUV_FIELD_OBS64: *bytes = 8 * n * (6 + S); return d.obs64;
+    case AUV_FIELD_REWARD64: *bytes = 8 * n; return d.reward64;
+    case AUV_FIELD_INFO64: *bytes = 8 * 8 * n; return d.info64;
+    case AUV_FIELD_WORLD_IDX: *bytes = 4 * n; return d.world_idx;
+    case AUV_FIELD_COUNTERS: *bytes = 16 * n; return d.counters;
+    case AUV_FIELD_MOVER_STATE: *bytes = 32 * n * d.m_max; return d.mover;
+    case AUV_FIELD_NEARBY: *bytes = n * d.k_max; return d.nearby;
+    case AUV_FIELD_EPISODE: *bytes = 8 * 4 * n; return d.episode;
+    case AUV_FIELD_CULL_LIMITS: *bytes = 8 * n * d.k_max; return d.limits;
+    case AUV_FIELD_NAV64: *bytes = 8 * 8 * n; return d.nav64;
+    case AUV_FIELD_COLLISION: *bytes = n; return d.collision;
+  }
+  *bytes = 0;
+  return nullptr;
+}
+
+size_t auv_field_bytes(const auv_handle_t* h, int32_t field) {
+  if (!h || !h->worlds_loaded) return 0;
+  size_t b = 0;
+  field_ptr(h, field, &b);
+  return b;
+}
+
+int auv_read(auv_handle_t* h, int32_t field, void* dst_dev, size_t bytes, void* stream) {
+  REQUIRE_READY(h);
+  size_t b = 0;
+  void* p = field_ptr(h, field, &b);
+  if (!p || !dst_dev || bytes != b) return fail(AUV_EINVAL, "auv_read: field %d expects %zu bytes, got %zu", field, b, bytes);
+  HIP_TRY(hipMemcpyAsync(dst_dev, p, b, hipMemcpyDefault, (hipStream_t)stream));
+  return AUV_OK;
+}
+
+int auv_write(auv_handle_t* h, int32_t field, const void* src_dev, size_t bytes, void* stream) {
+  REQUIRE_READY(h);
+  size_t b = 0;
+  void* p = field_ptr(h, field, &b);
+  if (!p || !src_dev || bytes != b) return fail(AUV_EINVAL, "auv_write: field %d expects %zu bytes, got %zu", field, b, bytes);
+  HIP_TRY(hipMemcpyAsync(p, src_dev, b, hipMemcpyDefault, (hipStream_t)stream));
+  return AUV_OK;
+}
+
+int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
+                      float* reward_dev, uint8_t* done_dev, void* stream) {
+  REQUIRE_READY(h);
+  (void)stream;
+  if (!actions_dev) return fail(AUV_EINVAL, "auv_graph_capture: null actions");
+  if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+  if (h->graph_exec) {
+    HIP_TRY(hipGraphExecDestroy(h->graph_exec));
+    h->graph_exec = nullptr;
+  }
+  if (h->graph) {
+    HIP_TRY(hipGraphDestroy(h->graph));
+    h->graph = nullptr;
+  }
+  HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+  enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream);
+  HIP_TRY(hipStreamEndCapture(h->cap_stream, &h->graph));
+  HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+  return AUV_OK;
+}
+
+int auv_graph_launch(auv_handle_t* h, void* stream) {
+  REQUIRE_READY(h);
+  if (!h->graph_exec) return fail(AUV_ESTATE, "auv_graph_launch: no captured graph");
+  HIP_TRY(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
+  return AUV_OK;
+}
+
+int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
+                   uint8_t* done_dev, void* stream, float* out_ms4) {
+  REQUIRE_READY(h);
+  if (!actions_dev || !out_ms4) return fail(AUV_EINVAL, "auv_step_timed: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (auto& e : h->ev)
+    if (!e) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipEventRecord(h->ev[0], st));
+  auv_launch_k1(h->d, actions_dev, action_dtype, st);
+  HIP_TRY(hipEventRecord(h->ev[1], st));
+  auv_launch_k2(h->d, 1, 0, st);
+  HIP_TRY(hipEventRecord(h->ev[2], st));
+  auv_launch_k3(h->d, 0, 0, obs_dev, reward_dev, done_dev, st);
+  HIP_TRY(hipEventRecord(h->ev[3], st));
+  if (h->d.cfg.auto_reset) {
+    auv_launch_k2(h->d, 0, 1, st);
+    auv_launch_k3(h->d, 1, 1, obs_dev, nullptr, nullptr, st);
+  }
+  HIP_TRY(hipEventRecord(h->ev[4], st));
+  HIP_TRY(hipEventSynchronize(h->ev[4]));
+  for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[i], h->ev[i + 1]));
+  return AUV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// auv_device.h — device-side data layout and small fp64 helpers shared by the three kernels.
+// gfx950 (MI355X) only.  All arithmetic is IEEE fp64 with contraction off (Makefile:
+// -ffp-contract=off) so that results agree with the CPU oracle / the fp64 NumPy reference to
+// ~1e-12 and the integer flags (collision, reached_goal, done) are bit-exact in practice.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/auv_hip.h"
+
+#define AUV_PI 3.141592653589793
+#define AUV_WAVE 64
+#define AUV_BLOCK 256          // 4 waves per environment-workgroup (K2, K3)
+#define AUV_MOVER_NSEG 5
+
+// Everything the kernels read, by value in the kernel argument buffer (no constant memory,
+// no host round trip; hipGraph-capturable).
+struct AuvDev {
+  auv_config_t cfg;
+  int32_t n;        // environments
+  int32_t n_worlds;
+  int32_t k_max, m_max;
+  // ---- world bank (HBM, read-only during step) ----
+  const int64_t* poly_off;
+  const double2* poly_xy;
+  const double* poly_cum;
+  const int64_t* knot_off;
+  const double* knot_s;
+  const double* knot_coef;     // [.][8]
+  const double* world_scalar;  // [W][8]
+  const int64_t* obs_off;
+  const int4* obs_meta;        // kind, seg_off, nseg, mover idx
+  const double* obs_cull;      // [.][3]
+  const double4* seg;          // ax, ay, bx, by
+  const int64_t* mv_off;
+  const double4* mv_param;     // width, pos0x, pos0y, n_vel
+  const double4* mv_init;      // px, py, heading, counter
+  const int64_t* mv_vtab_off;
+  const double2* mv_vtab;
+  // ---- environment state (HBM, SoA where per-env scalars) ----
+  double* state;       // [6][N]
+  int32_t* world_idx;  // [N]
+  int4* counters;      // [N] t_step, step_counter, episodes, fresh-flag
+  double* lidar_d;     // [N][S]
+  double* obs64;       // [N][6+S]
+  double* reward64;    // [N]
+  double* info64;      // [N][8]
+  double* nav64;       // [N][8]
+  double4* mover;      // [N][Mmax]
+  uint8_t* nearby;     // [N][Kmax]
+  double* episode;     // [N][4]
+  int2* limits;        // [N][Kmax]
+  uint8_t* collision;  // [N]
+};
+
+__device__ __forceinline__ double auv_princip(double a) {
+  // ((a + pi) % (2 pi)) - pi with Python's sign convention (utils/geomutils.py:4-5)
+  double m = fmod(a + AUV_PI, 2.0 * AUV_PI);
+  if (m < 0.0) m += 2.0 * AUV_PI;
+  return m - AUV_PI;
+}
+
+__device__ __forceinline__ double auv_clip(double x, double lo, double hi) {
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+
+// JTS/GEOS Distance::pointToSegment (what Point.distance / LineString.project evaluate)
+__device__ __forceinline__ double auv_pt_seg_dist(double px, double py, double ax, double ay, double bx,
+                                                  double by) {
+  double dxa = px - ax, dya = py - ay;
+  if (ax == bx && ay == by) return sqrt(dxa * dxa + dya * dya);
+  double ex = bx - ax, ey = by - ay;
+  double len2 = ex * ex + ey * ey;
+  double r = (dxa * ex + dya * ey) / len2;
+  if (r <= 0.0) return sqrt(dxa * dxa + dya * dya);
+  if (r >= 1.0) {
+    double dxb = px - bx, dyb = py - by;
+    return sqrt(dxb * dxb + dyb * dyb);
+  }
+  double s = ((ay - py) * ex - (ax - px) * ey) / len2;
+  return fabs(s) * sqrt(len2);
+}
+
+// Python floor-mod for ints (list index wrap in sensor.py:93-95)
+__device__ __forceinline__ int auv_pymod(long long a, int s) {
+  long long r = a % (long long)s;
+  return (int)(r < 0 ? r + s : r);
+}
+
+// wave64 reductions through DPP/permute shuffles
+__device__ __forceinline__ double auv_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, AUV_WAVE);
+  return v;
+}

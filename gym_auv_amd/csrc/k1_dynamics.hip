@@ -1,0 +1,103 @@
+// K1 — vessel dynamics: one thread advances one environment's 6-state 3-DOF model by one
+// Runge-Kutta-Fehlberg step (the 5th-order combination `q`), SoA state in HBM.
+//
+// Reference: Vessel.step            gym_auv/objects/vessel/vessel.py:226-247
+//            _thrust_surge/_moment_steer                 vessel.py:572-578
+//            _state_dot                                  vessel.py:561-570
+//            odesolver45                objects/vessel/odesolver.py:2-47
+//            M, D, N(nu)                utils/constants.py:33-43, 63-72
+//            NaN action -> zeros        environment.py:314-315
+// Roofline: HBM.  Algorithmic traffic per env-step: 6 fp64 state in + 6 out + 2 action
+// values (8 or 16 B) + one int4 counter r/w = 136..144 B; ~500 flop and 12 sin/cos.
+#include "auv_device.h"
+
+namespace {
+
+struct Vec6 {
+  double v[6];
+};
+
+__device__ __forceinline__ Vec6 state_dot(const Vec6& y, double tau_u, double tau_r) {
+  // constants.py:4-16
+  const double m = 23.8, x_g = 0.046, I_z = 1.760, X_udot = -2.0, Y_vdot = -10.0, Y_rdot = 0.0,
+               N_rdot = -1.0, N_vdot = 0.0, X_u = -2.0, Y_v = -7.0, Y_r = -0.1, N_v = -0.1, N_r = -0.5;
+  const double m11 = m - X_udot, m22 = m - Y_vdot, m23 = m * x_g - Y_rdot, m32 = m * x_g - N_vdot,
+               m33 = I_z - N_rdot;
+  const double det = m22 * m33 - m23 * m32;
+  const double i11 = 1.0 / m11, i22 = m33 / det, i23 = -m23 / det, i32 = -m32 / det, i33 = m22 / det;
+  double psi = auv_princip(y.v[2]);
+  double s, c;
+  sincos(psi, &s, &c);
+  double u = y.v[3], v = y.v[4], r = y.v[5];
+  Vec6 o;
+  o.v[0] = c * u + -s * v;   // Rz(psi).dot(nu), geomutils.py:37-43
+  o.v[1] = s * u + c * v;
+  o.v[2] = r;
+  double d0 = 2.0 * u;                       // D.dot(nu)
+  double d1 = 7.0 * v + -2.5425 * r;
+  double d2 = -2.5425 * v + 1.422 * r;
+  double n0 = -X_u * u;                      // N(nu).dot(nu)
+  double n1 = -Y_v * v + (m * u - Y_r) * r;
+  double n2 = -N_v * v + (m * x_g * u - N_r) * r;
+  double r0 = tau_u - d0 - n0, r1 = 0.0 - d1 - n1, r2 = tau_r - d2 - n2;
+  o.v[3] = i11 * r0;                          // M_inv.dot(...)
+  o.v[4] = i22 * r1 + i23 * r2;
+  o.v[5] = i32 * r1 + i33 * r2;
+  return o;
+}
+
+template <typename AT>
+__global__ void __launch_bounds__(AUV_WAVE) k1_dynamics(AuvDev d, const AT* __restrict__ actions) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.n) return;
+  const size_t n = (size_t)d.n;
+  double a0 = (double)actions[2 * (size_t)e], a1 = (double)actions[2 * (size_t)e + 1];
+  if (isnan(a0) || isnan(a1)) a0 = a1 = 0.0;
+  const double tu = auv_clip(a0, 0.0, 1.0) * d.cfg.thrust_max;
+  const double tr = auv_clip(a1, -1.0, 1.0) * d.cfg.moment_max;
+  const double h = d.cfg.dt;
+  Vec6 y, t;
+#pragma unroll
+  for (int i = 0; i < 6; i++) y.v[i] = d.state[i * n + e];
+
+  Vec6 s1 = state_dot(y, tu, tr);
+#pragma unroll
+  for (int i = 0; i < 6; i++) t.v[i] = y.v[i] + h * s1.v[i] / 4.0;
+  Vec6 s2 = state_dot(t, tu, tr);
+#pragma unroll
+  for (int i = 0; i < 6; i++) t.v[i] = y.v[i] + 3.0 * h * s1.v[i] / 32.0 + 9.0 * h * s2.v[i] / 32.0;
+  Vec6 s3 = state_dot(t, tu, tr);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+    t.v[i] = y.v[i] + 1932.0 * h * s1.v[i] / 2197.0 - 7200.0 * h * s2.v[i] / 2197.0 +
+             7296.0 * h * s3.v[i] / 2197.0;
+  Vec6 s4 = state_dot(t, tu, tr);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+    t.v[i] = y.v[i] + 439.0 * h * s1.v[i] / 216.0 - 8.0 * h * s2.v[i] + 3680.0 * h * s3.v[i] / 513.0 -
+             845.0 * h * s4.v[i] / 4104.0;
+  Vec6 s5 = state_dot(t, tu, tr);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+    t.v[i] = y.v[i] - 8.0 * h * s1.v[i] / 27.0 + 2 * h * s2.v[i] - 3544.0 * h * s3.v[i] / 2565 +
+             1859.0 * h * s4.v[i] / 4104.0 - 11.0 * h * s5.v[i] / 40.0;
+  Vec6 s6 = state_dot(t, tu, tr);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+    t.v[i] = y.v[i] + h * (16.0 * s1.v[i] / 135.0 + 6656.0 * s3.v[i] / 12825.0 +
+                           28561.0 * s4.v[i] / 56430.0 - 9.0 * s5.v[i] / 50.0 + 2.0 * s6.v[i] / 55.0);
+  t.v[2] = auv_princip(t.v[2]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) d.state[i * n + e] = t.v[i];
+  d.counters[e].y += 1;   // Vessel._step_counter (vessel.py:247)
+}
+
+}  // namespace
+
+void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st) {
+  dim3 grid((d.n + AUV_WAVE - 1) / AUV_WAVE), block(AUV_WAVE);
+  if (dtype == AUV_F64)
+    hipLaunchKernelGGL(k1_dynamics<double>, grid, block, 0, st, d, (const double*)actions);
+  else
+    hipLaunchKernelGGL(k1_dynamics<float>, grid, block, 0, st, d, (const float*)actions);
+}

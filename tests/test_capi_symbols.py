@@ -1,0 +1,65 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every symbol declared in
+include/auv_hip.h, and the ctypes struct layouts agree with the header (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from gym_auv_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "auv_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(auv_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_list_the_same_symbols():
+    assert _declared_symbols() == sorted(_capi.EXPORTED_SYMBOLS)
+
+
+def test_library_loads_and_exports_all_symbols():
+    if not os.path.exists(_capi.LIB_PATH):
+        pytest.fail("libauv_hip.so not built: run __graft_entry__.build()")
+    lib = _capi.load_library()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.auv_abi_version() == _capi.ABI_VERSION
+    assert lib.auv_last_error() is not None
+
+
+def test_struct_sizes_match_header(tmp_path):
+    """sizeof() from the real header (compiled with gcc) == the ctypes mirrors."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu\\n", '
+                   'sizeof(auv_config_t), sizeof(auv_world_bank_t));return 0;}\n'
+                   % os.path.join(ROOT, "include", "auv_hip.h"))
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    a, b = map(int, subprocess.check_output([str(exe)]).split())
+    assert C.sizeof(_capi.AuvConfig) == a == 9 * 8 + 10 * 4
+    assert C.sizeof(_capi.AuvWorldBank) == b
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_capi.AuvLibraryError):
+        saved = _capi._lib
+        try:
+            _capi._lib = None
+            _capi.load_library(str(tmp_path / "nope.so"))
+        finally:
+            _capi._lib = saved
+
+
+def test_product_never_imports_the_oracle():
+    """The product package must not reference oracle/ (no CPU fallback through the checker)."""
+    pkg = os.path.join(ROOT, "gym_auv_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "auv_oracle" not in txt and "import oracle" not in txt, f

@@ -1,0 +1,264 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the reference goldens.
+
+Tolerances: the north star asks for 1e-5 (fp32); the path computes in fp64, so the bounds
+used here are much tighter: 1e-9 on states/ranges/observations (fp64 fields), float32
+rounding (<= 6e-8 relative) on the float32 outputs; collision / reached_goal / done and the
+integer cull windows are compared bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+from gym_auv_amd._capi import make_config
+from gym_auv_amd.config import Config, effective_reference_config
+from gym_auv_amd.scenarios import moving_obstacles_world, polygon_world, static_circles_world
+from gym_auv_amd.world import build_world, pack_bank
+from gym_auv_amd.worldspec import WorldSpec, unpack_world
+from helpers import cfg_from_scalars, load, scene_order, scene_world
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-9
+
+
+def _env(cfg, bank, n, **kw):
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    return BatchedAuvEnv(cfg, bank, n, device="cuda:0", **kw)
+
+
+def _oracle(cfg, bank, n, **kw):
+    from oracle.pyoracle import Oracle
+    return Oracle(make_config(cfg, **kw), n, bank)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def empty_bank():
+    return pack_bank([build_world(moving_obstacles_world(0, 0, 0))])
+
+
+# ------------------------------------------------------------------------------- K1 dynamics
+@pytest.mark.parametrize("dt", [0.5, 1.0])
+def test_k1_dynamics_vs_reference_golden(dt, empty_bank):
+    z = load("g1_dynamics.npz")
+    sel = z["dt"] == dt
+    cfg = effective_reference_config()
+    cfg.simulation.t_step_size = dt
+    env = _env(cfg, empty_bank, int(sel.sum()), auto_reset=False)
+    env.reset()
+    env.write("STATE", z["state"][sel].T)
+    env.step_dynamics(torch.as_tensor(z["action"][sel], device="cuda:0"))
+    out = _np(env.read("STATE")).T
+    ref = z["next_state"][sel]
+    np.testing.assert_allclose(out[:, 2:], ref[:, 2:], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out[:, :2], ref[:, :2], rtol=0, atol=1e-11)
+    assert (out[:, 2] >= -np.pi).all() and (out[:, 2] < np.pi).all()
+
+
+def test_k1_nan_guard_and_f32_actions(empty_bank):
+    cfg = effective_reference_config()
+    env = _env(cfg, empty_bank, 4, auto_reset=False)
+    ora = _oracle(cfg, empty_bank, 4)
+    env.reset(), ora.reset()
+    a = np.array([[np.nan, 0.1], [0.3, np.nan], [0.0, 0.0], [0.7, -0.2]], dtype=np.float32)
+    env.step_dynamics(torch.as_tensor(a, device="cuda:0"))          # float32 action buffer
+    ora.step_dynamics(a.astype(np.float64))
+    s = _np(env.read("STATE"))
+    np.testing.assert_allclose(s, ora.read("STATE"), rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(s[:, 0], s[:, 2])                   # NaN rows == zero action
+
+
+# ------------------------------------------------------------------------------- K2 lidar
+def test_k2_lidar_all_golden_scenes():
+    z = load("g3_lidar.npz")
+    n_hit = 0
+    for i in range(len(z["names"])):
+        pre = "s%d_" % i
+        cfg = cfg_from_scalars(z["cfg_keys"], z[pre + "cfg"])
+        bank = pack_bank([build_world(scene_world(z, i))])
+        env = _env(cfg, bank, 1, auto_reset=False)
+        obs = env.reset()
+        order = scene_order(z, i)
+        d = _np(env.read("LIDAR_D"))[0]
+        np.testing.assert_allclose(d, z[pre + "d"], rtol=0, atol=ATOL, err_msg=str(z["names"][i]))
+        np.testing.assert_allclose(_np(env.read("OBS64"))[0, 6:], z[pre + "closeness"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(_np(obs)[0, 6:], z[pre + "closeness"], rtol=0, atol=1e-7)
+        assert bool(_np(env.read("COLLISION"))[0]) == bool(z[pre + "collision"])
+        near = _np(env.read("NEARBY"))[0][order].astype(bool)
+        np.testing.assert_array_equal(near, z[pre + "nearby"])
+        lim = _np(env.read("CULL_LIMITS"))[0][order]
+        np.testing.assert_array_equal(lim[near], z[pre + "limits"][near])
+        n_hit += int((d < 150).any())
+        env.close()
+    assert n_hit > 50
+
+
+# ------------------------------------------------------------------------------- K3 nav / reward
+@pytest.mark.parametrize("k", [0, 3, 8, 10])
+def test_k3_navigate_vs_reference_golden(k):
+    z = load("g2_path.npz")
+    pre = "p%d_" % k
+    cfg = cfg_from_scalars(z["cfg_keys"], z["cfg"])
+    q, ref = z[pre + "nav_query"], z[pre + "nav_out"]
+    spec = WorldSpec(waypoints=z[pre + "waypoints"], vessel_init=q[0])
+    env = _env(cfg, pack_bank([build_world(spec)]), len(q), auto_reset=False)
+    env.reset()
+    st = np.zeros((6, len(q)))
+    st[:3] = q.T
+    env.write("STATE", st)
+    env.write("INFO64", np.zeros((len(q), 8)))
+    env.nav_reward(mode=1)
+    nav, info = _np(env.read("NAV64")), _np(env.read("INFO64"))
+    tol = dict(rtol=0, atol=ATOL)
+    np.testing.assert_allclose(info[:, 6], ref[:, 0], **tol)
+    np.testing.assert_allclose(nav[:, 6], ref[:, 1], **tol)
+    np.testing.assert_allclose(nav[:, 5], ref[:, 2], **tol)
+    np.testing.assert_allclose(nav[:, 3], ref[:, 3], **tol)
+    np.testing.assert_allclose(nav[:, 4], ref[:, 4], **tol)
+    np.testing.assert_allclose(nav[:, 7], ref[:, 5], **tol)
+    np.testing.assert_allclose(info[:, 2], ref[:, 6], **tol)
+    np.testing.assert_allclose(info[:, 3], ref[:, 7], **tol)
+    np.testing.assert_array_equal(info[:, 1], ref[:, 8])
+
+
+@pytest.mark.parametrize("S,ns,nps", [(180, 9, 20), (64, 8, 8)])
+@pytest.mark.parametrize("rew,col", [("colav", 0), ("pathfollow", 1)])
+def test_k3_reward_vs_reference_golden(S, ns, nps, rew, col, empty_bank):
+    z = load("g4_reward.npz")
+    x, d, ref = z["S%d_in" % S], z["S%d_d" % S], z["S%d_reward" % S][:, col]
+    n = len(x)
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
+    env = _env(cfg, empty_bank, n, rewarder=rew, test_mode=True, auto_reset=False)
+    env.reset()
+    nav = np.zeros((n, 8))
+    nav[:, 0:3], nav[:, 5], nav[:, 4] = x[:, 0:3], x[:, 3], x[:, 4]
+    info = np.zeros((n, 8))
+    info[:, 3], info[:, 5] = x[:, 5], x[:, 6]
+    env.write("NAV64", nav), env.write("INFO64", info), env.write("LIDAR_D", d)
+    env.write("COLLISION", x[:, 7].astype(np.uint8))
+    done = _np(env.nav_reward(mode=2))
+    np.testing.assert_allclose(_np(env.read("REWARD64")), ref, rtol=1e-12, atol=1e-11)
+    np.testing.assert_allclose(_np(env.reward), ref, rtol=2e-7, atol=1e-6)      # float32 output
+    np.testing.assert_array_equal(done.astype(bool), x[:, 7].astype(bool))
+
+
+# ------------------------------------------------------------------------------- full step()
+@pytest.mark.parametrize("k", range(9))
+def test_rollout_vs_reference_golden(k):
+    z = load("g5_rollouts.npz")
+    pre = "r%d_" % k
+    cfg = cfg_from_scalars(z["cfg_keys"], z[pre + "cfg"])
+    spec = unpack_world(z, pre + "w_")
+    env = _env(cfg, pack_bank([build_world(spec)]), 1, rewarder=str(z["rewarder"][k]), auto_reset=False)
+    D = env.obs_dim
+    obs0 = _np(env.reset())
+    np.testing.assert_allclose(_np(env.read("OBS64"))[0, :D], z[pre + "obs0"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(obs0[0], z[pre + "obs0"], rtol=0, atol=1e-7)
+    st = _np(env.read("STATE"))
+    st[:, 0] = z[pre + "start_state"]
+    env.write("STATE", st)
+    for t in range(len(z[pre + "reward"])):
+        obs, rew, done, _ = env.step(torch.as_tensor(z[pre + "action"][t][None], device="cuda:0"))
+        info = _np(env.read("INFO64"))[0]
+        gi = z[pre + "info"][t]
+        np.testing.assert_allclose(_np(env.read("STATE"))[:, 0], z[pre + "state"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(env.read("OBS64"))[0, :D], z[pre + "obs"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(obs)[0], z[pre + "obs"][t], rtol=0, atol=1e-5)      # north-star bound
+        assert _np(env.read("REWARD64"))[0] == pytest.approx(z[pre + "reward"][t], abs=1e-8)
+        assert bool(_np(done)[0]) == bool(z[pre + "done"][t])
+        assert info[0] == gi[0] and info[1] == gi[1]
+        np.testing.assert_allclose(info[2:6], gi[2:6], rtol=0, atol=1e-8)
+        if cfg.vessel.use_lidar:
+            np.testing.assert_allclose(_np(env.read("LIDAR_D"))[0], z[pre + "d"][t], rtol=0, atol=1e-8)
+        mv = z[pre + "movers"][t]
+        if mv.size:
+            np.testing.assert_allclose(_np(env.read("MOVER_STATE"))[0, :len(mv)], mv, rtol=0, atol=1e-8)
+
+
+def _mixed_bank(n):
+    specs = []
+    for i in range(n):
+        if i % 3 == 0:
+            specs.append(moving_obstacles_world(1000 + i))
+        elif i % 3 == 1:
+            specs.append(static_circles_world(1000 + i, 20))
+        else:
+            specs.append(polygon_world(1000 + i, 12, n_circles=4, n_moving=3))
+    return pack_bank([build_world(s) for s in specs])
+
+
+@pytest.mark.parametrize("S,ns,nps", [(180, 9, 20), (64, 8, 8), (256, 16, 16)])
+def test_batched_step_vs_oracle_with_auto_reset(S, ns, nps):
+    """96 envs over 48 mixed worlds, random actions, auto-reset on; short episodes are forced
+    through a small max_timesteps so the reset pass is exercised."""
+    n = 96
+    bank = _mixed_bank(48)
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
+    cfg.episode.max_timesteps = 17
+    env = _env(cfg, bank, n, auto_reset=True)
+    ora = _oracle(cfg, bank, n, auto_reset=True)
+    np.testing.assert_allclose(_np(env.reset()), ora.reset(), rtol=0, atol=1e-6)
+    rs = np.random.RandomState(S)
+    n_done = 0
+    for t in range(45):
+        a = rs.uniform([-1, -0.15], [1, 0.15], (n, 2))
+        if t == 3:
+            a[5] = np.nan
+        obs, rew, done, _ = env.step(torch.as_tensor(a, device="cuda:0"))
+        o_obs, o_rew, o_done = ora.step(a)
+        np.testing.assert_array_equal(_np(done), o_done)
+        for f in ("STATE", "LIDAR_D", "OBS64", "REWARD64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE"):
+            np.testing.assert_allclose(_np(env.read(f)), ora.read(f), rtol=0, atol=ATOL, err_msg="%s step %d" % (f, t))
+        for f in ("WORLD_IDX", "COUNTERS", "NEARBY", "COLLISION", "CULL_LIMITS"):
+            g, o = _np(env.read(f)), ora.read(f)
+            if f == "COUNTERS":
+                g, o = g[:, :3], o[:, :3]
+            np.testing.assert_array_equal(g, o, err_msg="%s step %d" % (f, t))
+        np.testing.assert_allclose(_np(obs), o_obs, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(_np(rew), o_rew, rtol=1e-6, atol=1e-5)
+        n_done += int(o_done.sum())
+    assert n_done >= 2 * n          # every env finished at least two episodes
+
+
+def test_graph_replay_matches_eager():
+    n = 32
+    bank = _mixed_bank(16)
+    cfg = effective_reference_config(use_lidar=True)
+    a_env, b_env = _env(cfg, bank, n), _env(cfg, bank, n)
+    a_env.reset(), b_env.reset()
+    buf = b_env.capture_graph(torch.float32)
+    rs = np.random.RandomState(1)
+    for _ in range(10):
+        a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=torch.float32, device="cuda:0")
+        o1, r1, d1, _ = a_env.step(a)
+        buf.copy_(a)
+        o2, r2, d2, _ = b_env.step_graph()
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+
+
+def test_cull_exact_mode_vs_oracle():
+    n = 24
+    bank = _mixed_bank(24)
+    cfg = effective_reference_config(use_lidar=True)
+    env = _env(cfg, bank, n, cull="exact", auto_reset=False)
+    ora = _oracle(cfg, bank, n, cull="exact")
+    env.reset(), ora.reset()
+    np.testing.assert_allclose(_np(env.read("LIDAR_D")), ora.read("LIDAR_D"), rtol=0, atol=ATOL)
+
+
+def test_error_paths():
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    cfg = effective_reference_config(use_lidar=True)
+    bank = _mixed_bank(3)
+    env = _env(cfg, bank, 4)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((3, 2), device="cuda:0"))
+    with pytest.raises(AssertionError):
+        env.reset(world_idx=torch.tensor([0, 1, 2, 7]))
+    with pytest.raises(RuntimeError):
+        env.step_graph()
