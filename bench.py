@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched gym-auv step() hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the >=1 M env-steps/s target is quoted
+on): 4096 envs x 180 sensors per GPU, 50 static filled polygon obstacles per env, one distinct
+world per env (seed 1000 + global env index), effective reference dt = 0.5 s, LiDAR on,
+ColavRewarder, VecEnv auto-reset, i.i.d. U(action_space) actions (torch seed 0) resident in
+HBM before the timed region.  One "step" = one batched env.step() = K1 -> K2 -> K3 (+ the
+reset pass) over all envs of the rank.  Weak scaling: per-GPU work is fixed as N grows.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel,
+HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle = a C port of the
+reference algorithm, timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--workload", default="polygons50", choices=["polygons50", "circles20", "moving28", "mixed47"])
+    ap.add_argument("--graph", type=int, default=1, help="replay a captured hipGraph per step (1) or launch eagerly (0)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
+    ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    # name: (generator, kwargs, n_sectors, n_sensors_per_sector, description)
+    "polygons50": ("polygon_world", dict(n_polygons=50), 9, 20,
+                   "4096 envs x 180 sensors, 50 static polygon obstacles (BASELINE configs[2])"),
+    "circles20": ("static_circles_world", dict(n_circles=20), 8, 8,
+                  "4096 envs x 64 sensors, 20 static circular obstacles (BASELINE configs[1])"),
+    "moving28": ("moving_obstacles_world", dict(), 9, 20,
+                 "envs x 180 sensors, 17 moving + 11 static obstacles (BASELINE configs[3] per-GPU shard)"),
+    "mixed47": ("polygon_world", dict(n_polygons=10, n_circles=20, n_moving=17), 16, 16,
+                "envs x 256 sensors, 20 circles + 10 polygons + 17 movers (BASELINE configs[4] per-GPU shard)"),
+}
+
+
+def algorithmic_bytes(bank, cfg_S, world_of_env):
+    """Per-launch algorithmic HBM bytes of each kernel ('Kernels'): sums over the
+    envs of one rank, fp64 layout."""
+    P = np.diff(bank["poly_off"])[world_of_env].astype(np.float64)
+    K = np.diff(bank["obs_off"])[world_of_env].astype(np.float64)
+    meta = bank["obs_meta"]
+    nseg_world = np.zeros(int(bank["n_worlds"]))
+    w_of_obs = np.repeat(np.arange(int(bank["n_worlds"])), np.diff(bank["obs_off"]))
+    static = meta[:, 0] != 2
+    np.add.at(nseg_world, w_of_obs[static], meta[static, 2])
+    G = nseg_world[world_of_env]
+    S = float(cfg_S)
+    k1 = 144.0 * len(world_of_env)
+    k2 = (32.0 * G + 24.0 * K + 16.0 * K + 24.0 + 16.0 * S + K).sum()
+    k3 = (16.0 * P + 8.0 * S + 8.0 * (6 + S) + 4.0 * (6 + S) + 400.0).sum()
+    return dict(k1_dynamics=k1, k2_lidar=float(k2), k3_nav_reward=float(k3))
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    # ---- reset-time host work first, BEFORE anything initialises the GPU (worker processes
+    # are forked here; no process that has touched HIP forks or execs)
+    from gym_auv_amd.config import effective_reference_config
+    from gym_auv_amd.world import build_bank_parallel
+    gen, kwargs, ns, nps, desc = WORKLOADS[args.workload]
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
+    n_local = args.envs
+    lo = rank * n_local                                    # weak scaling: fixed envs per GPU
+    procs = args.procs or max(1, min(16, host_cores() // max(1, world)))
+    t0 = time.time()
+    cache = args.bank_cache and "%s.%s.%d.%d.npz" % (args.bank_cache, args.workload, lo, n_local)
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
+    else:
+        bank = build_bank_parallel(gen, range(1000 + lo, 1000 + lo + n_local), procs=procs, **kwargs)
+        if cache:
+            np.savez(cache, **bank)
+    t_gen = time.time() - t0
+
+    from gym_auv_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    from gym_auv_amd.batched_env import BatchedAuvEnv     # fails loudly without the HIP library
+    env = BatchedAuvEnv(cfg, bank, n_local, device=dev, auto_reset=True)
+    S = env.n_sensors
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(0 + rank)
+    n_pool = 64
+    low = torch.tensor([-1.0, -0.15], device=dev)
+    high = torch.tensor([1.0, 0.15], device=dev)
+    pool = low + (high - low) * torch.rand((n_pool, n_local, 2), generator=g, device=dev)   # resident in HBM
+
+    env.reset()
+    if args.graph:
+        abuf = env.capture_graph(torch.float32)
+
+        def do_step(i):
+            abuf.copy_(pool[i % n_pool])
+            env.step_graph()
+    else:
+        def do_step(i):
+            env.step(pool[i % n_pool])
+
+    for i in range(args.warmup):
+        do_step(i)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        do_step(args.warmup + i)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, dev)
+    # the only exchange of the path: episode returns for reporting, RCCL all_gather over xGMI
+    stats = D.gather_episode_stats(env.episode_stats())
+    total_envs = n_local * world
+    value = total_envs * args.steps / elapsed
+
+    # ---- per-kernel timing with HIP events on the launch stream (same workload, same process)
+    kms = np.zeros(4)
+    n_prof = min(args.steps, 100)
+    for i in range(n_prof):
+        kms += np.array(env.step_timed(pool[i % n_pool]))
+    kms /= n_prof
+    world_of_env = env.read("WORLD_IDX").cpu().numpy()
+    alg = algorithmic_bytes(bank, S, world_of_env)
+    names = ["k1_dynamics", "k2_lidar", "k3_nav_reward"]
+    per_kernel = {}
+    for j, nm in enumerate(names):
+        gbs = alg[nm] / (kms[j] * 1e-3) / 1e9 if kms[j] > 0 else 0.0
+        per_kernel[nm] = dict(avg_ms=round(float(kms[j]), 5), algorithmic_bytes=int(alg[nm]),
+                              achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+    per_kernel["reset_pass"] = dict(avg_ms=round(float(kms[3]), 5))
+    dom = max(names, key=lambda nm: per_kernel[nm]["avg_ms"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=dom, achieved=per_kernel[dom]["achieved_GBs"], peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=per_kernel[dom]["frac"], traffic=traffic, kernels=per_kernel)
+
+    out = dict(metric="env-steps/sec", value=round(value, 1), unit="env-steps/s", n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
+                           parallelism="env-shard x%d (no step-path collective)" % world,
+                           hipgraph=bool(args.graph), world_gen_s=round(t_gen, 1),
+                           episodes_finished=int(stats["episodes"].sum().item())),
+               roofline=roofline)
+
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, bank, n_local)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(cfg, bank, n_local):
+    """The CPU oracle (C port of the reference algorithm, fp64, -O2) on this box's host cores,
+    on a bounded sample of the same workload: the first 256 envs/worlds for 40 steps on all
+    cores (OpenMP over envs) and 10 steps on 1 thread."""
+    from gym_auv_amd._capi import make_config
+    from oracle import pyoracle
+    n = min(256, n_local)
+    ora = pyoracle.Oracle(make_config(cfg, auto_reset=True), n, bank)
+    rs = np.random.RandomState(0)
+    acts = rs.uniform([-1, -0.15], [1, 0.15], (8, n, 2))
+    cores = pyoracle.set_threads(host_cores())
+    ora.reset()
+    ora.step(acts[0])
+    steps = 40
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ora.step(acts[i % 8])
+    dt_all = time.perf_counter() - t0
+    pyoracle.set_threads(1)
+    t0 = time.perf_counter()
+    for i in range(10):
+        ora.step(acts[i % 8])
+    dt_one = time.perf_counter() - t0
+    pyoracle.set_threads(cores)
+    return dict(value=round(n * steps / dt_all, 1), unit="env-steps/s", cores=cores, kind="port",
+                sample="%d envs x %d steps of the same workload (OpenMP over envs, %d threads)" % (n, steps, cores),
+                value_1thread=round(n * 10 / dt_one, 1))
+
+
+if __name__ == "__main__":
+    main()

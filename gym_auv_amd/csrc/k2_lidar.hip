@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar(AuvDev d, int advance_move
     d.limits[(size_t)e * d.k_max + k] = lim;
     obs[k] = o;
   }
+  for (int k = K + tid; k < d.k_max; k += AUV_BLOCK) d.limits[(size_t)e * d.k_max + k] = make_int2(INT32_MIN, INT32_MIN);
   __syncthreads();
 
   // ---- phase D: (ray, segment) pairs, one obstacle per wave at a time ------------------

@@ -138,3 +138,59 @@ def pack_bank(worlds: Sequence[BuiltWorld]) -> Dict[str, np.ndarray]:
     bank["m_max"] = int(np.diff(mv_off).max()) if W else 0
     bank["p_max"] = int(np.diff(poly_off).max()) if W else 0
     return bank
+
+
+def merge_banks(banks: Sequence[Dict[str, np.ndarray]]) -> Dict[str, np.ndarray]:
+    """Concatenate packed banks (e.g. built by parallel workers) into one, fixing offsets."""
+    out: Dict[str, np.ndarray] = {}
+
+    def cat_off(name):
+        parts, base = [np.zeros(1, dtype=np.int64)], 0
+        for b in banks:
+            parts.append(b[name][1:] + base)
+            base += int(b[name][-1])
+        return np.concatenate(parts)
+
+    for name in ("poly_off", "knot_off", "obs_off", "mv_off", "mv_vtab_off"):
+        out[name] = cat_off(name)
+    for name in ("poly_xy", "poly_cum", "knot_s", "knot_coef", "world_scalar", "obs_cull", "seg",
+                 "mv_param", "mv_init", "mv_vtab"):
+        out[name] = np.ascontiguousarray(np.concatenate([b[name] for b in banks]))
+    metas, seg_base = [], 0
+    for b in banks:
+        m = b["obs_meta"].copy()
+        m[:, 1] += np.where(m[:, 0] == OBS_MOVER, 0, seg_base).astype(np.int32)
+        metas.append(m)
+        seg_base += len(b["seg"])
+    out["obs_meta"] = np.ascontiguousarray(np.concatenate(metas))
+    out["n_worlds"] = np.int32(sum(int(b["n_worlds"]) for b in banks))
+    out["k_max"] = max(int(b["k_max"]) for b in banks)
+    out["m_max"] = max(int(b["m_max"]) for b in banks)
+    out["p_max"] = max(int(b["p_max"]) for b in banks)
+    return out
+
+
+def _build_chunk(args):
+    kind, seeds, kwargs = args
+    from . import scenarios
+    gen = getattr(scenarios, kind)
+    return pack_bank([build_world(gen(int(s), **kwargs)) for s in seeds])
+
+
+def build_bank_parallel(kind: str, seeds: Sequence[int], procs: int = 1, **kwargs) -> Dict[str, np.ndarray]:
+    """Generate + build + pack worlds `scenarios.<kind>(seed, **kwargs)` for all seeds using
+    `procs` worker processes (reset-time host work; the reference does this serially in
+    `_generate()`)."""
+    seeds = list(seeds)
+    if procs <= 1 or len(seeds) < 2 * procs:
+        return _build_chunk((kind, seeds, kwargs))
+    import multiprocessing as mp
+    n_chunks = min(len(seeds), procs * 4)
+    chunks = [(kind, seeds[i::n_chunks], kwargs) for i in range(n_chunks)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        banks = pool.map(_build_chunk, chunks)
+    # restore seed order: chunk c holds seeds c, c+n_chunks, ... -> world index permutation
+    merged = merge_banks(banks)
+    order = np.concatenate([np.arange(len(seeds))[i::n_chunks] for i in range(n_chunks)])
+    merged["seed_order"] = np.asarray(seeds)[order]
+    return merged

@@ -21,6 +21,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/auv_hip.h"
 
@@ -729,3 +732,14 @@ int oracle_write(oracle_t* o, int32_t field, const void* src, size_t bytes) {
 }
 int32_t oracle_kmax(const oracle_t* o) { return o->k_max; }
 int32_t oracle_mmax(const oracle_t* o) { return o->m_max; }
+
+/* cpu_baseline support: number of OpenMP threads used by the batched loops */
+int oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}

@@ -45,6 +45,7 @@ def _load():
         lib.oracle_field_bytes.argtypes = [vp, i32]
         lib.oracle_field_bytes.restype = sz
         lib.oracle_kmax.argtypes = [vp]
+        lib.oracle_set_threads.argtypes = [C.c_int]
         lib.oracle_mmax.argtypes = [vp]
         _lib = lib
     return _lib
@@ -120,3 +121,8 @@ class Oracle:
     def write(self, name, arr):
         a = np.ascontiguousarray(arr, dtype=FIELD_DTYPES[name]).reshape(self._shape(name))
         assert self.lib.oracle_write(self.h, FIELDS[name], a.ctypes.data, a.nbytes) == 0
+
+
+def set_threads(n: int) -> int:
+    """Set (n > 0) / query the OpenMP thread count of the oracle's batched loops."""
+    return int(_load().oracle_set_threads(int(n)))

@@ -1,0 +1,66 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise sharding + the episode-stats
+all_gather used for reporting (the step() path itself has no collective)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from gym_auv_amd.distributed import shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 4096, 32768, 65537):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(blocks[:-1], blocks[1:]):
+                assert a1 == b0
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from gym_auv_amd import distributed as D
+    r, w, _ = D.init_from_env(backend="gloo")
+    lo, hi = D.shard_range(n_total, r, w)
+    idx = torch.arange(lo, hi, dtype=torch.float32)
+    stats = {"episode_return": idx * 2.0, "episode_length": idx + 100.0, "collision": (idx % 3 == 0).float()}
+    full = D.gather_episode_stats(stats)
+    t = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    D.barrier()
+    q.put((rank, lo, hi, {k: v.tolist() for k, v in full.items()}, t))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gloo_world2_gather_episode_stats():
+    world, n_total = 2, 11                  # uneven shards: 6 + 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    exp = torch.arange(n_total, dtype=torch.float32)
+    for rank, lo, hi, full, t in res:
+        assert full["episode_return"] == (exp * 2).tolist()
+        assert full["episode_length"] == (exp + 100).tolist()
+        assert full["collision"] == (exp % 3 == 0).float().tolist()
+        assert t == 2.0
+    assert sorted((r[1], r[2]) for r in res) == [(0, 6), (6, 11)]
