@@ -25,7 +25,7 @@ from .worldspec import WorldSpec
 
 _LIB = load_library()   # fail loudly at import time
 
-_TORCH_DTYPES = {np.float64: torch.float64, np.int32: torch.int32, np.uint8: torch.uint8}
+_TORCH_DTYPES = {np.float64: torch.float64, np.int32: torch.int32, np.uint8: torch.uint8, np.int64: torch.int64}
 
 
 def _check(rc: int, what: str):
@@ -167,7 +167,7 @@ class BatchedAuvEnv:
         n, S = self.n_envs, self.n_sensors
         return dict(STATE=(6, n), LIDAR_D=(n, S), OBS64=(n, 6 + S), REWARD64=(n,), INFO64=(n, 8),
                     WORLD_IDX=(n,), COUNTERS=(n, 4), MOVER_STATE=(n, self.m_max, 4), NEARBY=(n, self.k_max),
-                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,))[name]
+                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,), STAMPS=(n, 16))[name]
 
     def read(self, name: str) -> torch.Tensor:
         t = torch.empty(self.field_shape(name), dtype=_TORCH_DTYPES[FIELD_DTYPES[name]], device=self.device)

@@ -6,15 +6,17 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "auv_device.h"
 
 void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st);
-void auv_launch_k2(const AuvDev& d, int advance_movers, int only_fresh, hipStream_t st);
-void auv_launch_k3(const AuvDev& d, int mode, int only_fresh, float* obs, float* reward, uint8_t* done,
-                   hipStream_t st);
+void auv_launch_k2(const AuvDev& d, int advance_movers, hipStream_t st);
+void auv_launch_k2_fresh(const AuvDev& d, hipStream_t st);
+void auv_launch_k3(const AuvDev& d, int mode, float* obs, float* reward, uint8_t* done, hipStream_t st);
+void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st);
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
 
@@ -157,6 +159,39 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   rc |= dev_upload(bp, &d.poly_off, b->poly_off, (size_t)W + 1);
   rc |= dev_upload(bp, &d.poly_xy, b->poly_xy, (size_t)nP);
   rc |= dev_upload(bp, &d.poly_cum, b->poly_cum, (size_t)nP);
+  {
+    // derived data: bounding circle of every run of AUV_CHUNK polyline segments (K3's exact
+    // pruning).  Radius inflated so that rounding can never exclude a chunk that matters.
+    std::vector<int64_t> coff((size_t)W + 1, 0);
+    std::vector<double> cbound;
+    int nch_max = 1;
+    for (int w = 0; w < W; w++) {
+      const int64_t p0 = b->poly_off[w], P = b->poly_off[w + 1] - p0;
+      const int64_t nch = (P - 1 + AUV_CHUNK - 1) / AUV_CHUNK;
+      coff[w + 1] = coff[w] + nch;
+      if (nch > nch_max) nch_max = (int)nch;
+      for (int64_t c = 0; c < nch; c++) {
+        const int64_t v0 = c * AUV_CHUNK, v1 = (v0 + AUV_CHUNK < P - 1 ? v0 + AUV_CHUNK : P - 1);
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (int64_t v = v0; v <= v1; v++) {
+          const double x = b->poly_xy[2 * (p0 + v)], y = b->poly_xy[2 * (p0 + v) + 1];
+          x0 = x < x0 ? x : x0, x1 = x > x1 ? x : x1, y0 = y < y0 ? y : y0, y1 = y > y1 ? y : y1;
+        }
+        const double cx = 0.5 * (x0 + x1), cy = 0.5 * (y0 + y1);
+        double r2 = 0.0;
+        for (int64_t v = v0; v <= v1; v++) {
+          const double dx = b->poly_xy[2 * (p0 + v)] - cx, dy = b->poly_xy[2 * (p0 + v) + 1] - cy;
+          const double q = dx * dx + dy * dy;
+          r2 = q > r2 ? q : r2;
+        }
+        cbound.push_back(cx), cbound.push_back(cy);
+        cbound.push_back(sqrt(r2) * (1.0 + 1e-9) + 1e-9), cbound.push_back(0.0);
+      }
+    }
+    d.nch_max = nch_max;
+    rc |= dev_upload(bp, &d.chunk_off, coff.data(), (size_t)W + 1);
+    rc |= dev_upload(bp, &d.chunk_bound, cbound.data(), cbound.size() / 4);
+  }
   rc |= dev_upload(bp, &d.knot_off, b->knot_off, (size_t)W + 1);
   rc |= dev_upload(bp, &d.knot_s, b->knot_s, (size_t)nK);
   rc |= dev_upload(bp, &d.knot_coef, b->knot_coef, (size_t)nK * 8);
@@ -185,11 +220,15 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   rc |= dev_alloc(ep, &d.episode, n * 4);
   rc |= dev_alloc(ep, &d.limits, n * k_max);
   rc |= dev_alloc(ep, &d.collision, n);
+  rc |= dev_alloc(ep, &d.fresh_count, 4);
+  rc |= dev_alloc(ep, &d.fresh_list, n);
+  rc |= dev_alloc(ep, &d.stamps, n * 16);
   if (rc) return AUV_EHIP;
   std::vector<int32_t> wi(n);
   for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(e % (size_t)W);
   HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds 160 KiB", auv_k2_lds_bytes(d));
+  if (auv_k2_lds_bytes(d) > 64 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds 64 KiB per workgroup", auv_k2_lds_bytes(d));
+  if ((size_t)AUV_ENVS_PER_BLOCK * d.nch_max * 4 > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;
@@ -207,21 +246,22 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
 int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx_dev, float* obs_dev, void* stream) {
   REQUIRE_READY(h);
   hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(h->d.fresh_count, 0, sizeof(int32_t), st));
   auv_launch_reset(h->d, mask_dev, world_idx_dev, st);
-  auv_launch_k2(h->d, 0, 1, st);
-  auv_launch_k3(h->d, 1, 1, obs_dev, nullptr, nullptr, st);
+  auv_launch_k2_fresh(h->d, st);
+  auv_launch_k3_fresh(h->d, obs_dev, st);
   HIP_TRY(hipGetLastError());
   return AUV_OK;
 }
 
 static void enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, float* obs, float* reward, uint8_t* done,
                          hipStream_t st) {
-  auv_launch_k1(h->d, actions, dtype, st);
-  auv_launch_k2(h->d, 1, 0, st);
-  auv_launch_k3(h->d, 0, 0, obs, reward, done, st);
+  auv_launch_k1(h->d, actions, dtype, st);   // also empties the fresh list
+  auv_launch_k2(h->d, 1, st);
+  auv_launch_k3(h->d, 0, obs, reward, done, st);
   if (h->d.cfg.auto_reset) {
-    auv_launch_k2(h->d, 0, 1, st);
-    auv_launch_k3(h->d, 1, 1, obs, nullptr, nullptr, st);
+    auv_launch_k2_fresh(h->d, st);
+    auv_launch_k3_fresh(h->d, obs, st);
   }
 }
 
@@ -246,7 +286,7 @@ int auv_step_dynamics(auv_handle_t* h, const void* actions_dev, int32_t action_d
 
 int auv_lidar(auv_handle_t* h, int32_t advance_movers, void* stream) {
   REQUIRE_READY(h);
-  auv_launch_k2(h->d, advance_movers ? 1 : 0, 0, (hipStream_t)stream);
+  auv_launch_k2(h->d, advance_movers ? 1 : 0, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return AUV_OK;
 }
@@ -254,10 +294,12 @@ int auv_lidar(auv_handle_t* h, int32_t advance_movers, void* stream) {
 int auv_nav_reward(auv_handle_t* h, int32_t mode, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   REQUIRE_READY(h);
   if (mode < 0 || mode > 2) return fail(AUV_EINVAL, "auv_nav_reward: mode must be 0, 1 or 2");
-  auv_launch_k3(h->d, mode, 0, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
-  if (mode == 0 && h->d.cfg.auto_reset) {
-    auv_launch_k2(h->d, 0, 1, (hipStream_t)stream);
-    auv_launch_k3(h->d, 1, 1, obs_dev, nullptr, nullptr, (hipStream_t)stream);
+  const bool resets = (mode != 1) && h->d.cfg.auto_reset;
+  if (resets) HIP_TRY(hipMemsetAsync(h->d.fresh_count, 0, sizeof(int32_t), (hipStream_t)stream));
+  auv_launch_k3(h->d, mode, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
+  if (resets) {
+    auv_launch_k2_fresh(h->d, (hipStream_t)stream);
+    auv_launch_k3_fresh(h->d, obs_dev, (hipStream_t)stream);
   }
   HIP_TRY(hipGetLastError());
   return AUV_OK;
@@ -280,6 +322,7 @@ static void* field_ptr(const auv_handle_t* h, int32_t field, size_t* bytes) {
     case AUV_FIELD_CULL_LIMITS: *bytes = 8 * n * d.k_max; return d.limits;
     case AUV_FIELD_NAV64: *bytes = 8 * 8 * n; return d.nav64;
     case AUV_FIELD_COLLISION: *bytes = n; return d.collision;
+    case AUV_FIELD_STAMPS: *bytes = 8 * 16 * n; return d.stamps;
   }
   *bytes = 0;
   return nullptr;
@@ -348,13 +391,13 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   HIP_TRY(hipEventRecord(h->ev[0], st));
   auv_launch_k1(h->d, actions_dev, action_dtype, st);
   HIP_TRY(hipEventRecord(h->ev[1], st));
-  auv_launch_k2(h->d, 1, 0, st);
+  auv_launch_k2(h->d, 1, st);
   HIP_TRY(hipEventRecord(h->ev[2], st));
-  auv_launch_k3(h->d, 0, 0, obs_dev, reward_dev, done_dev, st);
+  auv_launch_k3(h->d, 0, obs_dev, reward_dev, done_dev, st);
   HIP_TRY(hipEventRecord(h->ev[3], st));
   if (h->d.cfg.auto_reset) {
-    auv_launch_k2(h->d, 0, 1, st);
-    auv_launch_k3(h->d, 1, 1, obs_dev, nullptr, nullptr, st);
+    auv_launch_k2_fresh(h->d, st);
+    auv_launch_k3_fresh(h->d, obs_dev, st);
   }
   HIP_TRY(hipEventRecord(h->ev[4], st));
   HIP_TRY(hipEventSynchronize(h->ev[4]));

@@ -10,8 +10,11 @@
 
 #define AUV_PI 3.141592653589793
 #define AUV_WAVE 64
-#define AUV_BLOCK 256          // 4 waves per environment-workgroup (K2, K3)
+#define AUV_BLOCK 256          // K2/K3: one wave per environment, 4 environments per workgroup
+#define AUV_ENVS_PER_BLOCK (AUV_BLOCK / AUV_WAVE)
 #define AUV_MOVER_NSEG 5
+#define AUV_CHUNK 64           // polyline segments per bounding-circle chunk (= one wave pass)
+#define AUV_FRESH_GRID 256     // workgroups of the reset-pass kernels (they loop over the fresh list)
 
 // Everything the kernels read, by value in the kernel argument buffer (no constant memory,
 // no host round trip; hipGraph-capturable).
@@ -24,6 +27,9 @@ struct AuvDev {
   const int64_t* poly_off;
   const double2* poly_xy;
   const double* poly_cum;
+  const int64_t* chunk_off;    // [W+1] offsets into chunk_bound (derived at load time)
+  const double4* chunk_bound;  // cx, cy, inflated radius, - : circle around AUV_CHUNK segments
+  int32_t nch_max;             // max chunks of any world
   const int64_t* knot_off;
   const double* knot_s;
   const double* knot_coef;     // [.][8]
@@ -51,7 +57,25 @@ struct AuvDev {
   double* episode;     // [N][4]
   int2* limits;        // [N][Kmax]
   uint8_t* collision;  // [N]
+  int32_t* fresh_count; // [1]  number of envs reset in this call (reset() / auto-reset)
+  int32_t* fresh_list;  // [N]  their indices; consumed by the reset-pass kernels
+  unsigned long long* stamps;  // [N][16] per-env phase cycle counts (diagnostic builds, -DAUV_STAMPS)
 };
+
+// In-kernel phase stamps (diagnostic build only: make STAMPS=1).  The stamp values leave the
+// kernel through `stamps` alone; no output is computed from them.
+#ifdef AUV_STAMPS
+#define AUV_STAMP_DECL unsigned long long _st[9]; int _si = 0; _st[_si++] = clock64();
+#define AUV_STAMP() _st[_si++] = clock64();
+#define AUV_STAMP_FLUSH(e, base)                                                        \
+  if (lane == 0) {                                                                      \
+    for (int _k = 1; _k < _si; _k++) d.stamps[(size_t)(e) * 16 + (base) + _k - 1] = _st[_k] - _st[_k - 1]; \
+  }
+#else
+#define AUV_STAMP_DECL
+#define AUV_STAMP()
+#define AUV_STAMP_FLUSH(e, base)
+#endif
 
 __device__ __forceinline__ double auv_princip(double a) {
   // ((a + pi) % (2 pi)) - pi with Python's sign convention (utils/geomutils.py:4-5)
@@ -81,15 +105,27 @@ __device__ __forceinline__ double auv_pt_seg_dist(double px, double py, double a
   return fabs(s) * sqrt(len2);
 }
 
-// Python floor-mod for ints (list index wrap in sensor.py:93-95)
-__device__ __forceinline__ int auv_pymod(long long a, int s) {
-  long long r = a % (long long)s;
-  return (int)(r < 0 ? r + s : r);
+// Python floor-mod for ints (sensor.py:93: idx_max_ray % n_rays)
+__device__ __forceinline__ int auv_pymod(int a, int s) {
+  int r = a % s;
+  return r < 0 ? r + s : r;
+}
+
+// LDS hand-off between lanes of the SAME wave: a wave's LDS operations execute in order, so
+// only outstanding operations must be waited for and the compiler kept from reordering.
+__device__ __forceinline__ void auv_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // wave64 reductions through DPP/permute shuffles
 __device__ __forceinline__ double auv_wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, AUV_WAVE);
+  return v;
+}
+__device__ __forceinline__ double auv_wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, AUV_WAVE));
   return v;
 }

@@ -50,6 +50,7 @@ template <typename AT>
 __global__ void __launch_bounds__(AUV_WAVE) k1_dynamics(AuvDev d, const AT* __restrict__ actions) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= d.n) return;
+  if (e == 0) *d.fresh_count = 0;   // the auto-reset list of this step starts empty (consumed after K3)
   const size_t n = (size_t)d.n;
   double a0 = (double)actions[2 * (size_t)e], a1 = (double)actions[2 * (size_t)e + 1];
   if (isnan(a0) || isnan(a1)) a0 = a1 = 0.0;

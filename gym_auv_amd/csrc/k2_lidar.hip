@@ -1,4 +1,5 @@
-// K2 — moving-obstacle update + LiDAR sweep: one 256-thread workgroup per environment.
+// K2 — moving-obstacle update + LiDAR sweep: ONE WAVE (64 lanes) PER ENVIRONMENT, four
+// environments per 256-thread workgroup, no workgroup barriers (everything is wave-synchronous).
 //
 // Reference: BaseEnvironment._update              gym_auv/environment.py:386-392
 //            VesselObstacle._update / boundary     objects/obstacles.py:195-233
@@ -7,20 +8,24 @@
 //            _find_limit_angle_rays                sensor.py:41-71
 //            simulate_sensor                       sensor.py:140-159
 //
-// Work decomposition (wave64):
-//   phase A  threads <-> movers: advance kinematics, rebuild the 5 pentagon segments + cull
-//            circle in LDS.
-//   phase B  threads <-> obstacles: (every 25th vessel step) nearby test; cull window
+// Work decomposition (front and back parts per wave; the pair sweep of the four environments of
+// a workgroup is shared by all 256 threads, so a heavy environment -- the vessel inside several
+// cull circles, i.e. windows of all S rays -- is spread over four waves):
+//   phase A  lanes <-> movers: advance kinematics, rebuild the 5 pentagon segments + cull
+//            circle in the wave's LDS slice.
+//   phase C  lanes <-> rays (S/64 passes): ray vectors (one sincos per ray) into LDS.
+//   phase B  lanes <-> obstacles: (every 25th vessel step) nearby test; cull window
 //            [i_min-1, i_max % S) with the reference's Python-range / negative-index
-//            semantics; point-in-polygon for filled obstacles.
-//   phase C  threads <-> rays: ray end points (one sincos per ray) into LDS.
-//   phase D  each wave takes obstacles round-robin; its 64 lanes enumerate the
-//            (ray-in-window x boundary-segment) pairs of that obstacle, so lanes stay busy
-//            however narrow the window is; a hit does an LDS atomic-min on the ray's range
-//            (non-negative fp64 ordered as uint64).
-//   phase E  threads <-> rays: write d, closeness (fused), block-OR the collision flag.
-// Only pairs inside the reference's cull windows are evaluated (~10-15 % of S x G), which is
-// what makes this kernel traffic-bound rather than VALU-bound.
+//            semantics; obstacles with a non-empty window are compacted (ballot + popcount).
+//   phase S  the boundary segments of the surviving obstacles are staged into LDS in ONE
+//            flattened, coalesced pass (vessel-relative: a - p0, b - a, and the ray-independent
+//            cross product), with the point-in-polygon predicates of filled obstacles evaluated
+//            on the fly (LDS xor/or per obstacle).
+//   phase D  obstacle by obstacle, the 64 lanes enumerate the (ray-in-window x staged
+//            segment) pairs, so lanes stay busy however narrow the window is; a hit does an
+//            LDS atomic-min on the ray's range (non-negative fp64 ordered as uint64).
+//   phase E  lanes <-> rays: write d, closeness (fused), wave-OR the collision flag (ballot).
+// Only pairs inside the reference's cull windows are evaluated (~5-15 % of S x G).
 // Roofline: HBM.  Algorithmic bytes per env-step (fp64 layout): 32*G (segments, G per env)
 // + 24*K (cull circles) + 16*K (meta) + 24 (pose) + 16*S (d + closeness out) + K (nearby).
 #include "auv_device.h"
@@ -31,40 +36,43 @@ struct ObsLds {        // per-obstacle scratch in LDS
   int kind;
   int seg_off;         // absolute index into seg[] (static) or mover slot*5 (mover)
   int nseg;
-  int start;           // first ray index of the window (may be negative)
+  int start;           // first ray index of the window (may be negative, > -2S)
   int count;           // number of rays in the window (0 = culled / not nearby)
-  int inside;          // p0 inside a filled obstacle
+  int stage_off;       // offset of its staged segments in the wave's LDS stage, or -1 (sweep from HBM)
+};
+
+struct EnvHdr {        // head of each wave's LDS slice: what the pair sweep needs to know
+  double px, py;
+  int n_act;           // obstacles with a non-empty ray window
+  int pad[3];
 };
 
 __device__ __forceinline__ unsigned long long d2u(double x) { return (unsigned long long)__double_as_longlong(x); }
 __device__ __forceinline__ double u2d(unsigned long long x) { return __longlong_as_double((long long)x); }
 
-// sensor.py:140-159 for one (ray, boundary segment) pair: returns distance or -1
-__device__ __forceinline__ double ray_seg(double px, double py, double rx, double ry, double ax, double ay,
-                                          double bx, double by) {
-  double sx = bx - ax, sy = by - ay;
-  double den = rx * sy - ry * sx;
-  if (den == 0.0) return -1.0;
-  double wx = ax - px, wy = ay - py;
-  double tn = wx * sy - wy * sx;   // t = tn/den along the ray
-  double un = wx * ry - wy * rx;   // u = un/den along the boundary segment
-  // 0 <= tn/den <= 1 and 0 <= un/den <= 1, decided without dividing (exactly equivalent for
-  // correctly rounded IEEE division)
-  bool pos = den > 0.0;
-  bool hit = pos ? (tn >= 0.0 && tn <= den && un >= 0.0 && un <= den)
-                 : (tn <= 0.0 && tn >= den && un <= 0.0 && un >= den);
-  if (!hit) return -1.0;
-  double t = tn / den;
-  double X = px + t * rx, Y = py + t * ry;
-  double dx = X - px, dy = Y - py;
-  return sqrt(dx * dx + dy * dy);
+__device__ __forceinline__ int wrap_ray(int i, int S) {   // Python list index for i in (-2S, 2S)
+  if (i < 0) i += S;
+  if (i < 0) i += S;
+  if (i >= S) i -= S;
+  return i;
 }
 
-__device__ __forceinline__ bool point_in_polygon(double px, double py, const double4* seg, int nseg) {
+// point in closed polygon; "on the boundary" (GEOS distance == 0) decided with the same
+// predicates as Distance::pointToSegment == 0, without its divisions / square roots
+template <typename SegPtr>
+__device__ __forceinline__ bool point_in_polygon(double px, double py, SegPtr seg, int nseg) {
   bool inside = false;
   for (int i = 0; i < nseg; i++) {
     double4 s = seg[i];
-    if (auv_pt_seg_dist(px, py, s.x, s.y, s.z, s.w) == 0.0) return true;
+    double ex = s.z - s.x, ey = s.w - s.y;
+    double dxa = px - s.x, dya = py - s.y;
+    double len2 = ex * ex + ey * ey;
+    double dot = dxa * ex + dya * ey;
+    bool on;
+    if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
+    else if (dot >= len2) on = (px == s.z && py == s.w);
+    else on = ((s.y - py) * ex - (s.x - px) * ey) == 0.0;
+    if (on) return true;
     if ((s.y > py) != (s.w > py)) {
       double xint = s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
       if (px < xint) inside = !inside;
@@ -73,7 +81,8 @@ __device__ __forceinline__ bool point_in_polygon(double px, double py, const dou
   return inside;
 }
 
-__device__ __forceinline__ double point_boundary_distance(double px, double py, const double4* seg, int nseg) {
+template <typename SegPtr>
+__device__ __forceinline__ double point_boundary_distance(double px, double py, SegPtr seg, int nseg) {
   double best = 1.0e300;
   for (int i = 0; i < nseg; i++) {
     double4 s = seg[i];
@@ -83,25 +92,87 @@ __device__ __forceinline__ double point_boundary_distance(double px, double py, 
   return best;
 }
 
-// LDS layout (dynamic): [Mmax*5] double4 mover segs | [Mmax] double4 mover cull (cx, cy, rho, -) |
-//                       [S] double2 ray vectors | [S] u64 d-bits | [Kmax] ObsLds | int any-flag
-__global__ void __launch_bounds__(AUV_BLOCK) k2_lidar(AuvDev d, int advance_movers, int only_fresh) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int e = blockIdx.x;
-  const int tid = threadIdx.x;
+#define K2_SEG_CAP 128   // staged segments per wave (4 KiB + 1 KiB of LDS)
+
+// per-wave LDS slice (decreasing alignment):
+//   EnvHdr | [Mmax*5] double4 mover segs | [Mmax] double4 mover cull | [CAP] double4 staged
+//   (wx,wy,sx,sy) | [S] double2 ray vectors | [CAP] double staged tn | [S] u64 d-bits |
+//   [Kmax] ObsLds | [Kmax] int active list | [Kmax+1] int segment prefix | [Kmax] int inside flags
+__host__ __device__ __forceinline__ size_t k2_slice_bytes(int S, int k_max, int m_max) {
+  size_t b = sizeof(EnvHdr) + (size_t)m_max * AUV_MOVER_NSEG * 32 + (size_t)m_max * 32 + (size_t)K2_SEG_CAP * 32 +
+             (size_t)S * 16 + (size_t)K2_SEG_CAP * 8 + (size_t)S * 8 + (size_t)k_max * sizeof(ObsLds) +
+             (size_t)k_max * 4 + (size_t)(k_max + 1) * 4 + (size_t)k_max * 4;
+  return (b + 15) & ~(size_t)15;
+}
+
+struct Slice {
+  EnvHdr* hdr;
+  double4* mvseg;
+  double4* mvcull;
+  double4* stage;
+  double2* rayv;
+  double* stage_tn;
+  unsigned long long* dbits;
+  ObsLds* obs;
+  int* act;
+  int* sbase;
+  int* par;
+};
+
+__device__ __forceinline__ Slice carve(unsigned char* p, int S, int k_max, int m_max) {
+  Slice s;
+  s.hdr = (EnvHdr*)p;
+  s.mvseg = (double4*)(s.hdr + 1);
+  s.mvcull = s.mvseg + m_max * AUV_MOVER_NSEG;
+  s.stage = s.mvcull + m_max;
+  s.rayv = (double2*)(s.stage + K2_SEG_CAP);
+  s.stage_tn = (double*)(s.rayv + S);
+  s.dbits = (unsigned long long*)(s.stage_tn + K2_SEG_CAP);
+  s.obs = (ObsLds*)(s.dbits + S);
+  s.act = (int*)(s.obs + k_max);
+  s.sbase = s.act + k_max;
+  s.par = s.sbase + k_max + 1;
+  return s;
+}
+
+// pairs of one obstacle against its ray window, enumerated by `nthr` threads (`tid` of them);
+// seg_at(si) yields (wx, wy, sx, sy) and the ray-independent numerator tn = wx*sy - wy*sx of t
+// (sensor.py:140-159)
+template <typename SegFn>
+__device__ __forceinline__ void sweep_pairs(const ObsLds& o, int tid, int nthr, int S, double px, double py,
+                                            const double2* rayv, unsigned long long* dbits, SegFn seg_at) {
+  const int total = o.count * o.nseg;
+  const float inv = 1.0f / (float)o.nseg;
+  const bool small = total < 32768;                       // exactness bound of the float quotient
+  for (int q = tid; q < total; q += nthr) {
+    const int ro = small ? (int)(((float)q + 0.5f) * inv) : q / o.nseg;
+    const int si = q - ro * o.nseg;
+    const int i = wrap_ray(o.start + ro, S);
+    double4 w;       // wx, wy, sx, sy
+    double tn;
+    seg_at(si, w, tn);
+    const double2 r = rayv[i];
+    double den = r.x * w.w - r.y * w.z;
+    double un = w.x * r.y - w.y * r.x;                    // u = un/den along the boundary segment
+    // 0 <= tn/den <= 1 and 0 <= un/den <= 1 decided without dividing (exactly equivalent for
+    // correctly rounded IEEE division); den < 0 handled by flipping all three signs (exact)
+    const bool neg = den < 0.0;
+    const double dn = neg ? -den : den, t1 = neg ? -tn : tn, u1 = neg ? -un : un;
+    const bool hit = (dn != 0.0) & (t1 >= 0.0) & (t1 <= dn) & (u1 >= 0.0) & (u1 <= dn);
+    if (hit) {
+      const double t = tn / den;
+      const double X = px + t * r.x, Y = py + t * r.y;
+      const double dx = X - px, dy = Y - py;
+      atomicMin(&dbits[i], d2u(sqrt(dx * dx + dy * dy)));
+    }
+  }
+}
+
+// phases A, C, B, S for one environment, by one wave
+__device__ void k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
-  int4 cnt = d.counters[e];
-  if (only_fresh && cnt.w == 0) return;   // reset pass: untouched envs leave immediately
-
-  // carve the dynamic LDS by decreasing alignment (no static __shared__ ahead of it)
-  double4* mvseg = (double4*)smem;
-  double4* mvcull = mvseg + d.m_max * AUV_MOVER_NSEG;
-  double2* rayv = (double2*)(mvcull + d.m_max);
-  unsigned long long* dbits = (unsigned long long*)(rayv + S);
-  ObsLds* obs = (ObsLds*)(dbits + S);
-  int& s_any = *(int*)(obs + d.k_max);
-
+  const int4 cnt = d.counters[e];
   const double px = d.state[0 * n + e], py = d.state[1 * n + e], psi = d.state[2 * n + e];
   const int w = d.world_idx[e];
   const long long k0 = d.obs_off[w];
@@ -110,23 +181,26 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar(AuvDev d, int advance_move
   const int M = (int)(d.mv_off[w + 1] - m0);
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   const double dangle = 2 * AUV_PI / S;
-  if (tid == 0) s_any = 0;
+  if (lane == 0) {
+    L.hdr->px = px, L.hdr->py = py;
+    L.hdr->n_act = 0;
+  }
 
   // ---- phase A: movers (obstacles.py:195-233) ---------------------------------------
-  for (int m = tid; m < M; m += AUV_BLOCK) {
+  for (int m = lane; m < M; m += AUV_WAVE) {
     double4 st = d.mover[(size_t)e * d.m_max + m];
-    const double4 par = d.mv_param[m0 + m];
+    const double4 par_m = d.mv_param[m0 + m];
     if (advance_movers) {
       const double dt = d.cfg.dt;
       const long long voff = d.mv_vtab_off[m0 + m];
-      const long long vlen = d.mv_vtab_off[m0 + m + 1] - voff;
+      const int vlen = (int)(d.mv_vtab_off[m0 + m + 1] - voff);
       st.w += dt;
-      long long idx = (long long)floor(st.w);
-      if (idx >= (long long)par.w - 1) {
+      int idx = (int)floor(st.w);
+      if (idx >= (int)par_m.w - 1) {
         st.w = 0.0;
         idx = 0;
-        st.x = par.y;
-        st.y = par.z;
+        st.x = par_m.y;
+        st.y = par_m.z;
       }
       if (idx > vlen - 1) idx = vlen - 1;
       double2 v = d.mv_vtab[voff + idx];
@@ -136,12 +210,12 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar(AuvDev d, int advance_move
       st.y = st.y + dy;
       d.mover[(size_t)e * d.m_max + m] = st;
     }
-    const double wd = par.x;
+    const double wd = par_m.x;
     double s, c;
     sincos(st.z, &s, &c);
     // closed form of enclosing_circle for the pentagon (MRR = body box): tests/test_world.py
     const double x0 = 5.0 * wd / 18.0, dxc = wd / 2.0 - x0;
-    mvcull[m] = make_double4(st.x + x0 + c * dxc, st.y + s * dxc, wd * sqrt(5.0) / 2.0, 0.0);
+    L.mvcull[m] = make_double4(st.x + x0 + c * dxc, st.y + s * dxc, wd * sqrt(5.0) / 2.0, 0.0);
     if (fabs(c) < 2.5e-16) c = 0.0;   // shapely.affinity.rotate snaps tiny cos/sin
     if (fabs(s) < 2.5e-16) s = 0.0;
     const double bx[5] = {-wd / 2, -wd / 2, wd / 2, 3.0 / 2 * wd, wd / 2};
@@ -156,141 +230,266 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar(AuvDev d, int advance_move
 #pragma unroll
     for (int i = 0; i < 5; i++) {
       int j = (i + 1) % 5;
-      mvseg[m * AUV_MOVER_NSEG + i] = make_double4(vx[i], vy[i], vx[j], vy[j]);
+      L.mvseg[m * AUV_MOVER_NSEG + i] = make_double4(vx[i], vy[i], vx[j], vy[j]);
     }
   }
-  // ---- phase C (independent of A): ray vectors, vessel.py:66-68, :317 ----------------
-  for (int i = tid; i < S; i += AUV_BLOCK) {
+  if (!d.cfg.use_lidar) return;   // lidar_d stays at sensor_range from reset; collision stays 0
+
+  // ---- phase C: ray vectors, vessel.py:66-68, :317 ------------------------------------
+  for (int i = lane; i < S; i += AUV_WAVE) {
     double ang = (-AUV_PI + (i + 1) * dangle) + psi;
     double s, c;
     sincos(ang, &s, &c);
     // end point minus origin, formed exactly as the reference forms the end point
     double ex = px + c * R, ey = py + s * R;
-    rayv[i] = make_double2(ex - px, ey - py);
-    dbits[i] = d2u(R);
+    L.rayv[i] = make_double2(ex - px, ey - py);
+    L.dbits[i] = d2u(R);
   }
-  __syncthreads();
-  if (!d.cfg.use_lidar) return;
+  auv_wave_lds_sync();
 
-  // ---- phase B: nearby list + cull windows -------------------------------------------
+  // ---- phase B: nearby list + cull windows; compaction of obstacles with a window ---------
   const bool refresh = (cnt.y % d.cfg.sensor_interval_load_obstacles) == 0;   // vessel.py:266
-  for (int k = tid; k < K; k += AUV_BLOCK) {
-    const int4 meta = d.obs_meta[k0 + k];
-    const bool mover = meta.x == AUV_OBS_MOVER;
-    const double4* seg = mover ? (mvseg + meta.w * AUV_MOVER_NSEG) : (d.seg + meta.y);
-    ObsLds o;
-    o.kind = meta.x;
-    o.seg_off = mover ? meta.w * AUV_MOVER_NSEG : meta.y;
-    o.nseg = meta.z;
-    o.start = 0;
-    o.count = 0;
-    o.inside = 0;
-    int inside_known = 0;
-    uint8_t near;
-    if (refresh) {
-      double dist;
-      if (meta.x != AUV_OBS_RING && point_in_polygon(px, py, seg, meta.z)) {
-        dist = 0.0;
-        o.inside = 1;
+  int n_act = 0;
+  for (int kb = 0; kb < K; kb += AUV_WAVE) {
+    const int k = kb + lane;
+    bool active = false;
+    if (k < K) {
+      const int4 meta = d.obs_meta[k0 + k];
+      const bool mover = meta.x == AUV_OBS_MOVER;
+      ObsLds o;
+      o.kind = meta.x;
+      o.seg_off = mover ? meta.w * AUV_MOVER_NSEG : meta.y;
+      o.nseg = meta.z;
+      o.start = 0;
+      o.count = 0;
+      o.stage_off = -1;
+      uint8_t near;
+      if (refresh) {
+        // vessel.py:266-273: Point.distance(boundary) - width < range (filled: 0 inside)
+        bool in = false;
+        if (meta.x != AUV_OBS_RING)
+          in = mover ? point_in_polygon(px, py, L.mvseg + o.seg_off, meta.z)
+                     : point_in_polygon(px, py, d.seg + meta.y, meta.z);
+        const double dist = in ? 0.0
+                               : (mover ? point_boundary_distance(px, py, L.mvseg + o.seg_off, meta.z)
+                                        : point_boundary_distance(px, py, d.seg + meta.y, meta.z));
+        near = (dist - W < R) ? 1 : 0;
+        d.nearby[(size_t)e * d.k_max + k] = near;
       } else {
-        dist = point_boundary_distance(px, py, seg, meta.z);
+        near = d.nearby[(size_t)e * d.k_max + k];
       }
-      inside_known = 1;
-      near = (dist - W < R) ? 1 : 0;
-      d.nearby[(size_t)e * d.k_max + k] = near;
-    } else {
-      near = d.nearby[(size_t)e * d.k_max + k];
-    }
-    int2 lim = make_int2(INT32_MIN, INT32_MIN);
-    if (near) {
-      long long start, stop;
-      if (d.cfg.cull_mode == AUV_CULL_EXACT) {
-        start = 0;
-        stop = S;
-      } else {
-        double cx, cy, rho;
-        if (mover) {
-          double4 c4 = mvcull[meta.w];
-          cx = c4.x, cy = c4.y, rho = c4.z;
+      int2 lim = make_int2(INT32_MIN, INT32_MIN);
+      if (near) {
+        int start, stop;
+        if (d.cfg.cull_mode == AUV_CULL_EXACT) {
+          start = 0;
+          stop = S;
         } else {
-          cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
+          double cx, cy, rho;
+          if (mover) {
+            double4 c4 = L.mvcull[meta.w];
+            cx = c4.x, cy = c4.y, rho = c4.z;
+          } else {
+            cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
+          }
+          double relx = cx - px, rely = cy - py;
+          double bearing = atan2(rely, relx) - psi;          // not wrapped (sensor.py:54)
+          double dist = sqrt(relx * relx + rely * rely);
+          double safe = dist > 1e-8 ? dist : 1e-8;
+          double q = rho / safe;
+          double f = (q > 1.0 || q < -1.0 || isnan(q)) ? AUV_PI : asin(q);   // NaN -> pi (sensor.py:34-36)
+          // |bearing| < 2 pi and f <= pi, so both indices lie in (-S, 2S): int32 is ample
+          int imin = (int)floor((AUV_PI + (bearing - f)) / dangle);
+          int imax = (int)ceil((AUV_PI + (bearing + f)) / dangle);
+          lim = make_int2(imin, imax);
+          start = imin - 1;
+          stop = auv_pymod(imax, S);                           // range(i_min - 1, i_max % S)
         }
-        double relx = cx - px, rely = cy - py;
-        double bearing = atan2(rely, relx) - psi;          // not wrapped (sensor.py:54)
-        double dist = sqrt(relx * relx + rely * rely);
-        double safe = dist > 1e-8 ? dist : 1e-8;
-        double q = rho / safe;
-        double f = (q > 1.0 || q < -1.0 || isnan(q)) ? AUV_PI : asin(q);   // NaN -> pi (sensor.py:34-36)
-        long long imin = (long long)floor((AUV_PI + (bearing - f)) / dangle);
-        long long imax = (long long)ceil((AUV_PI + (bearing + f)) / dangle);
-        lim = make_int2((int)imin, (int)imax);
-        start = imin - 1;
-        stop = auv_pymod(imax, S);                           // range(i_min - 1, i_max % S)
+        if (stop > start) {
+          o.start = start;
+          o.count = stop - start;
+          active = true;
+        }
       }
-      if (stop > start) {
-        o.start = (int)start;
-        o.count = (int)(stop - start);
-        if (meta.x != AUV_OBS_RING && !inside_known) o.inside = point_in_polygon(px, py, seg, meta.z) ? 1 : 0;
-        s_any = 1;
+      d.limits[(size_t)e * d.k_max + k] = lim;
+      L.obs[k] = o;
+    }
+    const unsigned long long mask = __ballot(active);
+    if (active) L.act[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+    n_act += __popcll(mask);
+  }
+  for (int k = K + lane; k < d.k_max; k += AUV_WAVE) d.limits[(size_t)e * d.k_max + k] = make_int2(INT32_MIN, INT32_MIN);
+  if (lane == 0) L.hdr->n_act = n_act;
+  auv_wave_lds_sync();
+  // prefix of boundary-segment counts over the active list (wave scan, 64 entries per pass);
+  // an obstacle is staged iff the prefix up to and including it fits the staging buffer
+  {
+    int carry = 0;
+    for (int ab = 0; ab < n_act; ab += AUV_WAVE) {
+      const int a = ab + lane;
+      int v = (a < n_act) ? L.obs[L.act[a]].nseg : 0;
+#pragma unroll
+      for (int o = 1; o < AUV_WAVE; o <<= 1) {
+        int t = __shfl_up(v, o, AUV_WAVE);
+        if (lane >= o) v += t;
+      }
+      if (a < n_act) {
+        const int end = carry + v, nseg = L.obs[L.act[a]].nseg;
+        L.sbase[a + 1] = end;
+        L.obs[L.act[a]].stage_off = (end <= K2_SEG_CAP) ? end - nseg : -1;
+        L.par[a] = 0;
+      }
+      carry += __shfl(v, AUV_WAVE - 1, AUV_WAVE);
+    }
+    if (lane == 0) L.sbase[0] = 0;
+  }
+  auv_wave_lds_sync();
+
+  // ---- phase S: one flattened, coalesced pass over the boundary segments that fit the stage ----
+  int n_staged = 0;                                    // obstacles staged (a prefix of the list)
+  while (n_staged < n_act && L.sbase[n_staged + 1] <= K2_SEG_CAP) n_staged++;
+  const int T = L.sbase[n_staged];
+  for (int t = lane; t < T; t += AUV_WAVE) {
+    int a = 0;
+    while (t >= L.sbase[a + 1]) a++;
+    const ObsLds o = L.obs[L.act[a]];
+    const int si = t - L.sbase[a];
+    const double4 s = (o.kind == AUV_OBS_MOVER) ? L.mvseg[o.seg_off + si] : d.seg[o.seg_off + si];
+    const double wx = s.x - px, wy = s.y - py, sx = s.z - s.x, sy = s.w - s.y;
+    L.stage[t] = make_double4(wx, wy, sx, sy);
+    L.stage_tn[t] = wx * sy - wy * sx;
+    if (o.kind != AUV_OBS_RING) {
+      // point-in-polygon predicates of this boundary segment (same tests as point_in_polygon)
+      const double dxa = px - s.x, dya = py - s.y;
+      const double len2 = sx * sx + sy * sy;
+      const double dot = dxa * sx + dya * sy;
+      bool on;
+      if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
+      else if (dot >= len2) on = (px == s.z && py == s.w);
+      else on = ((s.y - py) * sx - (s.x - px) * sy) == 0.0;
+      if (on) atomicOr(&L.par[a], 2);
+      if ((s.y > py) != (s.w > py)) {
+        const double xint = s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
+        if (px < xint) atomicXor(&L.par[a], 1);
       }
     }
-    d.limits[(size_t)e * d.k_max + k] = lim;
-    obs[k] = o;
   }
-  for (int k = K + tid; k < d.k_max; k += AUV_BLOCK) d.limits[(size_t)e * d.k_max + k] = make_int2(INT32_MIN, INT32_MIN);
-  __syncthreads();
+  // boundaries that did not fit are swept straight from HBM; their inside flag is computed here
+  for (int a = n_staged; a < n_act; a++) {
+    const ObsLds o = L.obs[L.act[a]];
+    if (o.kind != AUV_OBS_RING && lane == 0)
+      L.par[a] = ((o.kind == AUV_OBS_MOVER) ? point_in_polygon(px, py, L.mvseg + o.seg_off, o.nseg)
+                                            : point_in_polygon(px, py, d.seg + o.seg_off, o.nseg)) ? 1 : 0;
+  }
+  auv_wave_lds_sync();
+}
 
-  // ---- phase D: (ray, segment) pairs, one obstacle per wave at a time ------------------
-  if (s_any) {
-    const int wave = tid / AUV_WAVE, lane = tid % AUV_WAVE;
-    for (int k = wave; k < K; k += AUV_BLOCK / AUV_WAVE) {
-      const ObsLds o = obs[k];
-      if (o.count == 0) continue;
-      if (o.kind != AUV_OBS_RING && o.inside) {
-        // p0 inside a filled polygon: the clipped ray starts at p0 -> distance 0 on every ray
-        for (int q = lane; q < o.count; q += AUV_WAVE) atomicMin(&dbits[auv_pymod((long long)o.start + q, S)], 0ull);
-        continue;
-      }
-      const double4* seg = (o.kind == AUV_OBS_MOVER) ? (mvseg + o.seg_off) : (d.seg + o.seg_off);
-      const int total = o.count * o.nseg;
-      const float inv = 1.0f / (float)o.nseg;
-      for (int q = lane; q < total; q += AUV_WAVE) {
-        int ro = (total < 32768) ? (int)(((float)q + 0.5f) * inv) : q / o.nseg;
-        int si = q - ro * o.nseg;
-        int i = auv_pymod((long long)o.start + ro, S);
-        double4 s = seg[si];
-        double2 r = rayv[i];
-        double dist = ray_seg(px, py, r.x, r.y, s.x, s.y, s.z, s.w);
-        if (dist >= 0.0) atomicMin(&dbits[i], d2u(dist));
-      }
+// phase D for the environment whose slice is L, enumerated by `nthr` threads
+__device__ void k2_pairs(const AuvDev& d, const Slice& L, const int tid, const int nthr) {
+  const int S = d.cfg.n_sensors;
+  const int n_act = L.hdr->n_act;
+  const double px = L.hdr->px, py = L.hdr->py;
+  for (int a = 0; a < n_act; a++) {
+    const ObsLds o = L.obs[L.act[a]];
+    if (o.kind != AUV_OBS_RING && L.par[a] != 0) {
+      // p0 inside (or on) a filled polygon: the clipped ray starts at p0 -> distance 0 on every ray
+      for (int q = tid; q < o.count; q += nthr) atomicMin(&L.dbits[wrap_ray(o.start + q, S)], 0ull);
+    } else if (o.stage_off >= 0) {
+      const double4* sg = L.stage + o.stage_off;
+      const double* st = L.stage_tn + o.stage_off;
+      sweep_pairs(o, tid, nthr, S, px, py, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
+        wv = sg[si];
+        tn = st[si];
+      });
+    } else if (o.kind == AUV_OBS_MOVER) {
+      const double4* g = L.mvseg + o.seg_off;
+      sweep_pairs(o, tid, nthr, S, px, py, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
+        const double4 s = g[si];
+        wv = make_double4(s.x - px, s.y - py, s.z - s.x, s.w - s.y);
+        tn = wv.x * wv.w - wv.y * wv.z;
+      });
+    } else {
+      const double4* g = d.seg + o.seg_off;
+      sweep_pairs(o, tid, nthr, S, px, py, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
+        const double4 s = g[si];
+        wv = make_double4(s.x - px, s.y - py, s.z - s.x, s.w - s.y);
+        tn = wv.x * wv.w - wv.y * wv.z;
+      });
     }
   }
-  __syncthreads();
+}
 
-  // ---- phase E: outputs (vessel.py:88-95, :356-359) ---------------------------------------
+// phase E: outputs (vessel.py:88-95, :356-359)
+__device__ void k2_back(const AuvDev& d, const int e, const int lane, const Slice& L) {
+  const int S = d.cfg.n_sensors;
+  const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   int col = 0;
   const double logR = log(1 + R);
-  for (int i = tid; i < S; i += AUV_BLOCK) {
-    double di = u2d(dbits[i]);
+  for (int i = lane; i < S; i += AUV_WAVE) {
+    double di = u2d(L.dbits[i]);
     d.lidar_d[(size_t)e * S + i] = di;
     double cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0)
                                            : 1 - auv_clip(di / R, 0.0, 1.0);
     d.obs64[(size_t)e * (6 + S) + 6 + i] = auv_clip(cl, -1.0, 1.0);
     col |= (di < W);
   }
-  col = __syncthreads_or(col);
-  if (tid == 0) d.collision[e] = (uint8_t)(col != 0);
+  col = __any(col);
+  if (lane == 0) d.collision[e] = (uint8_t)(col != 0);
+}
+
+// all environments: wave g prepares env g; the pair sweep of the workgroup's four environments
+// is shared by its 256 threads
+__global__ void __launch_bounds__(AUV_BLOCK) k2_lidar(AuvDev d, int advance_movers) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int S = d.cfg.n_sensors;
+  const size_t sb = k2_slice_bytes(S, d.k_max, d.m_max);
+  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const bool valid = e < d.n;
+  const Slice L = carve(smem + wave * sb, S, d.k_max, d.m_max);
+  if (valid) k2_front(d, e, lane, L, advance_movers);
+  else if (lane == 0) L.hdr->n_act = 0;
+  if (!d.cfg.use_lidar) return;            // uniform over the grid
+  __syncthreads();
+#pragma unroll 1
+  for (int j = 0; j < AUV_ENVS_PER_BLOCK; j++) k2_pairs(d, carve(smem + j * sb, S, d.k_max, d.m_max), threadIdx.x, AUV_BLOCK);
+  __syncthreads();
+  if (valid) k2_back(d, e, lane, L);
+}
+
+// reset pass: only the environments on the fresh list (reset() / auto-reset), movers not
+// advanced; wave-synchronous (trip counts differ per wave, so no workgroup barriers here)
+__global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int S = d.cfg.n_sensors;
+  const int nf = *d.fresh_count;
+  const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
+  for (int i = blockIdx.x * AUV_ENVS_PER_BLOCK + wave; i < nf; i += gridDim.x * AUV_ENVS_PER_BLOCK) {
+    const int e = d.fresh_list[i];
+    k2_front(d, e, lane, L, 0);
+    if (d.cfg.use_lidar) {
+      k2_pairs(d, L, lane, AUV_WAVE);
+      auv_wave_lds_sync();
+      k2_back(d, e, lane, L);
+    }
+    auv_wave_lds_sync();
+  }
 }
 
 }  // namespace
 
 size_t auv_k2_lds_bytes(const AuvDev& d) {
-  size_t S = d.cfg.n_sensors;
-  return S * 8 + S * 16 + (size_t)d.m_max * AUV_MOVER_NSEG * 32 + (size_t)d.m_max * 32 +
-         (size_t)d.k_max * sizeof(ObsLds) + 16;
+  return k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
 }
 
-void auv_launch_k2(const AuvDev& d, int advance_movers, int only_fresh, hipStream_t st) {
-  hipLaunchKernelGGL(k2_lidar, dim3(d.n), dim3(AUV_BLOCK), auv_k2_lds_bytes(d), st, d, advance_movers,
-                     only_fresh);
+void auv_launch_k2(const AuvDev& d, int advance_movers, hipStream_t st) {
+  hipLaunchKernelGGL(k2_lidar, dim3((d.n + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK), dim3(AUV_BLOCK),
+                     auv_k2_lds_bytes(d), st, d, advance_movers);
+}
+
+void auv_launch_k2_fresh(const AuvDev& d, hipStream_t st) {
+  int grid = (d.n + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK;
+  if (grid > AUV_FRESH_GRID) grid = AUV_FRESH_GRID;
+  hipLaunchKernelGGL(k2_lidar_fresh, dim3(grid), dim3(AUV_BLOCK), auv_k2_lds_bytes(d), st, d);
 }

@@ -1,5 +1,5 @@
 // K3 — path navigation + reward + episode termination + observation assembly:
-// one 256-thread workgroup per environment.
+// ONE WAVE PER ENVIRONMENT, four environments per 256-thread workgroup, wave-synchronous.
 //
 // Reference: Vessel.navigate                  gym_auv/objects/vessel/vessel.py:461-541
 //            Path.get_closest_arclength       objects/path.py:84-93  (GEOS LineString.project:
@@ -9,12 +9,21 @@
 //            PathFollowRewarder.calculate     objects/rewarder.py:78-140
 //            BaseEnvironment.observe/step/_isdone  environment.py:247-290, 325-347, 375-384
 //
-// The projection streams the environment's dense polyline (P ~ 10 L vertices, fp64 x,y
-// interleaved = one 16-B load per lane, 1 KiB per wave-instruction) and min-reduces
-// (distance, first index) with wave shuffles, then one lane evaluates the spline and the
-// scalar logic.  The Colav closeness term is a block reduction over the S beams.
-// Roofline: HBM.  Algorithmic bytes per env-step: 16*P (polyline) + 8*S (d in) + 8*(6+S)
-// (obs64 r/w) + 4*(6+S) (obs f32 out) + ~400 (knot rows, scalars, info/nav/counters).
+// Nearest point on the dense polyline (P ~ 10 L vertices), EXACT but pruned: the polyline is
+// cut into chunks of 64 segments, each with a bounding circle (built at load time).
+//   pass 1  lanes <-> chunks: U = min over chunks of (|p - c| + rad)  -- an upper bound on the
+//           distance to the path;
+//   pass 2  a chunk can hold the (first) minimum only if |p - c| - rad <= U: the survivors
+//           (typically 1-3 of ~160) are listed in LDS in ascending order (ballot + popcount);
+//   pass 3  lanes <-> the 64 segments of each surviving chunk, GEOS point-segment distance,
+//           (distance, first index) min-reduced with wave shuffles.
+// Every segment that could win or tie survives, so the result (and the reference's "first
+// minimum wins" tie-break) is identical to the brute-force scan.  Then two lanes evaluate the
+// spline at s and s+look-ahead in parallel, the Colav closeness term is a wave reduction over
+// the S beams, lane 0 does the scalar reward / done logic.
+// Roofline: HBM.  Algorithmic bytes per env-step: 32*ceil((P-1)/64) (chunk circles) + ~3 KiB
+// (surviving chunks' vertices) + 8*S (d in) + 8*(6+S) (obs64 r/w) + 4*(6+S) (obs f32 out)
+// + ~600 (knot rows, scalars, info/nav/counters).
 #include "auv_device.h"
 
 namespace {
@@ -67,22 +76,38 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, int w, double s, doub
   }
 }
 
+// restore reset-time state of env e bound to world w2 (environment.py:203-213, vessel.py:189-224)
+__device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int lane, int episodes) {
+  const int S = d.cfg.n_sensors;
+  const size_t n = (size_t)d.n;
+  const double* ws2 = d.world_scalar + 8 * (size_t)w2;
+  if (lane == 0) {
+    d.world_idx[e] = w2;
+    d.state[0 * n + e] = ws2[3], d.state[1 * n + e] = ws2[4], d.state[2 * n + e] = ws2[5];
+    d.state[3 * n + e] = 0.0, d.state[4 * n + e] = 0.0, d.state[5 * n + e] = 0.0;
+    double* inf = d.info64 + 8 * (size_t)e;
+#pragma unroll
+    for (int i = 0; i < 8; i++) inf[i] = 0.0;
+    d.collision[e] = 0;
+    d.counters[e] = make_int4(0, 0, episodes, 0);
+    d.fresh_list[atomicAdd(d.fresh_count, 1)] = e;
+  }
+  for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
+  const long long m0 = d.mv_off[w2];
+  const int M = (int)(d.mv_off[w2 + 1] - m0);
+  for (int m = lane; m < M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = d.mv_init[m0 + m];
+  for (int k = lane; k < d.k_max; k += AUV_WAVE) d.nearby[(size_t)e * d.k_max + k] = 0;
+}
+
 // mode 0: navigate + observe + reward + done (+ auto-reset bookkeeping)
 // mode 1: navigate + observe only (reset path)
 // mode 2: reward + done only, from the buffers as they stand (test hook)
-__global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, int only_fresh,
-                                                           float* __restrict__ obs_out,
-                                                           float* __restrict__ reward_out,
-                                                           uint8_t* __restrict__ done_out) {
-  __shared__ MinIdx s_min[AUV_BLOCK / AUV_WAVE];
-  __shared__ double s_sum[2][AUV_BLOCK / AUV_WAVE];
-  __shared__ int s_reset;
-  const int e = blockIdx.x, tid = threadIdx.x;
-  const int wave = tid / AUV_WAVE, lane = tid % AUV_WAVE;
+__device__ void k3_env(const AuvDev& d, const int e, const int lane, const int mode, int* list,
+                       float* __restrict__ obs_out, float* __restrict__ reward_out,
+                       uint8_t* __restrict__ done_out) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   int4 cnt = d.counters[e];
-  if (only_fresh && cnt.w == 0) return;
   const int w = d.world_idx[e];
   const double* ws = d.world_scalar + 8 * (size_t)w;
   const double L = ws[0];
@@ -92,45 +117,75 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, i
   double* ob = d.obs64 + (size_t)e * (6 + S);
   const int D = 6 + (d.cfg.use_lidar ? S : 0);
 
+  AUV_STAMP_DECL
   if (mode != 2) {
-    // ---- nearest point on the dense polyline (path.py:84-93) ----
+    // ---- nearest point on the dense polyline (path.py:84-93), exact with chunk pruning ----
     const long long p0 = d.poly_off[w];
     const int P = (int)(d.poly_off[w + 1] - p0);
     const double2* xy = d.poly_xy + p0;
+    const long long c0 = d.chunk_off[w];
+    const int nch = (int)(d.chunk_off[w + 1] - c0);
+    const double4* cb = d.chunk_bound + c0;
+    double U = 1.7976931348623157e308;
+    for (int c = lane; c < nch; c += AUV_WAVE) {
+      double4 b = cb[c];
+      double dx = px - b.x, dy = py - b.y;
+      U = fmin(U, sqrt(dx * dx + dy * dy) + b.z);
+    }
+    U = auv_wave_min(U);
+    AUV_STAMP()
+    int n_act = 0;
+    for (int cbase = 0; cbase < nch; cbase += AUV_WAVE) {
+      const int c = cbase + lane;
+      bool act = false;
+      if (c < nch) {
+        double4 b = cb[c];
+        double dx = px - b.x, dy = py - b.y;
+        act = (sqrt(dx * dx + dy * dy) - b.z) <= U;
+      }
+      const unsigned long long mask = __ballot(act);
+      if (act) list[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = c;
+      n_act += __popcll(mask);
+    }
+    auv_wave_lds_sync();
+    AUV_STAMP()
     MinIdx best;
     best.d = 1.7976931348623157e308;
     best.j = 0x7fffffff;
-    for (int j = tid; j < P - 1; j += AUV_BLOCK) {
-      double2 a = xy[j], b = xy[j + 1];
-      double dd = auv_pt_seg_dist(px, py, a.x, a.y, b.x, b.y);
-      if (dd < best.d) best.d = dd, best.j = j;
+    for (int a = 0; a < n_act; a++) {
+      const int j = list[a] * AUV_CHUNK + lane;
+      if (j < P - 1) {
+        double2 A = xy[j], B = xy[j + 1];
+        double dd = auv_pt_seg_dist(px, py, A.x, A.y, B.x, B.y);
+        if (dd < best.d) best.d = dd, best.j = j;
+      }
     }
     best = wave_min_first(best);
-    if (lane == 0) s_min[wave] = best;
-    __syncthreads();
-    if (tid == 0) {
-      MinIdx b = s_min[0];
-#pragma unroll
-      for (int i = 1; i < AUV_BLOCK / AUV_WAVE; i++) b = min_first(b, s_min[i]);
-      const int bj = b.j;
-      // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure
-      double2 A = xy[bj], B = xy[bj + 1];
-      double dx = B.x - A.x, dy = B.y - A.y, len2 = dx * dx + dy * dy;
-      double seglen = sqrt(len2);
-      double pf = (len2 == 0.0) ? 0.0 : ((px - A.x) * dx + (py - A.y) * dy) / len2;
-      double cum = d.poly_cum[p0 + bj];
-      double s = pf <= 0.0 ? cum : (pf <= 1.0 ? cum + pf * seglen : cum + seglen);
-      // vessel.py:471-515
-      double p[2], dp[2], pt[2], dpt[2];
-      path_eval(d, w, s, L, p, dp);
-      double chi = atan2(dp[1], dp[0]);
+    AUV_STAMP()
+    const int bj = best.j;
+    // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure (all lanes, uniform)
+    double2 A = xy[bj], B = xy[bj + 1];
+    double dx = B.x - A.x, dy = B.y - A.y, len2 = dx * dx + dy * dy;
+    double seglen = sqrt(len2);
+    double pf = (len2 == 0.0) ? 0.0 : ((px - A.x) * dx + (py - A.y) * dy) / len2;
+    double cum = d.poly_cum[p0 + bj];
+    const double s = pf <= 0.0 ? cum : (pf <= 1.0 ? cum + pf * seglen : cum + seglen);
+    double s_t = s + d.cfg.look_ahead_distance;
+    if (L < s_t) s_t = L;
+    // vessel.py:471-515 -- lane 0 evaluates the spline at s, lane 1 at s_t (same instructions)
+    double p[2], dp[2];
+    path_eval(d, w, lane == 1 ? s_t : s, L, p, dp);
+    double dir = atan2(dp[1], dp[0]);                       // lane 0: chi; lane 1: look-ahead direction
+    double tgt = atan2(p[1] - py, p[0] - px);               // lane 1: target heading
+    const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(tgt, 1, AUV_WAVE);
+    if (lane == 0) {
+      const double chi = dir;
       double ddx = p[0] - px, ddy = p[1] - py;
-      double cte = sin(-chi) * ddx + cos(-chi) * ddy;
-      double s_t = s + d.cfg.look_ahead_distance;
-      if (L < s_t) s_t = L;
-      path_eval(d, w, s_t, L, pt, dpt);
-      double la = auv_princip(atan2(dpt[1], dpt[0]) - psi);
-      double he = auv_princip(atan2(pt[1] - py, pt[0] - px) - psi);
+      double sn, cs;
+      sincos(-chi, &sn, &cs);
+      double cte = sn * ddx + cs * ddy;
+      double la = auv_princip(la_dir - psi);
+      double he = auv_princip(tgt1 - psi);
       double progress = s / L;
       double maxp = inf[5];
       if (progress > maxp) maxp = progress;
@@ -141,13 +196,18 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, i
       nv[0] = u, nv[1] = v, nv[2] = r, nv[3] = la, nv[4] = he, nv[5] = cte / 100, nv[6] = chi, nv[7] = s_t;
       inf[0] = d.collision[e];
       inf[1] = reached, inf[2] = goal, inf[3] = progress, inf[5] = maxp, inf[6] = s, inf[7] = 0.0;
+      // environment.py:276-280; lane 0 also emits the float32 copies of its own six values so
+      // that no lane re-reads, within this kernel, global memory another lane has just written
 #pragma unroll
-      for (int i = 0; i < 6; i++) ob[i] = auv_clip(nv[i], -1.0, 1.0);   // environment.py:276-280
+      for (int i = 0; i < 6; i++) {
+        double c6 = auv_clip(nv[i], -1.0, 1.0);
+        ob[i] = c6;
+        if (obs_out) obs_out[(size_t)e * D + i] = (float)c6;   // (a reset pass overwrites the row)
+      }
     }
-    __syncthreads();
   }
 
-  int done = 0;
+  AUV_STAMP()
   if (mode != 1) {
     // ---- reward (rewarder.py) ----
     double num = 0.0, den = 0.0;
@@ -155,7 +215,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, i
     if (colav) {
       const double* dd = d.lidar_d + (size_t)e * S;
       const double dangle = 2 * AUV_PI / S;
-      for (int i = tid; i < S; i += AUV_BLOCK) {
+      for (int i = lane; i < S; i += AUV_WAVE) {
         double angle = -AUV_PI + (i + 1) * dangle;          // body-frame beam angle (vessel.py:66-68)
         double weight = 1 / (1 + fabs(10.0 * angle));        // gamma_theta
         double raw = d.cfg.sensor_range * exp(-0.1 * dd[i]); // gamma_x; velocity channel == 0 (sensor.py:159)
@@ -164,10 +224,9 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, i
       }
       num = auv_wave_sum(num);
       den = auv_wave_sum(den);
-      if (lane == 0) s_sum[0][wave] = num, s_sum[1][wave] = den;
     }
-    __syncthreads();
-    if (tid == 0) {
+    int do_reset = 0;
+    if (lane == 0) {
       const double lambda = 0.5, eta = 0.0, gamma_y_e = 5.0, penalty_yawrate = 10.0, neutral_speed = 0.05,
                    max_speed = 2.0;
       const int collision = d.collision[e];
@@ -185,13 +244,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, i
           reward = path_reward - living_penalty + eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) +
                    slow_penalty;
         } else {
-          double closeness_reward = 0.0;
-          if (S > 0) {
-            double tn = 0.0, td = 0.0;
-#pragma unroll
-            for (int i = 0; i < AUV_BLOCK / AUV_WAVE; i++) tn += s_sum[0][i], td += s_sum[1][i];
-            closeness_reward = -tn / td;
-          }
+          double closeness_reward = (S > 0) ? -num / den : 0.0;
           if (inf[3] < inf[5]) path_reward = fmin(path_reward, 0.0);
           double slow_penalty = (speed < 0.04) ? -2 : 0;
           reward = lambda * path_reward + (1 - lambda) * closeness_reward - living_penalty +
@@ -204,8 +257,8 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, i
       double cum = inf[4] + reward;
       inf[4] = cum;
       const int t_step = cnt.x;
-      done = collision || (inf[1] != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
-             (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);
+      const int done = collision || (inf[1] != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
+                       (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);
       cnt.x = t_step + 1;
       if (reward_out) reward_out[e] = (float)reward;
       if (done_out) done_out[e] = (uint8_t)done;
@@ -214,78 +267,73 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, i
         ep[0] = cum, ep[1] = t_step + 1, ep[2] = collision, ep[3] = inf[1];
         cnt.z += 1;
       }
-      s_reset = done && d.cfg.auto_reset;
-      if (!s_reset) {
-        cnt.w = 0;
-        d.counters[e] = cnt;
-      }
+      do_reset = done && d.cfg.auto_reset;
+      if (!do_reset) d.counters[e] = cnt;
     }
-    __syncthreads();
-    if (s_reset) {
-      // VecEnv auto-reset: rebind to the next world of the bank and restore reset-time state
-      // (environment.py:203-213, vessel.py:189-224); the reset observation is produced by the
-      // follow-up "fresh" pass (K2 + K3 mode 1).
-      const int w2 = (int)(((long long)w + d.n) % d.n_worlds);
-      const double* ws2 = d.world_scalar + 8 * (size_t)w2;
-      if (tid == 0) {
-        d.world_idx[e] = w2;
-        d.state[0 * n + e] = ws2[3], d.state[1 * n + e] = ws2[4], d.state[2 * n + e] = ws2[5];
-        d.state[3 * n + e] = 0.0, d.state[4 * n + e] = 0.0, d.state[5 * n + e] = 0.0;
-        for (int i = 0; i < 8; i++) inf[i] = 0.0;
-        d.collision[e] = 0;
-        d.counters[e] = make_int4(0, 0, cnt.z, 1);   // fresh
-      }
-      for (int i = tid; i < S; i += AUV_BLOCK) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
-      const long long m0 = d.mv_off[w2];
-      const int M = (int)(d.mv_off[w2 + 1] - m0);
-      for (int m = tid; m < M; m += AUV_BLOCK) d.mover[(size_t)e * d.m_max + m] = d.mv_init[m0 + m];
-      for (int k = tid; k < d.k_max; k += AUV_BLOCK) d.nearby[(size_t)e * d.k_max + k] = 0;
-      return;   // obs written by the fresh pass
+    do_reset = __shfl(do_reset, 0, AUV_WAVE);
+    AUV_STAMP()
+    AUV_STAMP_FLUSH(e, 8)   // 8:bounds 9:list 10:scan 11:nav 12:reward
+    if (do_reset) {
+      // VecEnv auto-reset: rebind to the next world of the bank; the reset observation is
+      // produced by the follow-up reset pass (k2_lidar_fresh + k3_observe_fresh).
+      restore_env(d, e, (int)(((long long)w + d.n) % d.n_worlds), lane, __shfl(cnt.z, 0, AUV_WAVE));
+      return;
     }
-  } else if (tid == 0) {
-    cnt.w = 0;   // observed: no longer fresh
-    d.counters[e] = cnt;
   }
 
-  // ---- observation row, float32 (environment.py:139-143, :263-280) ----
+  // ---- observation row, float32 (environment.py:139-143, :263-280): closeness part written by K2 ----
   if (obs_out && mode != 2) {
-    for (int i = tid; i < D; i += AUV_BLOCK) obs_out[(size_t)e * D + i] = (float)ob[i];
+    for (int i = 6 + lane; i < D; i += AUV_WAVE) obs_out[(size_t)e * D + i] = (float)ob[i];
   }
 }
 
-// reset(): restore reset-time state for masked envs and mark them fresh
+__global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, float* __restrict__ obs_out,
+                                                           float* __restrict__ reward_out,
+                                                           uint8_t* __restrict__ done_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  if (e >= d.n) return;
+  k3_env(d, e, lane, mode, (int*)smem + (size_t)wave * d.nch_max, obs_out, reward_out, done_out);
+}
+
+// reset pass: first observation of the environments on the fresh list (mode 1)
+__global__ void __launch_bounds__(AUV_BLOCK) k3_observe_fresh(AuvDev d, float* __restrict__ obs_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int nf = *d.fresh_count;
+  int* list = (int*)smem + (size_t)wave * d.nch_max;
+  for (int i = blockIdx.x * AUV_ENVS_PER_BLOCK + wave; i < nf; i += gridDim.x * AUV_ENVS_PER_BLOCK) {
+    k3_env(d, d.fresh_list[i], lane, 1, list, obs_out, nullptr, nullptr);
+    auv_wave_lds_sync();
+  }
+}
+
+// reset(): restore reset-time state for masked envs and put them on the fresh list
 __global__ void __launch_bounds__(AUV_BLOCK) k_reset(AuvDev d, const uint8_t* __restrict__ mask,
                                                      const int32_t* __restrict__ world_idx) {
-  const int e = blockIdx.x, tid = threadIdx.x;
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  if (e >= d.n) return;
   if (mask && !mask[e]) return;
-  const int S = d.cfg.n_sensors;
-  const size_t n = (size_t)d.n;
   const int w = world_idx ? world_idx[e] : d.world_idx[e];
-  const double* ws = d.world_scalar + 8 * (size_t)w;
-  if (tid == 0) {
-    d.world_idx[e] = w;
-    d.state[0 * n + e] = ws[3], d.state[1 * n + e] = ws[4], d.state[2 * n + e] = ws[5];
-    d.state[3 * n + e] = 0.0, d.state[4 * n + e] = 0.0, d.state[5 * n + e] = 0.0;
-    double* inf = d.info64 + 8 * (size_t)e;
-    for (int i = 0; i < 8; i++) inf[i] = 0.0;
-    d.collision[e] = 0;
-    int4 c = d.counters[e];
-    d.counters[e] = make_int4(0, 0, c.z, 1);
-  }
-  for (int i = tid; i < S; i += AUV_BLOCK) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
-  const long long m0 = d.mv_off[w];
-  const int M = (int)(d.mv_off[w + 1] - m0);
-  for (int m = tid; m < M; m += AUV_BLOCK) d.mover[(size_t)e * d.m_max + m] = d.mv_init[m0 + m];
-  for (int k = tid; k < d.k_max; k += AUV_BLOCK) d.nearby[(size_t)e * d.k_max + k] = 0;
+  restore_env(d, e, w, lane, d.counters[e].z);
 }
 
 }  // namespace
 
-void auv_launch_k3(const AuvDev& d, int mode, int only_fresh, float* obs, float* reward, uint8_t* done,
-                   hipStream_t st) {
-  hipLaunchKernelGGL(k3_nav_reward, dim3(d.n), dim3(AUV_BLOCK), 0, st, d, mode, only_fresh, obs, reward, done);
+static size_t k3_lds_bytes(const AuvDev& d) { return (size_t)AUV_ENVS_PER_BLOCK * d.nch_max * sizeof(int); }
+static int env_grid(const AuvDev& d) { return (d.n + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK; }
+
+void auv_launch_k3(const AuvDev& d, int mode, float* obs, float* reward, uint8_t* done, hipStream_t st) {
+  hipLaunchKernelGGL(k3_nav_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), k3_lds_bytes(d), st, d, mode, obs, reward, done);
+}
+
+void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st) {
+  int grid = env_grid(d) < AUV_FRESH_GRID ? env_grid(d) : AUV_FRESH_GRID;
+  hipLaunchKernelGGL(k3_observe_fresh, dim3(grid), dim3(AUV_BLOCK), k3_lds_bytes(d), st, d, obs);
 }
 
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, hipStream_t st) {
-  hipLaunchKernelGGL(k_reset, dim3(d.n), dim3(AUV_BLOCK), 0, st, d, mask, world_idx);
+  hipLaunchKernelGGL(k_reset, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, mask, world_idx);
 }

@@ -131,7 +131,9 @@ enum {
   AUV_FIELD_NAV64 = 11,      /* [N][8] unclipped Vessel.navigate outputs: u, v, r,
                                  look_ahead_heading_error, heading_error, cross_track_error/100,
                                  path_direction, target_arclength        (vessel.py:518-536) */
-  AUV_FIELD_COLLISION = 12   /* [N] uint8  Vessel._collision                                */
+  AUV_FIELD_COLLISION = 12,  /* [N] uint8  Vessel._collision                                */
+  AUV_FIELD_STAMPS = 13      /* [N][16] uint64 per-phase cycle counts; zeros unless the library
+                                 was built with STAMPS=1 (diagnostic)                       */
 };
 
 /* Create an environment batch of n_envs on device `device_id`.            (environment.py:29-164) */

@@ -1,0 +1,20 @@
+"""Diagnostic: per-phase cycle shares of K2/K3 (library must be built with `make STAMPS=1`).
+Usage on the GPU box: python bench.py --bank-cache /tmp/bank --steps 20 --cpu-baseline 0; python tools/phase_stamps.py"""
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gym_auv_amd.batched_env import BatchedAuvEnv
+from gym_auv_amd.config import effective_reference_config
+from gym_auv_amd.world import build_bank_parallel
+cfg = effective_reference_config(use_lidar=True)
+n = 4096
+z = np.load("/tmp/bank.polygons50.0.4096.npz"); bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
+env = BatchedAuvEnv(cfg, bank, n, auto_reset=True)
+env.reset()
+a = torch.rand((n, 2), device="cuda:0") * 2 - 1
+for i in range(30): env.step(a)
+torch.cuda.synchronize()
+st = env.read("STAMPS").cpu().numpy().astype(np.float64)
+names = ["K2.A movers", "K2.C rays", "K2.B windows", "K2.D pairs", "K2.E out", "-", "-", "-", "K3.bounds", "K3.list", "K3.scan", "K3.nav", "K3.reward"]
+for i, nm in enumerate(names):
+    if nm != "-": print("%-12s mean %9.0f  p50 %9.0f  max %9.0f ticks" % (nm, st[:, i].mean(), np.median(st[:, i]), st[:, i].max()))
+print(env.step_timed(a))
