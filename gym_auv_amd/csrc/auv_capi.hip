@@ -19,6 +19,7 @@ void auv_launch_k3(const AuvDev& d, int mode, float* obs, float* reward, uint8_t
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st);
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
+hipError_t auv_k2_prepare(const AuvDev& d);
 
 static thread_local char g_err[512] = "";
 
@@ -227,7 +228,8 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   std::vector<int32_t> wi(n);
   for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(e % (size_t)W);
   HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (auv_k2_lds_bytes(d) > 64 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds 64 KiB per workgroup", auv_k2_lds_bytes(d));
+  if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
+  HIP_TRY(auv_k2_prepare(d));
   if ((size_t)AUV_ENVS_PER_BLOCK * d.nch_max * 4 > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);

@@ -139,7 +139,7 @@ __device__ __forceinline__ Slice carve(unsigned char* p, int S, int k_max, int m
 // seg_at(si) yields (wx, wy, sx, sy) and the ray-independent numerator tn = wx*sy - wy*sx of t
 // (sensor.py:140-159)
 template <typename SegFn>
-__device__ __forceinline__ void sweep_pairs(const ObsLds& o, int tid, int nthr, int S, double px, double py,
+__device__ __forceinline__ void sweep_pairs(const ObsLds& o, int tid, int nthr, int S,
                                             const double2* rayv, unsigned long long* dbits, SegFn seg_at) {
   const int total = o.count * o.nseg;
   const float inv = 1.0f / (float)o.nseg;
@@ -159,12 +159,10 @@ __device__ __forceinline__ void sweep_pairs(const ObsLds& o, int tid, int nthr, 
     const bool neg = den < 0.0;
     const double dn = neg ? -den : den, t1 = neg ? -tn : tn, u1 = neg ? -un : un;
     const bool hit = (dn != 0.0) & (t1 >= 0.0) & (t1 <= dn) & (u1 >= 0.0) & (u1 <= dn);
-    if (hit) {
-      const double t = tn / den;
-      const double X = px + t * r.x, Y = py + t * r.y;
-      const double dx = X - px, dy = Y - py;
-      atomicMin(&dbits[i], d2u(sqrt(dx * dx + dy * dy)));
-    }
+    // The reference's distance |p0 + t r - p0| is (weakly) monotone in t for a fixed ray, also in
+    // floating point, so min over hits of the distance == distance at the min t: keep min t
+    // (t in [0, 1], ordered as uint64) and form the distance once per ray in phase E.
+    if (hit) atomicMin(&dbits[i], d2u(tn / den));
   }
 }
 
@@ -243,7 +241,7 @@ __device__ void k2_front(const AuvDev& d, const int e, const int lane, const Sli
     // end point minus origin, formed exactly as the reference forms the end point
     double ex = px + c * R, ey = py + s * R;
     L.rayv[i] = make_double2(ex - px, ey - py);
-    L.dbits[i] = d2u(R);
+    L.dbits[i] = d2u(2.0);   // no hit yet (hits have t in [0, 1])
   }
   auv_wave_lds_sync();
 
@@ -266,14 +264,32 @@ __device__ void k2_front(const AuvDev& d, const int e, const int lane, const Sli
       uint8_t near;
       if (refresh) {
         // vessel.py:266-273: Point.distance(boundary) - width < range (filled: 0 inside)
-        bool in = false;
-        if (meta.x != AUV_OBS_RING)
-          in = mover ? point_in_polygon(px, py, L.mvseg + o.seg_off, meta.z)
-                     : point_in_polygon(px, py, d.seg + meta.y, meta.z);
-        const double dist = in ? 0.0
-                               : (mover ? point_boundary_distance(px, py, L.mvseg + o.seg_off, meta.z)
-                                        : point_boundary_distance(px, py, d.seg + meta.y, meta.z));
-        near = (dist - W < R) ? 1 : 0;
+        // The boundary lies inside the obstacle's enclosing circle (c, rho), so
+        //   |p0 - c| - rho <= distance(p0, boundary) <= |p0 - c| + rho ;
+        // only obstacles the two bounds cannot classify need the exact distance (same answer,
+        // far fewer segment loops).  1e-9 m of slack keeps rounding on the exact side.
+        double cx, cy, rho;
+        if (mover) {
+          double4 c4 = L.mvcull[meta.w];
+          cx = c4.x, cy = c4.y, rho = c4.z;
+        } else {
+          cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
+        }
+        const double dc = sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy));
+        if (dc - rho - W >= R + 1e-9) {
+          near = 0;
+        } else if (dc + rho - W < R - 1e-9) {
+          near = 1;
+        } else {
+          bool in = false;
+          if (meta.x != AUV_OBS_RING)
+            in = mover ? point_in_polygon(px, py, L.mvseg + o.seg_off, meta.z)
+                       : point_in_polygon(px, py, d.seg + meta.y, meta.z);
+          const double dist = in ? 0.0
+                                 : (mover ? point_boundary_distance(px, py, L.mvseg + o.seg_off, meta.z)
+                                          : point_boundary_distance(px, py, d.seg + meta.y, meta.z));
+          near = (dist - W < R) ? 1 : 0;
+        }
         d.nearby[(size_t)e * d.k_max + k] = near;
       } else {
         near = d.nearby[(size_t)e * d.k_max + k];
@@ -397,20 +413,20 @@ __device__ void k2_pairs(const AuvDev& d, const Slice& L, const int tid, const i
     } else if (o.stage_off >= 0) {
       const double4* sg = L.stage + o.stage_off;
       const double* st = L.stage_tn + o.stage_off;
-      sweep_pairs(o, tid, nthr, S, px, py, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
+      sweep_pairs(o, tid, nthr, S, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
         wv = sg[si];
         tn = st[si];
       });
     } else if (o.kind == AUV_OBS_MOVER) {
       const double4* g = L.mvseg + o.seg_off;
-      sweep_pairs(o, tid, nthr, S, px, py, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
+      sweep_pairs(o, tid, nthr, S, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
         const double4 s = g[si];
         wv = make_double4(s.x - px, s.y - py, s.z - s.x, s.w - s.y);
         tn = wv.x * wv.w - wv.y * wv.z;
       });
     } else {
       const double4* g = d.seg + o.seg_off;
-      sweep_pairs(o, tid, nthr, S, px, py, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
+      sweep_pairs(o, tid, nthr, S, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
         const double4 s = g[si];
         wv = make_double4(s.x - px, s.y - py, s.z - s.x, s.w - s.y);
         tn = wv.x * wv.w - wv.y * wv.z;
@@ -425,8 +441,17 @@ __device__ void k2_back(const AuvDev& d, const int e, const int lane, const Slic
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   int col = 0;
   const double logR = log(1 + R);
+  const double px = L.hdr->px, py = L.hdr->py;
   for (int i = lane; i < S; i += AUV_WAVE) {
-    double di = u2d(L.dbits[i]);
+    const double t = u2d(L.dbits[i]);
+    double di = R;                                          // sensor.py:156
+    if (t <= 1.0) {
+      // intersection point, then Point.distance: exactly the reference's arithmetic
+      const double2 r = L.rayv[i];
+      const double X = px + t * r.x, Y = py + t * r.y;
+      const double dx = X - px, dy = Y - py;
+      di = sqrt(dx * dx + dy * dy);
+    }
     d.lidar_d[(size_t)e * S + i] = di;
     double cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0)
                                            : 1 - auv_clip(di / R, 0.0, 1.0);
@@ -447,14 +472,21 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar(AuvDev d, int advance_move
   const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
   const bool valid = e < d.n;
   const Slice L = carve(smem + wave * sb, S, d.k_max, d.m_max);
+  AUV_STAMP_DECL
   if (valid) k2_front(d, e, lane, L, advance_movers);
   else if (lane == 0) L.hdr->n_act = 0;
   if (!d.cfg.use_lidar) return;            // uniform over the grid
+  AUV_STAMP()
   __syncthreads();
+  AUV_STAMP()
 #pragma unroll 1
   for (int j = 0; j < AUV_ENVS_PER_BLOCK; j++) k2_pairs(d, carve(smem + j * sb, S, d.k_max, d.m_max), threadIdx.x, AUV_BLOCK);
+  AUV_STAMP()
   __syncthreads();
+  AUV_STAMP()
   if (valid) k2_back(d, e, lane, L);
+  AUV_STAMP()
+  if (valid) { AUV_STAMP_FLUSH(e, 0) }   // 0:front 1:barrier 2:pairs 3:barrier 4:back
 }
 
 // reset pass: only the environments on the fresh list (reset() / auto-reset), movers not
@@ -481,6 +513,15 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
 
 size_t auv_k2_lds_bytes(const AuvDev& d) {
   return k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
+}
+
+// gfx950 has 160 KiB of LDS per CU; footprints above the 64 KiB default need the opt-in.
+hipError_t auv_k2_prepare(const AuvDev& d) {
+  const size_t b = auv_k2_lds_bytes(d);
+  if (b <= 64 * 1024) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)k2_lidar, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)k2_lidar_fresh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
 }
 
 void auv_launch_k2(const AuvDev& d, int advance_movers, hipStream_t st) {

@@ -138,3 +138,142 @@ def polygon_world(seed: int, n_polygons: int = 50, n_circles: int = 0, n_moving:
     base.polygons = polys
     base.name = "polygon_world_seed%d" % seed
     return base
+
+
+# ------------------------------------------------------------------------------------------
+# The reference's fixed test scenarios (/root/reference/gym_auv/envs/testscenario.py:20-360)
+def _start_on_path(path: Path) -> np.ndarray:
+    p = path(0)
+    return np.array([p[0], p[1], path.get_direction(0)])
+
+
+def _mover_from_table(width, waypoints: np.ndarray, dt: float, trailing_update: bool) -> MoverSpec:
+    """VesselObstacle from unit-time waypoints [n, 2]: velocities = successive differences
+    (obstacles.py:160-173); reset-time state = constructor's update(0.1) (+ the scenario's
+    trailing _update() where it has one)."""
+    vel = np.diff(waypoints, axis=0)
+    n_vel = len(vel)
+    if np.abs(vel - vel[0]).max() < 1e-9:
+        vel = vel[:1]
+    param = (float(width), waypoints[0, 0], waypoints[0, 1], n_vel)
+    st = (waypoints[0, 0], waypoints[0, 1], np.pi / 2, 0.0)
+    st = advance_mover(param, vel, st, 0.1)
+    if trailing_update:
+        st = advance_mover(param, vel, st, dt)
+    return MoverSpec(width=float(width), pos0=waypoints[0].copy(), vel=vel, n_vel=n_vel,
+                     pos=np.array(st[:2]), heading=float(st[2]), counter=float(st[3]))
+
+
+def test_scenario1() -> WorldSpec:
+    wp = np.array([[0.0, 1100.0], [0.0, 1100.0]])
+    path = Path(wp)
+    circles, arclen = [], 30.0
+    for o in range(20):
+        r = 10 + 10 * o ** 1.5
+        arclen += r * 2 + 30
+        p = path(arclen)
+        circles.append([p[0], p[1], r])
+    return WorldSpec(waypoints=wp, vessel_init=_start_on_path(path), circles=np.array(circles), name="TestScenario1")
+
+
+def test_scenario2() -> WorldSpec:
+    wp = np.vstack([[t * np.cos(t / 100), 2 * t] for t in range(500)]).T
+    path = Path(wp)
+    circles, arclen, r = [], 30.0, 5
+    while True:
+        arclen += 2 * r
+        if arclen >= path.length:
+            break
+        disp = 140 - 120 / (1 + np.exp(-0.005 * arclen))
+        p = path(arclen)
+        ang = path.get_direction(arclen) - np.pi / 2
+        off = disp * np.array([np.cos(ang), np.sin(ang)])
+        circles.append([p[0] + off[0], p[1] + off[1], r])
+        circles.append([p[0] - off[0], p[1] - off[1], r])
+    return WorldSpec(waypoints=wp, vessel_init=_start_on_path(path), circles=np.array(circles), name="TestScenario2")
+
+
+def _ring_of_circles(keep) -> WorldSpec:
+    wp = np.vstack([[0, 0], [0, 500]]).T.astype(np.float64)
+    path = Path(wp)
+    circles = []
+    for n in range(21):
+        ang = keep(n)
+        if ang is None:
+            continue
+        circles.append([np.cos(ang) * 100, np.sin(ang) * 100, 25])
+    return WorldSpec(waypoints=wp, vessel_init=_start_on_path(path), circles=np.array(circles, dtype=np.float64))
+
+
+def test_scenario3() -> WorldSpec:
+    w = _ring_of_circles(lambda n: np.pi / 4 + n / 20 * np.pi / 2)
+    w.name = "TestScenario3"
+    return w
+
+
+def test_scenario4() -> WorldSpec:
+    # testscenario.py:125 compares a boolean (`abs(angle < 3/2*pi) < pi/12`): it skips exactly
+    # the obstacles with angle >= 3/2 pi -- reproduced as is
+    def keep(n):
+        ang = n / 20 * 2 * np.pi
+        return None if abs(ang < 3 / 2 * np.pi) < np.pi / 12 else ang
+    w = _ring_of_circles(keep)
+    w.name = "TestScenario4"
+    return w
+
+
+def _single_mover_world(path_wp, start_angle, radius, direction_vec, speed, dt, name) -> WorldSpec:
+    path = Path(np.asarray(path_wp, dtype=np.float64))
+    init = _start_on_path(path)
+    start = np.array([init[0] + radius * np.sin(start_angle), init[1] + radius * np.cos(start_angle)])
+    i = np.arange(5000)[:, None]
+    pts = start[None, :] + speed * np.asarray(direction_vec)[None, :] * i
+    pts[0] = start
+    return WorldSpec(waypoints=np.asarray(path_wp, dtype=np.float64), vessel_init=init,
+                     movers=[_mover_from_table(30, pts, dt, trailing_update=True)], name=name)
+
+
+def test_head_on(seed: int = 0, dt: float = 0.5) -> WorldSpec:
+    import random as _random
+    a = _random.Random(seed).uniform(-5 * np.pi / 180, 5 * np.pi / 180)   # testscenario.py:147
+    return _single_mover_world(np.vstack([[0, 0], [0, 250]]).T, a, 150, (-np.sin(a), -np.cos(a)), 0.5, dt, "TestHeadOn")
+
+
+def test_crossing(dt: float = 0.5) -> WorldSpec:
+    sh = 90 * np.pi / 180
+    return _single_mover_world(np.vstack([[0, 0], [0, 500]]).T, -45 * np.pi / 180, 200, (np.sin(sh), np.cos(sh)), 0.5, dt,
+                               "TestCrossing")
+
+
+def test_crossing1(dt: float = 0.5) -> WorldSpec:
+    sh = -50 * np.pi / 180
+    return _single_mover_world(np.vstack([[0, 0], [0, 500]]).T, 70 * np.pi / 180, 200, (np.sin(sh), np.cos(sh)), 0.5, dt,
+                               "TestCrossing1")
+
+
+def empty_scenario() -> WorldSpec:
+    wp = np.vstack([[25, 10], [25, 200]]).T.astype(np.float64)
+    return WorldSpec(waypoints=wp, vessel_init=_start_on_path(Path(wp)), name="EmptyScenario")
+
+
+def debug_scenario(seed: int = 0, dt: float = 0.5) -> WorldSpec:
+    """testscenario.py:291-360: 5 movers on circles + 5 on straight lines, parameters from the
+    env-local stream; no trailing _update()."""
+    rng, _ = np_random(seed)
+    wp = np.vstack([[250, 100], [250, 200]]).T.astype(np.float64)
+    path = Path(wp)
+    i = np.arange(10000)
+    movers = []
+    for idx in range(5):
+        shift = rng.rand() * 2 * np.pi
+        radius = rng.rand() * 40 + 30
+        speed = rng.rand() * 0.003 + 0.003
+        pts = np.stack([250 + radius * np.cos(speed * i + shift), 150 + 70 * idx + radius * np.sin(speed * i + shift)], axis=1)
+        movers.append(_mover_from_table(6, pts, dt, trailing_update=False))
+    for idx in range(5):
+        start = rng.rand() * 200 + 150
+        speed = rng.rand() * 0.03 + 0.03
+        shift = 10 * rng.rand()
+        pts = np.stack([np.full(len(i), 245 + 2.5 * idx + shift), start - 10 * speed * i], axis=1)
+        movers.append(_mover_from_table(6, pts, dt, trailing_update=False))
+    return WorldSpec(waypoints=wp, vessel_init=_start_on_path(path), movers=movers, name="DebugScenario")

@@ -1,0 +1,71 @@
+"""-m gpu: the single-environment gym.Env-style adapter, mirroring the reference's own
+tests/test_end_to_end.py:20-58 (every registered scenario id: reset, one step([0.5, 0.6]),
+observation inside the space, reward/done/info types, observation changed) and
+tests/test_config.py (observation length follows the LiDAR setting)."""
+import numpy as np
+import pytest
+
+from gym_auv_amd.config import Config, effective_reference_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _ids():
+    from gym_auv_amd.env import SCENARIOS
+    return list(SCENARIOS.keys())
+
+
+@pytest.mark.parametrize("scenario_name", ["MovingObstaclesNoRules-v0", "PathFollowNoObstacles-v0", "TestScenario1-v0",
+                                           "TestScenario2-v0", "TestScenario3-v0", "TestScenario4-v0", "TestHeadOn-v0",
+                                           "TestCrossing-v0", "TestCrossing1-v0", "DebugScenario-v0", "EmptyScenario-v0"])
+def test_single_step(scenario_name):
+    from gym_auv_amd.env import make
+    assert scenario_name in _ids()
+    env = make(scenario_name)
+    first_obs = env.reset()
+    obs, reward, done, info = env.step(np.array([0.5, 0.6]))
+    space = env.observation_space
+    assert isinstance(obs, np.ndarray) and obs.shape == space.shape == (6,)      # LiDAR is off by default
+    assert np.all(space.low <= obs) and np.all(space.high >= obs)
+    assert isinstance(reward, float) and isinstance(done, bool) and isinstance(info, dict)
+    assert set(info) == {"collision", "reached_goal", "goal_distance", "progress"}
+    assert np.any(first_obs != obs)
+    env.close()
+
+
+def test_lidar_observation_length_and_episode_bookkeeping():
+    from gym_auv_amd.env import make
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.episode.max_timesteps = 6
+    env = make("MovingObstaclesNoRules-v0", env_config=cfg)
+    env.seed(3)
+    obs = env.reset()
+    assert obs.shape == (6 + cfg.vessel.n_lidar_observations,) == (186,)
+    done, steps = False, 0
+    while not done:
+        obs, reward, done, info = env.step(env.action_space.sample())
+        steps += 1
+    assert steps == 6                       # done once t_step (before its increment) reaches max_timesteps - 1
+    env.reset()
+    assert len(env.history) == 1 and env.history[0]["timesteps"] == 6 and env.episode == 3
+    assert env.total_t_steps == 6
+    # accepts the RLlib-style {"config": Config} wrapper too (environment.py:66-74)
+    from gym_auv_amd.env import AuvEnv
+    e2 = AuvEnv({"config": Config()})
+    assert e2.config.simulation.t_step_size == 1.0
+    e2.close(), env.close()
+
+
+def test_seed_reproduces_world_and_rollout():
+    from gym_auv_amd.env import make
+    outs = []
+    for _ in range(2):
+        env = make("MovingObstaclesNoRules-v0", env_config=effective_reference_config(use_lidar=True))
+        env.seed(11)
+        o0 = env.reset()
+        o1, r1, _, _ = env.step(np.array([0.9, 0.1]))
+        outs.append((o0, o1, r1))
+        env.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]

@@ -107,3 +107,31 @@ def test_pack_bank_layout_and_roundtrip(tmp_path):
     back = unpack_world(np.load(tmp_path / "w.npz"), "w_")
     assert len(back.polygons) == 10
     np.testing.assert_array_equal(back.polygons[3], specs[2].polygons[3])
+
+
+def test_fixed_test_scenarios_match_reference_worlds():
+    """TestScenario1 / TestHeadOn / DebugScenario generators vs worlds captured from the
+    reference (first-episode semantics: the reference's TestScenario* append their obstacles
+    again on every reset, so the captured second-episode list holds each circle twice)."""
+    from gym_auv_amd import scenarios as sc
+    z = load("g5_rollouts.npz")
+    names = [str(n) for n in z["names"]]
+    for name, mine in (("testscenario1", sc.test_scenario1()), ("headon", sc.test_head_on(51)),
+                       ("debug", sc.debug_scenario(61))):
+        ref = unpack_world(z, "r%d_w_" % names.index(name))
+        np.testing.assert_array_equal(ref.waypoints, mine.waypoints)
+        np.testing.assert_allclose(ref.vessel_init, mine.vessel_init, rtol=0, atol=1e-15)
+        nc = len(mine.circles)
+        if nc:
+            np.testing.assert_array_equal(ref.circles[:nc], mine.circles)
+            assert len(ref.circles) in (nc, 2 * nc)
+        assert len(ref.movers) == len(mine.movers)
+        for a, b in zip(ref.movers, mine.movers):
+            assert a.width == b.width and a.n_vel == b.n_vel and a.counter == pytest.approx(b.counter)
+            np.testing.assert_allclose(a.pos, b.pos, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(a.vel, b.vel, rtol=0, atol=1e-12)
+    assert len(sc.test_scenario2().circles) == 278
+    assert len(sc.test_scenario3().circles) == 21
+    assert len(sc.test_scenario4().circles) == 15      # the boolean-compare quirk (testscenario.py:125)
+    assert len(sc.test_crossing().movers) == len(sc.test_crossing1().movers) == 1
+    assert len(sc.empty_scenario().circles) == 0

@@ -14,7 +14,7 @@ a = torch.rand((n, 2), device="cuda:0") * 2 - 1
 for i in range(30): env.step(a)
 torch.cuda.synchronize()
 st = env.read("STAMPS").cpu().numpy().astype(np.float64)
-names = ["K2.A movers", "K2.C rays", "K2.B windows", "K2.D pairs", "K2.E out", "-", "-", "-", "K3.bounds", "K3.list", "K3.scan", "K3.nav", "K3.reward"]
+names = ["K2.front", "K2.barrier1", "K2.pairs(4 envs)", "K2.barrier2", "K2.back", "-", "-", "-", "K3.bounds", "K3.list", "K3.scan", "K3.nav", "K3.reward"]
 for i, nm in enumerate(names):
-    if nm != "-": print("%-12s mean %9.0f  p50 %9.0f  max %9.0f ticks" % (nm, st[:, i].mean(), np.median(st[:, i]), st[:, i].max()))
+    if nm != "-": print("%-18s mean %9.0f  p50 %9.0f  max %9.0f ticks" % (nm, st[:, i].mean(), np.median(st[:, i]), st[:, i].max()) + '  argmax env %d' % st[:, i].argmax())
 print(env.step_timed(a))
