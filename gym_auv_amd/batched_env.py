@@ -135,21 +135,25 @@ class BatchedAuvEnv:
                                    self._stream()), "auv_nav_reward")
         return self.done
 
-    # hipGraph: capture once (fixed action buffer), replay per step
-    def capture_graph(self, dtype=torch.float32):
-        self._graph_actions = torch.zeros((self.n_envs, 2), dtype=dtype, device=self.device)
+    # hipGraph: capture once, replay per step.  `slots` > 1 makes the action buffer a ring of
+    # [slots, N, 2]: step k consumes slot k % slots, so nothing has to be copied or re-bound.
+    def capture_graph(self, dtype=torch.float32, slots: int = 1):
+        self._graph_actions = torch.zeros((slots, self.n_envs, 2), dtype=dtype, device=self.device)
         dt = _capi.AUV_F64 if dtype == torch.float64 else _capi.AUV_F32
         torch.cuda.synchronize(self.device)
+        _check(_LIB.auv_set_action_ring(self._h, int(slots)), "auv_set_action_ring")
         _check(_LIB.auv_graph_capture(self._h, C.c_void_p(self._graph_actions.data_ptr()), dt,
                                       C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
                                       C.c_void_p(self.done.data_ptr()), self._stream()), "auv_graph_capture")
-        return self._graph_actions
+        return self._graph_actions if slots > 1 else self._graph_actions[0]
 
     def step_graph(self, actions: Optional[torch.Tensor] = None):
         if self._graph_actions is None:
             raise RuntimeError("capture_graph() first")
         if actions is not None:
-            self._graph_actions.copy_(actions)
+            if self._graph_actions.shape[0] != 1:
+                raise ValueError("with an action ring write the slots directly")
+            self._graph_actions[0].copy_(actions)
         _check(_LIB.auv_graph_launch(self._h, self._stream()), "auv_graph_launch")
         return self.obs, self.reward, self.done, self._lazy_info()
 

@@ -17,7 +17,10 @@ void auv_launch_k2(const AuvDev& d, int advance_movers, hipStream_t st);
 void auv_launch_k2_fresh(const AuvDev& d, hipStream_t st);
 void auv_launch_k3(const AuvDev& d, int mode, float* obs, float* reward, uint8_t* done, hipStream_t st);
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st);
-void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, hipStream_t st);
+void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st);
+void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st);
+void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, float* obs, hipStream_t st);
+void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
 hipError_t auv_k2_prepare(const AuvDev& d);
 
@@ -44,6 +47,8 @@ struct auv_handle {
   bool worlds_loaded;
   std::vector<void*> env_allocs, bank_allocs;
   hipStream_t cap_stream;
+  hipStream_t aux_stream;        // second branch of the step: K3-nav runs beside K2
+  hipEvent_t ev_fork, ev_join;
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
   hipEvent_t ev[6];
@@ -97,7 +102,15 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->graph = nullptr;
   h->graph_exec = nullptr;
   h->cap_stream = nullptr;
+  h->aux_stream = nullptr;
+  h->ev_fork = h->ev_join = nullptr;
   for (auto& e : h->ev) e = nullptr;
+  if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete h;
+    return fail(AUV_EHIP, "auv_create: cannot create the auxiliary stream / events");
+  }
   *out = h;
   return AUV_OK;
 }
@@ -109,6 +122,9 @@ int auv_destroy(auv_handle_t* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   free_pool(h->env_allocs);
@@ -224,10 +240,18 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
   rc |= dev_alloc(ep, &d.stamps, n * 16);
+  rc |= dev_alloc(ep, &d.ring_pos, 4);
+  d.ring_slots = 1;
+  rc |= dev_alloc(ep, &d.w_obs64, (size_t)W * (6 + S));
+  rc |= dev_alloc(ep, &d.w_lidar, (size_t)W * S);
+  rc |= dev_alloc(ep, &d.w_info, (size_t)W * 8);
+  rc |= dev_alloc(ep, &d.w_nav, (size_t)W * 8);
+  rc |= dev_alloc(ep, &d.w_nearby, (size_t)W * k_max);
+  rc |= dev_alloc(ep, &d.w_limits, (size_t)W * k_max);
+  rc |= dev_alloc(ep, &d.w_collision, (size_t)W);
+  d.w_ready = 0;
   if (rc) return AUV_EHIP;
   std::vector<int32_t> wi(n);
-  for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(e % (size_t)W);
-  HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
   if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
   HIP_TRY(auv_k2_prepare(d));
   if ((size_t)AUV_ENVS_PER_BLOCK * d.nch_max * 4 > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
@@ -235,6 +259,27 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
     (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;
   }
+  // ---- reset rows: the first observation of every world (navigate + perceive at its initial
+  // pose) is a constant of the world; compute it once, N worlds at a time, with the step's own
+  // kernels (reset state -> K2 -> K3 on the fresh list), and keep the rows per world.
+  for (int w0 = 0; w0 < W; w0 += d.n) {
+    const int count = (W - w0 < d.n) ? (W - w0) : d.n;
+    for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(w0 + (int)(e % (size_t)count));
+    HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d.fresh_count, 0, sizeof(int32_t)));
+    auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);   // w_ready == 0: everything goes on the fresh list
+    auv_launch_k2_fresh(d, nullptr);
+    auv_launch_k3_fresh(d, nullptr, nullptr);
+    auv_launch_harvest(d, count, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  d.w_ready = 1;
+  // initial binding e -> world e % W, reset-time state (the first reset() call is then a copy)
+  for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(e % (size_t)W);
+  HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d.counters, 0, n * sizeof(int4)));
+  auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);
+  HIP_TRY(hipDeviceSynchronize());
   h->worlds_loaded = true;
   return AUV_OK;
 }
@@ -248,23 +293,25 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
 int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx_dev, float* obs_dev, void* stream) {
   REQUIRE_READY(h);
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(h->d.fresh_count, 0, sizeof(int32_t), st));
-  auv_launch_reset(h->d, mask_dev, world_idx_dev, st);
-  auv_launch_k2_fresh(h->d, st);
-  auv_launch_k3_fresh(h->d, obs_dev, st);
+  auv_launch_reset(h->d, mask_dev, world_idx_dev, obs_dev, st);
   HIP_TRY(hipGetLastError());
   return AUV_OK;
 }
 
-static void enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, float* obs, float* reward, uint8_t* done,
-                         hipStream_t st) {
+// One step: K1, then K2 (LiDAR) on the caller's stream with K3-nav forked onto the auxiliary
+// stream (they are independent given the new state), joined before K3-reward.  Works the same
+// eagerly and under stream capture (the fork/join events become graph edges).
+static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, float* obs, float* reward, uint8_t* done,
+                        hipStream_t st) {
   auv_launch_k1(h->d, actions, dtype, st);   // also empties the fresh list
+  HIP_TRY(hipEventRecord(h->ev_fork, st));
+  HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+  auv_launch_k3_nav(h->d, obs, h->aux_stream);
+  HIP_TRY(hipEventRecord(h->ev_join, h->aux_stream));
   auv_launch_k2(h->d, 1, st);
-  auv_launch_k3(h->d, 0, obs, reward, done, st);
-  if (h->d.cfg.auto_reset) {
-    auv_launch_k2_fresh(h->d, st);
-    auv_launch_k3_fresh(h->d, obs, st);
-  }
+  HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+  auv_launch_k3_reward(h->d, obs, reward, done, st);   // a done env with auto-reset copies its next world's reset rows
+  return AUV_OK;
 }
 
 int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
@@ -272,8 +319,22 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
   REQUIRE_READY(h);
   if (!actions_dev) return fail(AUV_EINVAL, "auv_step: null actions");
   if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_step: bad action dtype");
-  enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
+  int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
+  REQUIRE_READY(h);
+  if (n_slots < 1) return fail(AUV_EINVAL, "auv_set_action_ring: n_slots must be >= 1");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(h->d.ring_pos, 0, sizeof(int32_t)));
+  h->d.ring_slots = n_slots;
+  if (h->graph_exec) {   // a captured graph has the old value baked into its kernel arguments
+    HIP_TRY(hipGraphExecDestroy(h->graph_exec));
+    h->graph_exec = nullptr;
+  }
   return AUV_OK;
 }
 
@@ -296,13 +357,7 @@ int auv_lidar(auv_handle_t* h, int32_t advance_movers, void* stream) {
 int auv_nav_reward(auv_handle_t* h, int32_t mode, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream) {
   REQUIRE_READY(h);
   if (mode < 0 || mode > 2) return fail(AUV_EINVAL, "auv_nav_reward: mode must be 0, 1 or 2");
-  const bool resets = (mode != 1) && h->d.cfg.auto_reset;
-  if (resets) HIP_TRY(hipMemsetAsync(h->d.fresh_count, 0, sizeof(int32_t), (hipStream_t)stream));
   auv_launch_k3(h->d, mode, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
-  if (resets) {
-    auv_launch_k2_fresh(h->d, (hipStream_t)stream);
-    auv_launch_k3_fresh(h->d, obs_dev, (hipStream_t)stream);
-  }
   HIP_TRY(hipGetLastError());
   return AUV_OK;
 }
@@ -370,8 +425,10 @@ int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_d
     h->graph = nullptr;
   }
   HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-  enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream);
-  HIP_TRY(hipStreamEndCapture(h->cap_stream, &h->graph));
+  int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream);
+  hipError_t ce = hipStreamEndCapture(h->cap_stream, &h->graph);
+  if (rc) return rc;
+  HIP_TRY(ce);
   HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
   return AUV_OK;
 }
@@ -397,11 +454,7 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   HIP_TRY(hipEventRecord(h->ev[2], st));
   auv_launch_k3(h->d, 0, obs_dev, reward_dev, done_dev, st);
   HIP_TRY(hipEventRecord(h->ev[3], st));
-  if (h->d.cfg.auto_reset) {
-    auv_launch_k2_fresh(h->d, st);
-    auv_launch_k3_fresh(h->d, obs_dev, st);
-  }
-  HIP_TRY(hipEventRecord(h->ev[4], st));
+  HIP_TRY(hipEventRecord(h->ev[4], st));   // (no separate reset pass any more: resets copy per-world rows)
   HIP_TRY(hipEventSynchronize(h->ev[4]));
   for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[i], h->ev[i + 1]));
   return AUV_OK;

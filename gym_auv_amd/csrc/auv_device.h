@@ -57,8 +57,20 @@ struct AuvDev {
   double* episode;     // [N][4]
   int2* limits;        // [N][Kmax]
   uint8_t* collision;  // [N]
-  int32_t* fresh_count; // [1]  number of envs reset in this call (reset() / auto-reset)
-  int32_t* fresh_list;  // [N]  their indices; consumed by the reset-pass kernels
+  int32_t* fresh_count; // [1]  } work list of the load-time pass that computes the reset rows
+  int32_t* fresh_list;  // [N]  }
+  // ---- per-world reset rows (derived once at load time by running the reset observation of
+  //      every world through K2/K3): what reset() / auto-reset copy instead of recomputing ----
+  double* w_obs64;     // [W][6+S]
+  double* w_lidar;     // [W][S]
+  double* w_info;      // [W][8]
+  double* w_nav;       // [W][8]
+  uint8_t* w_nearby;   // [W][Kmax]
+  int2* w_limits;      // [W][Kmax]
+  uint8_t* w_collision;// [W]
+  int32_t w_ready;     // 0 while the rows are being computed
+  int32_t* ring_pos;    // [1]  current slot of the action ring (advanced once per step by K3)
+  int32_t ring_slots;   // 1 = plain action buffer
   unsigned long long* stamps;  // [N][16] per-env phase cycle counts (diagnostic builds, -DAUV_STAMPS)
 };
 

@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(AUV_WAVE) k1_dynamics(AuvDev d, const AT* __re
   if (e >= d.n) return;
   if (e == 0) *d.fresh_count = 0;   // the auto-reset list of this step starts empty (consumed after K3)
   const size_t n = (size_t)d.n;
+  if (d.ring_slots > 1) actions += (size_t)(*d.ring_pos) * 2 * n;   // action ring: slot of this step
   double a0 = (double)actions[2 * (size_t)e], a1 = (double)actions[2 * (size_t)e + 1];
   if (isnan(a0) || isnan(a1)) a0 = a1 = 0.0;
   const double tu = auv_clip(a0, 0.0, 1.0) * d.cfg.thrust_max;

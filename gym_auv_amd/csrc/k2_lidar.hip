@@ -8,9 +8,7 @@
 //            _find_limit_angle_rays                sensor.py:41-71
 //            simulate_sensor                       sensor.py:140-159
 //
-// Work decomposition (front and back parts per wave; the pair sweep of the four environments of
-// a workgroup is shared by all 256 threads, so a heavy environment -- the vessel inside several
-// cull circles, i.e. windows of all S rays -- is spread over four waves):
+// Work decomposition inside the wave:
 //   phase A  lanes <-> movers: advance kinematics, rebuild the 5 pentagon segments + cull
 //            circle in the wave's LDS slice.
 //   phase C  lanes <-> rays (S/64 passes): ray vectors (one sincos per ray) into LDS.
@@ -18,27 +16,30 @@
 //            [i_min-1, i_max % S) with the reference's Python-range / negative-index
 //            semantics; obstacles with a non-empty window are compacted (ballot + popcount).
 //   phase S  the boundary segments of the surviving obstacles are staged into LDS in ONE
-//            flattened, coalesced pass (vessel-relative: a - p0, b - a, and the ray-independent
-//            cross product), with the point-in-polygon predicates of filled obstacles evaluated
-//            on the fly (LDS xor/or per obstacle).
-//   phase D  obstacle by obstacle, the 64 lanes enumerate the (ray-in-window x staged
-//            segment) pairs, so lanes stay busy however narrow the window is; a hit does an
-//            LDS atomic-min on the ray's range (non-negative fp64 ordered as uint64).
-//   phase E  lanes <-> rays: write d, closeness (fused), wave-OR the collision flag (ballot).
-// Only pairs inside the reference's cull windows are evaluated (~5-15 % of S x G).
+//            flattened, coalesced pass (vessel-relative: a - p0, b - a), together with the
+//            point-in-polygon predicates of filled obstacles (LDS xor/or per obstacle) and the
+//            conservative range of ray indices each segment can possibly be hit by (its angular
+//            span seen from p0, fp32 atan2, widened by a ray on both sides).
+//   phase D  lanes <-> staged segments: each lane walks the rays of its segment's span that
+//            also lie in the obstacle's window (the reference's culling decides visibility; the
+//            span only skips pairs that cannot intersect), exact fp64 ray/segment test, a hit
+//            does an LDS atomic-min on the ray's t (non-negative fp64 ordered as uint64).
+//   phase E  lanes <-> rays: distance from the min t, closeness (fused), ballot -> collision.
+// Work per environment is ~2 x (rays subtended by the nearby boundaries), a few hundred pair
+// tests instead of S x G = 99 k, and no longer depends on how wide the reference's windows are.
 // Roofline: HBM.  Algorithmic bytes per env-step (fp64 layout): 32*G (segments, G per env)
 // + 24*K (cull circles) + 16*K (meta) + 24 (pose) + 16*S (d + closeness out) + K (nearby).
 #include "auv_device.h"
 
 namespace {
 
-struct ObsLds {        // per-obstacle scratch in LDS
+struct ObsLds {        // per-obstacle scratch in LDS (24 B)
   int kind;
   int seg_off;         // absolute index into seg[] (static) or mover slot*5 (mover)
   int nseg;
   int start;           // first ray index of the window (may be negative, > -2S)
   int count;           // number of rays in the window (0 = culled / not nearby)
-  int stage_off;       // offset of its staged segments in the wave's LDS stage, or -1 (sweep from HBM)
+  int pad;
 };
 
 struct EnvHdr {        // head of each wave's LDS slice: what the pair sweep needs to know
@@ -92,16 +93,19 @@ __device__ __forceinline__ double point_boundary_distance(double px, double py, 
   return best;
 }
 
-#define K2_SEG_CAP 128   // staged segments per wave (4 KiB + 1 KiB of LDS)
+#define K2_SEG_CAP 96    // staged segments per wave and batch (slice <= 10 KiB -> 16 waves per CU)
+#define K2_ITEM_RAYS 8    // rays per work item of the pair sweep
 
 // per-wave LDS slice (decreasing alignment):
 //   EnvHdr | [Mmax*5] double4 mover segs | [Mmax] double4 mover cull | [CAP] double4 staged
-//   (wx,wy,sx,sy) | [S] double2 ray vectors | [CAP] double staged tn | [S] u64 d-bits |
-//   [Kmax] ObsLds | [Kmax] int active list | [Kmax+1] int segment prefix | [Kmax] int inside flags
+//   (wx,wy,sx,sy) | [S] double2 ray vectors | [S] u64 min-t bits | [Kmax] ObsLds |
+//   [CAP] short2 ray span | [Kmax] int active list | [Kmax+1] int segment prefix |
+//   [Kmax] int inside flags | [CAP] u16 owner | [CAP+1] u16 work-item prefix
 __host__ __device__ __forceinline__ size_t k2_slice_bytes(int S, int k_max, int m_max) {
   size_t b = sizeof(EnvHdr) + (size_t)m_max * AUV_MOVER_NSEG * 32 + (size_t)m_max * 32 + (size_t)K2_SEG_CAP * 32 +
-             (size_t)S * 16 + (size_t)K2_SEG_CAP * 8 + (size_t)S * 8 + (size_t)k_max * sizeof(ObsLds) +
-             (size_t)k_max * 4 + (size_t)(k_max + 1) * 4 + (size_t)k_max * 4;
+             (size_t)S * 16 + (size_t)S * 8 + (size_t)k_max * sizeof(ObsLds) + (size_t)K2_SEG_CAP * 4 +
+             (size_t)k_max * 4 + (size_t)(k_max + 1) * 4 + (size_t)k_max * 4 + (size_t)K2_SEG_CAP * 2 +
+             (size_t)(K2_SEG_CAP + 2) * 2;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -111,12 +115,14 @@ struct Slice {
   double4* mvcull;
   double4* stage;
   double2* rayv;
-  double* stage_tn;
   unsigned long long* dbits;
   ObsLds* obs;
+  short2* span;
   int* act;
   int* sbase;
   int* par;
+  unsigned short* owner;
+  unsigned short* ioff;
 };
 
 __device__ __forceinline__ Slice carve(unsigned char* p, int S, int k_max, int m_max) {
@@ -126,48 +132,49 @@ __device__ __forceinline__ Slice carve(unsigned char* p, int S, int k_max, int m
   s.mvcull = s.mvseg + m_max * AUV_MOVER_NSEG;
   s.stage = s.mvcull + m_max;
   s.rayv = (double2*)(s.stage + K2_SEG_CAP);
-  s.stage_tn = (double*)(s.rayv + S);
-  s.dbits = (unsigned long long*)(s.stage_tn + K2_SEG_CAP);
+  s.dbits = (unsigned long long*)(s.rayv + S);
   s.obs = (ObsLds*)(s.dbits + S);
-  s.act = (int*)(s.obs + k_max);
+  s.span = (short2*)(s.obs + k_max);
+  s.act = (int*)(s.span + K2_SEG_CAP);
   s.sbase = s.act + k_max;
   s.par = s.sbase + k_max + 1;
+  s.owner = (unsigned short*)(s.par + k_max);
+  s.ioff = s.owner + K2_SEG_CAP;
   return s;
 }
 
-// pairs of one obstacle against its ray window, enumerated by `nthr` threads (`tid` of them);
-// seg_at(si) yields (wx, wy, sx, sy) and the ray-independent numerator tn = wx*sy - wy*sx of t
-// (sensor.py:140-159)
-template <typename SegFn>
-__device__ __forceinline__ void sweep_pairs(const ObsLds& o, int tid, int nthr, int S,
-                                            const double2* rayv, unsigned long long* dbits, SegFn seg_at) {
+// exact test of one (ray, boundary segment) pair, sensor.py:140-159; w = (wx, wy, sx, sy) with
+// w = a - p0, s = b - a.  A hit keeps min t on the ray: the reference's distance
+// |p0 + t r - p0| is (weakly) monotone in t for a fixed ray, also in floating point, so the min
+// over hits of the distance == the distance at the min t (formed once per ray in phase E).
+__device__ __forceinline__ void test_pair(const double4 w, const double tn, const double2 r,
+                                          unsigned long long* slot) {
+  const double den = r.x * w.w - r.y * w.z;
+  const double un = w.x * r.y - w.y * r.x;              // u = un/den along the boundary segment
+  // 0 <= tn/den <= 1 and 0 <= un/den <= 1 decided without dividing (exactly equivalent for
+  // correctly rounded IEEE division); den < 0 handled by flipping all three signs (exact)
+  const bool neg = den < 0.0;
+  const double dn = neg ? -den : den, t1 = neg ? -tn : tn, u1 = neg ? -un : un;
+  const bool hit = (dn != 0.0) & (t1 >= 0.0) & (t1 <= dn) & (u1 >= 0.0) & (u1 <= dn);
+  if (hit) atomicMin(slot, d2u(tn / den));
+}
+
+// (window x boundary) pairs of an obstacle that did not fit the LDS stage, straight from HBM
+template <typename SegPtr>
+__device__ __forceinline__ void sweep_unstaged(const ObsLds& o, int tid, int nthr, int S, double px, double py,
+                                               const double2* rayv, unsigned long long* dbits, SegPtr g) {
   const int total = o.count * o.nseg;
-  const float inv = 1.0f / (float)o.nseg;
-  const bool small = total < 32768;                       // exactness bound of the float quotient
   for (int q = tid; q < total; q += nthr) {
-    const int ro = small ? (int)(((float)q + 0.5f) * inv) : q / o.nseg;
-    const int si = q - ro * o.nseg;
+    const int ro = q / o.nseg, si = q - ro * o.nseg;
     const int i = wrap_ray(o.start + ro, S);
-    double4 w;       // wx, wy, sx, sy
-    double tn;
-    seg_at(si, w, tn);
-    const double2 r = rayv[i];
-    double den = r.x * w.w - r.y * w.z;
-    double un = w.x * r.y - w.y * r.x;                    // u = un/den along the boundary segment
-    // 0 <= tn/den <= 1 and 0 <= un/den <= 1 decided without dividing (exactly equivalent for
-    // correctly rounded IEEE division); den < 0 handled by flipping all three signs (exact)
-    const bool neg = den < 0.0;
-    const double dn = neg ? -den : den, t1 = neg ? -tn : tn, u1 = neg ? -un : un;
-    const bool hit = (dn != 0.0) & (t1 >= 0.0) & (t1 <= dn) & (u1 >= 0.0) & (u1 <= dn);
-    // The reference's distance |p0 + t r - p0| is (weakly) monotone in t for a fixed ray, also in
-    // floating point, so min over hits of the distance == distance at the min t: keep min t
-    // (t in [0, 1], ordered as uint64) and form the distance once per ray in phase E.
-    if (hit) atomicMin(&dbits[i], d2u(tn / den));
+    const double4 s = g[si];
+    const double4 w = make_double4(s.x - px, s.y - py, s.z - s.x, s.w - s.y);
+    test_pair(w, w.x * w.w - w.y * w.z, rayv[i], &dbits[i]);
   }
 }
 
 // phases A, C, B, S for one environment, by one wave
-__device__ void k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers) {
+__device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const int4 cnt = d.counters[e];
@@ -231,7 +238,7 @@ __device__ void k2_front(const AuvDev& d, const int e, const int lane, const Sli
       L.mvseg[m * AUV_MOVER_NSEG + i] = make_double4(vx[i], vy[i], vx[j], vy[j]);
     }
   }
-  if (!d.cfg.use_lidar) return;   // lidar_d stays at sensor_range from reset; collision stays 0
+  if (!d.cfg.use_lidar) return 0;   // lidar_d stays at sensor_range from reset; collision stays 0
 
   // ---- phase C: ray vectors, vessel.py:66-68, :317 ------------------------------------
   for (int i = lane; i < S; i += AUV_WAVE) {
@@ -260,7 +267,7 @@ __device__ void k2_front(const AuvDev& d, const int e, const int lane, const Sli
       o.nseg = meta.z;
       o.start = 0;
       o.count = 0;
-      o.stage_off = -1;
+      o.pad = 0;
       uint8_t near;
       if (refresh) {
         // vessel.py:266-273: Point.distance(boundary) - width < range (filled: 0 inside)
@@ -350,9 +357,7 @@ __device__ void k2_front(const AuvDev& d, const int e, const int lane, const Sli
         if (lane >= o) v += t;
       }
       if (a < n_act) {
-        const int end = carry + v, nseg = L.obs[L.act[a]].nseg;
-        L.sbase[a + 1] = end;
-        L.obs[L.act[a]].stage_off = (end <= K2_SEG_CAP) ? end - nseg : -1;
+        L.sbase[a + 1] = carry + v;
         L.par[a] = 0;
       }
       carry += __shfl(v, AUV_WAVE - 1, AUV_WAVE);
@@ -360,78 +365,159 @@ __device__ void k2_front(const AuvDev& d, const int e, const int lane, const Sli
     if (lane == 0) L.sbase[0] = 0;
   }
   auv_wave_lds_sync();
+  return n_act;
+}
 
-  // ---- phase S: one flattened, coalesced pass over the boundary segments that fit the stage ----
-  int n_staged = 0;                                    // obstacles staged (a prefix of the list)
-  while (n_staged < n_act && L.sbase[n_staged + 1] <= K2_SEG_CAP) n_staged++;
-  const int T = L.sbase[n_staged];
-  for (int t = lane; t < T; t += AUV_WAVE) {
-    int a = 0;
-    while (t >= L.sbase[a + 1]) a++;
-    const ObsLds o = L.obs[L.act[a]];
-    const int si = t - L.sbase[a];
-    const double4 s = (o.kind == AUV_OBS_MOVER) ? L.mvseg[o.seg_off + si] : d.seg[o.seg_off + si];
-    const double wx = s.x - px, wy = s.y - py, sx = s.z - s.x, sy = s.w - s.y;
-    L.stage[t] = make_double4(wx, wy, sx, sy);
-    L.stage_tn[t] = wx * sy - wy * sx;
-    if (o.kind != AUV_OBS_RING) {
-      // point-in-polygon predicates of this boundary segment (same tests as point_in_polygon)
-      const double dxa = px - s.x, dya = py - s.y;
-      const double len2 = sx * sx + sy * sy;
-      const double dot = dxa * sx + dya * sy;
-      bool on;
+// inside flag of one filled obstacle straight from its boundary in HBM/LDS, lanes <-> segments
+// (ballot: any on-boundary, parity of crossings): same predicates as point_in_polygon
+template <typename SegPtr>
+__device__ __forceinline__ int inside_flag_wave(double px, double py, SegPtr g, int nseg, int lane) {
+  int on_any = 0, cross = 0;
+  for (int sb = 0; sb < nseg; sb += AUV_WAVE) {
+    const int si = sb + lane;
+    bool on = false, cr = false;
+    if (si < nseg) {
+      const double4 s = g[si];
+      const double sx = s.z - s.x, sy = s.w - s.y, dxa = px - s.x, dya = py - s.y;
+      const double len2 = sx * sx + sy * sy, dot = dxa * sx + dya * sy;
       if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
       else if (dot >= len2) on = (px == s.z && py == s.w);
       else on = ((s.y - py) * sx - (s.x - px) * sy) == 0.0;
-      if (on) atomicOr(&L.par[a], 2);
-      if ((s.y > py) != (s.w > py)) {
-        const double xint = s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
-        if (px < xint) atomicXor(&L.par[a], 1);
-      }
+      if ((s.y > py) != (s.w > py)) cr = px < s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
     }
+    on_any |= __any(on);
+    cross += __popcll(__ballot(cr));
   }
-  // boundaries that did not fit are swept straight from HBM; their inside flag is computed here
-  for (int a = n_staged; a < n_act; a++) {
-    const ObsLds o = L.obs[L.act[a]];
-    if (o.kind != AUV_OBS_RING && lane == 0)
-      L.par[a] = ((o.kind == AUV_OBS_MOVER) ? point_in_polygon(px, py, L.mvseg + o.seg_off, o.nseg)
-                                            : point_in_polygon(px, py, d.seg + o.seg_off, o.nseg)) ? 1 : 0;
-  }
-  auv_wave_lds_sync();
+  return (on_any ? 2 : 0) | (cross & 1);
 }
 
-// phase D for the environment whose slice is L, enumerated by `nthr` threads
-__device__ void k2_pairs(const AuvDev& d, const Slice& L, const int tid, const int nthr) {
+// phases S + D for one environment, by one wave, in batches of <= K2_SEG_CAP boundary segments
+__device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int lane, const int n_act,
+                                   const double psi) {
   const int S = d.cfg.n_sensors;
-  const int n_act = L.hdr->n_act;
   const double px = L.hdr->px, py = L.hdr->py;
-  for (int a = 0; a < n_act; a++) {
-    const ObsLds o = L.obs[L.act[a]];
-    if (o.kind != AUV_OBS_RING && L.par[a] != 0) {
-      // p0 inside (or on) a filled polygon: the clipped ray starts at p0 -> distance 0 on every ray
-      for (int q = tid; q < o.count; q += nthr) atomicMin(&L.dbits[wrap_ray(o.start + q, S)], 0ull);
-    } else if (o.stage_off >= 0) {
-      const double4* sg = L.stage + o.stage_off;
-      const double* st = L.stage_tn + o.stage_off;
-      sweep_pairs(o, tid, nthr, S, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
-        wv = sg[si];
-        tn = st[si];
-      });
-    } else if (o.kind == AUV_OBS_MOVER) {
-      const double4* g = L.mvseg + o.seg_off;
-      sweep_pairs(o, tid, nthr, S, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
-        const double4 s = g[si];
-        wv = make_double4(s.x - px, s.y - py, s.z - s.x, s.w - s.y);
-        tn = wv.x * wv.w - wv.y * wv.z;
-      });
-    } else {
+  for (int a0 = 0; a0 < n_act;) {
+    const int base0 = L.sbase[a0];
+    if (L.sbase[a0 + 1] - base0 > K2_SEG_CAP) {
+      // a single boundary larger than the stage (never a circle or a mover): sweep it from HBM
+      const ObsLds o = L.obs[L.act[a0]];
       const double4* g = d.seg + o.seg_off;
-      sweep_pairs(o, tid, nthr, S, L.rayv, L.dbits, [&](int si, double4& wv, double& tn) {
-        const double4 s = g[si];
-        wv = make_double4(s.x - px, s.y - py, s.z - s.x, s.w - s.y);
-        tn = wv.x * wv.w - wv.y * wv.z;
-      });
+      if (o.kind != AUV_OBS_RING && inside_flag_wave(px, py, g, o.nseg, lane) != 0) {
+        for (int q = lane; q < o.count; q += AUV_WAVE) atomicMin(&L.dbits[wrap_ray(o.start + q, S)], 0ull);
+      } else {
+        sweep_unstaged(o, lane, AUV_WAVE, S, px, py, L.rayv, L.dbits, g);
+      }
+      a0 += 1;
+      continue;
     }
+    int a1 = a0 + 1;
+    while (a1 < n_act && L.sbase[a1 + 1] - base0 <= K2_SEG_CAP) a1++;
+    const int T = L.sbase[a1] - base0;
+
+    // ---- phase S: one flattened, coalesced pass over the batch's boundary segments ----
+    for (int t = lane; t < T; t += AUV_WAVE) {
+      int a = a0;
+      while (t + base0 >= L.sbase[a + 1]) a++;
+      const ObsLds o = L.obs[L.act[a]];
+      const int si = t + base0 - L.sbase[a];
+      const double4 s = (o.kind == AUV_OBS_MOVER) ? L.mvseg[o.seg_off + si] : d.seg[o.seg_off + si];
+      const double wx = s.x - px, wy = s.y - py, sx = s.z - s.x, sy = s.w - s.y;
+      L.stage[t] = make_double4(wx, wy, sx, sy);
+      L.owner[t] = (unsigned short)a;
+      {
+        // conservative range of ray indices this segment can be hit by: the rays between the
+        // bearings of its end points (shorter arc; a segment subtends < pi from any point off
+        // its line), fp32 trigonometry, rays of slack on both sides (fp32 error ~1e-5 rays)
+        const float ax = (float)wx, ay = (float)wy, bx = (float)(s.z - px), by = (float)(s.w - py);
+        short2 sp;
+        if ((fabsf(ax) + fabsf(ay) < 1e-6f) || (fabsf(bx) + fabsf(by) < 1e-6f)) {
+          sp = make_short2(0, (short)S);                         // p0 (almost) on an end point: all rays
+        } else {
+          const float PI_F = 3.14159265358979f;
+          const float ta = atan2f(ay, ax), tb = atan2f(by, bx);
+          float dl = tb - ta;
+          if (dl > PI_F) dl -= 2.0f * PI_F;
+          if (dl <= -PI_F) dl += 2.0f * PI_F;
+          const float ts = dl >= 0.0f ? ta : tb;
+          const float inv_da = (float)S / (2.0f * PI_F);
+          const float f = (ts - (float)psi + PI_F) * inv_da - 1.0f;   // fractional ray index of the arc start
+          const int n = (int)ceilf(fabsf(dl) * inv_da) + 4;
+          const int klo = ((int)floorf(f) - 1) % S;               // any representative; wrapped per ray
+          sp = make_short2((short)klo, (short)(n > S ? S : n));
+        }
+        L.span[t] = sp;
+      }
+      if (o.kind != AUV_OBS_RING) {
+        // point-in-polygon predicates of this boundary segment (same tests as point_in_polygon)
+        const double dxa = px - s.x, dya = py - s.y;
+        const double len2 = sx * sx + sy * sy;
+        const double dot = dxa * sx + dya * sy;
+        bool on;
+        if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
+        else if (dot >= len2) on = (px == s.z && py == s.w);
+        else on = ((s.y - py) * sx - (s.x - px) * sy) == 0.0;
+        if (on) atomicOr(&L.par[a], 2);
+        if ((s.y > py) != (s.w > py)) {
+          const double xint = s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
+          if (px < xint) atomicXor(&L.par[a], 1);
+        }
+      }
+    }
+    auv_wave_lds_sync();
+
+    // ---- phase D (i): obstacles containing p0 -> distance 0 on every ray of their window ----
+    for (int a = a0; a < a1; a++) {
+      const ObsLds o = L.obs[L.act[a]];
+      if (o.kind != AUV_OBS_RING && L.par[a] != 0)
+        for (int q = lane; q < o.count; q += AUV_WAVE) atomicMin(&L.dbits[wrap_ray(o.start + q, S)], 0ull);
+    }
+    // ---- phase D (ii): work items = (staged segment, run of <= K2_ITEM_RAYS rays of its span),
+    //      lanes <-> items, so a segment seen under a wide angle is shared by several lanes ----
+    int n_items = 0;
+    for (int tb = 0; tb < T; tb += AUV_WAVE) {           // wave prefix sum of items per segment
+      const int t = tb + lane;
+      int v = 0;
+      if (t < T) {
+        const int a = L.owner[t];
+        const ObsLds o = L.obs[L.act[a]];
+        if (!(o.kind != AUV_OBS_RING && L.par[a] != 0)) v = (L.span[t].y + K2_ITEM_RAYS - 1) / K2_ITEM_RAYS;
+      }
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < AUV_WAVE; o <<= 1) {
+        int x = __shfl_up(incl, o, AUV_WAVE);
+        if (lane >= o) incl += x;
+      }
+      if (t < T) L.ioff[t + 1] = (unsigned short)(n_items + incl);
+      n_items += __shfl(incl, AUV_WAVE - 1, AUV_WAVE);
+    }
+    if (lane == 0) L.ioff[0] = 0;
+    auv_wave_lds_sync();
+    for (int it = lane; it < n_items; it += AUV_WAVE) {
+      int lo = 0, hi = T;                                  // largest t with ioff[t] <= it
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)L.ioff[mid] <= it) lo = mid; else hi = mid;
+      }
+      const int t = lo;
+      const int a = L.owner[t];
+      const ObsLds o = L.obs[L.act[a]];
+      const double4 w = L.stage[t];
+      const double tn = w.x * w.w - w.y * w.z;               // ray-independent numerator of t
+      const short2 sp = L.span[t];
+      const bool all = o.count >= S;
+      const int start_w = wrap_ray(o.start, S);
+      const int j0 = (it - (int)L.ioff[t]) * K2_ITEM_RAYS;
+      const int j1 = (j0 + K2_ITEM_RAYS < sp.y) ? j0 + K2_ITEM_RAYS : sp.y;
+      for (int j = j0; j < j1; j++) {
+        const int r = wrap_ray(sp.x + j, S);
+        int x = r - start_w;                                  // position of ray r inside the window
+        if (x < 0) x += S;
+        if (all || x < o.count) test_pair(w, tn, L.rayv[r], &L.dbits[r]);
+      }
+    }
+    auv_wave_lds_sync();
+    a0 = a1;
   }
 }
 
@@ -462,35 +548,33 @@ __device__ void k2_back(const AuvDev& d, const int e, const int lane, const Slic
   if (lane == 0) d.collision[e] = (uint8_t)(col != 0);
 }
 
-// all environments: wave g prepares env g; the pair sweep of the workgroup's four environments
-// is shared by its 256 threads
-__global__ void __launch_bounds__(AUV_BLOCK) k2_lidar(AuvDev d, int advance_movers) {
+// all environments: wave g handles env g
+__global__ void __launch_bounds__(AUV_BLOCK, 4) k2_lidar(AuvDev d, int advance_movers) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int S = d.cfg.n_sensors;
-  const size_t sb = k2_slice_bytes(S, d.k_max, d.m_max);
   const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
-  const bool valid = e < d.n;
-  const Slice L = carve(smem + wave * sb, S, d.k_max, d.m_max);
+  if (e >= d.n) return;
+  const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
   AUV_STAMP_DECL
-  if (valid) k2_front(d, e, lane, L, advance_movers);
-  else if (lane == 0) L.hdr->n_act = 0;
-  if (!d.cfg.use_lidar) return;            // uniform over the grid
+#ifdef AUV_STAMPS
+  const unsigned long long t_real0 = wall_clock64();
+#endif
+  const int n_act = k2_front(d, e, lane, L, advance_movers);
+  if (!d.cfg.use_lidar) return;
   AUV_STAMP()
-  __syncthreads();
+  k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
   AUV_STAMP()
-#pragma unroll 1
-  for (int j = 0; j < AUV_ENVS_PER_BLOCK; j++) k2_pairs(d, carve(smem + j * sb, S, d.k_max, d.m_max), threadIdx.x, AUV_BLOCK);
+  k2_back(d, e, lane, L);
   AUV_STAMP()
-  __syncthreads();
-  AUV_STAMP()
-  if (valid) k2_back(d, e, lane, L);
-  AUV_STAMP()
-  if (valid) { AUV_STAMP_FLUSH(e, 0) }   // 0:front 1:barrier 2:pairs 3:barrier 4:back
+  AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
+#ifdef AUV_STAMPS
+  if (lane == 0) d.stamps[(size_t)e * 16 + 3] = t_real0, d.stamps[(size_t)e * 16 + 4] = wall_clock64();
+  if (lane == 0) d.stamps[(size_t)e * 16 + 5] = (unsigned long long)L.sbase[n_act], d.stamps[(size_t)e * 16 + 6] = (unsigned long long)n_act;
+#endif
 }
 
-// reset pass: only the environments on the fresh list (reset() / auto-reset), movers not
-// advanced; wave-synchronous (trip counts differ per wave, so no workgroup barriers here)
+// reset pass: only the environments on the fresh list (reset() / auto-reset), movers not advanced
 __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
@@ -499,10 +583,9 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
   const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
   for (int i = blockIdx.x * AUV_ENVS_PER_BLOCK + wave; i < nf; i += gridDim.x * AUV_ENVS_PER_BLOCK) {
     const int e = d.fresh_list[i];
-    k2_front(d, e, lane, L, 0);
+    const int n_act = k2_front(d, e, lane, L, 0);
     if (d.cfg.use_lidar) {
-      k2_pairs(d, L, lane, AUV_WAVE);
-      auv_wave_lds_sync();
+      k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
       k2_back(d, e, lane, L);
     }
     auv_wave_lds_sync();

@@ -76,38 +76,58 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, int w, double s, doub
   }
 }
 
-// restore reset-time state of env e bound to world w2 (environment.py:203-213, vessel.py:189-224)
-__device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int lane, int episodes) {
+// restore reset-time state of env e bound to world w2 (environment.py:203-245, vessel.py:189-224).
+// The reset observation (navigate + perceive at the initial pose) is a per-world constant that
+// was computed once at load time; here it is copied.  While those rows are being computed
+// (w_ready == 0) the env is put on the fresh list instead.
+__device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int lane, int episodes,
+                                            float* __restrict__ obs_out) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const double* ws2 = d.world_scalar + 8 * (size_t)w2;
+  const int D = 6 + (d.cfg.use_lidar ? S : 0);
   if (lane == 0) {
     d.world_idx[e] = w2;
     d.state[0 * n + e] = ws2[3], d.state[1 * n + e] = ws2[4], d.state[2 * n + e] = ws2[5];
     d.state[3 * n + e] = 0.0, d.state[4 * n + e] = 0.0, d.state[5 * n + e] = 0.0;
-    double* inf = d.info64 + 8 * (size_t)e;
-#pragma unroll
-    for (int i = 0; i < 8; i++) inf[i] = 0.0;
-    d.collision[e] = 0;
     d.counters[e] = make_int4(0, 0, episodes, 0);
-    d.fresh_list[atomicAdd(d.fresh_count, 1)] = e;
+    if (!d.w_ready) {
+      double* inf = d.info64 + 8 * (size_t)e;
+#pragma unroll
+      for (int i = 0; i < 8; i++) inf[i] = 0.0;
+      d.collision[e] = 0;
+      d.fresh_list[atomicAdd(d.fresh_count, 1)] = e;
+    } else {
+      d.collision[e] = d.w_collision[w2];
+    }
   }
-  for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
   const long long m0 = d.mv_off[w2];
   const int M = (int)(d.mv_off[w2 + 1] - m0);
   for (int m = lane; m < M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = d.mv_init[m0 + m];
-  for (int k = lane; k < d.k_max; k += AUV_WAVE) d.nearby[(size_t)e * d.k_max + k] = 0;
+  if (!d.w_ready) {
+    for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
+    for (int k = lane; k < d.k_max; k += AUV_WAVE) d.nearby[(size_t)e * d.k_max + k] = 0;
+    return;
+  }
+  for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.w_lidar[(size_t)w2 * S + i];
+  for (int i = lane; i < 6 + S; i += AUV_WAVE) {
+    const double v = d.w_obs64[(size_t)w2 * (6 + S) + i];
+    d.obs64[(size_t)e * (6 + S) + i] = v;
+    if (obs_out && i < D) obs_out[(size_t)e * D + i] = (float)v;
+  }
+  if (lane < 8) d.info64[8 * (size_t)e + lane] = d.w_info[8 * (size_t)w2 + lane];
+  else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = d.w_nav[8 * (size_t)w2 + lane - 8];
+  for (int k = lane; k < d.k_max; k += AUV_WAVE) {
+    d.nearby[(size_t)e * d.k_max + k] = d.w_nearby[(size_t)w2 * d.k_max + k];
+    d.limits[(size_t)e * d.k_max + k] = d.w_limits[(size_t)w2 * d.k_max + k];
+  }
 }
 
-// mode 0: navigate + observe + reward + done (+ auto-reset bookkeeping)
-// mode 1: navigate + observe only (reset path)
-// mode 2: reward + done only, from the buffers as they stand (test hook)
-__device__ void k3_env(const AuvDev& d, const int e, const int lane, const int mode, int* list,
-                       float* __restrict__ obs_out, float* __restrict__ reward_out,
-                       uint8_t* __restrict__ done_out) {
+// ---- navigation part (Vessel.navigate + the six navigation observations) ----------------------
+// Independent of the LiDAR sweep, so the step path runs it concurrently with K2.
+__device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* list, float* __restrict__ obs_out) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
-  int4 cnt = d.counters[e];
   const int w = d.world_idx[e];
   const double* ws = d.world_scalar + 8 * (size_t)w;
   const double L = ws[0];
@@ -118,23 +138,53 @@ __device__ void k3_env(const AuvDev& d, const int e, const int lane, const int m
   const int D = 6 + (d.cfg.use_lidar ? S : 0);
 
   AUV_STAMP_DECL
-  if (mode != 2) {
-    // ---- nearest point on the dense polyline (path.py:84-93), exact with chunk pruning ----
-    const long long p0 = d.poly_off[w];
-    const int P = (int)(d.poly_off[w + 1] - p0);
-    const double2* xy = d.poly_xy + p0;
-    const long long c0 = d.chunk_off[w];
-    const int nch = (int)(d.chunk_off[w + 1] - c0);
-    const double4* cb = d.chunk_bound + c0;
-    double U = 1.7976931348623157e308;
+  // ---- nearest point on the dense polyline (path.py:84-93), exact with chunk pruning ----
+  const long long p0 = d.poly_off[w];
+  const int P = (int)(d.poly_off[w + 1] - p0);
+  const double2* xy = d.poly_xy + p0;
+  const long long c0 = d.chunk_off[w];
+  const int nch = (int)(d.chunk_off[w + 1] - c0);
+  const double4* cb = d.chunk_bound + c0;
+  // up to 4 chunks per lane stay in registers (paths up to 16 k vertices); their loads are
+  // issued together.  Longer paths take the generic two-pass route below.
+  constexpr int CPL = 4;
+  double cdist[CPL], crad[CPL];
+  double U = 1.7976931348623157e308;
+  const bool in_regs = nch <= CPL * AUV_WAVE;
+  if (in_regs) {
+    double4 b[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+      const int c = i * AUV_WAVE + lane;
+      b[i] = cb[c < nch ? c : nch - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+      const double dx = px - b[i].x, dy = py - b[i].y;
+      cdist[i] = sqrt(dx * dx + dy * dy);
+      crad[i] = b[i].z;
+      if (i * AUV_WAVE + lane < nch) U = fmin(U, cdist[i] + crad[i]);
+    }
+  } else {
     for (int c = lane; c < nch; c += AUV_WAVE) {
       double4 b = cb[c];
       double dx = px - b.x, dy = py - b.y;
       U = fmin(U, sqrt(dx * dx + dy * dy) + b.z);
     }
-    U = auv_wave_min(U);
-    AUV_STAMP()
-    int n_act = 0;
+  }
+  U = auv_wave_min(U);
+  AUV_STAMP()
+  int n_act = 0;
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+      const int c = i * AUV_WAVE + lane;
+      const bool act = (c < nch) && (cdist[i] - crad[i] <= U);
+      const unsigned long long mask = __ballot(act);
+      if (act) list[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = c;
+      n_act += __popcll(mask);
+    }
+  } else {
     for (int cbase = 0; cbase < nch; cbase += AUV_WAVE) {
       const int c = cbase + lane;
       bool act = false;
@@ -147,68 +197,82 @@ __device__ void k3_env(const AuvDev& d, const int e, const int lane, const int m
       if (act) list[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = c;
       n_act += __popcll(mask);
     }
-    auv_wave_lds_sync();
-    AUV_STAMP()
-    MinIdx best;
-    best.d = 1.7976931348623157e308;
-    best.j = 0x7fffffff;
-    for (int a = 0; a < n_act; a++) {
-      const int j = list[a] * AUV_CHUNK + lane;
-      if (j < P - 1) {
-        double2 A = xy[j], B = xy[j + 1];
-        double dd = auv_pt_seg_dist(px, py, A.x, A.y, B.x, B.y);
-        if (dd < best.d) best.d = dd, best.j = j;
-      }
-    }
-    best = wave_min_first(best);
-    AUV_STAMP()
-    const int bj = best.j;
-    // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure (all lanes, uniform)
-    double2 A = xy[bj], B = xy[bj + 1];
-    double dx = B.x - A.x, dy = B.y - A.y, len2 = dx * dx + dy * dy;
-    double seglen = sqrt(len2);
-    double pf = (len2 == 0.0) ? 0.0 : ((px - A.x) * dx + (py - A.y) * dy) / len2;
-    double cum = d.poly_cum[p0 + bj];
-    const double s = pf <= 0.0 ? cum : (pf <= 1.0 ? cum + pf * seglen : cum + seglen);
-    double s_t = s + d.cfg.look_ahead_distance;
-    if (L < s_t) s_t = L;
-    // vessel.py:471-515 -- lane 0 evaluates the spline at s, lane 1 at s_t (same instructions)
-    double p[2], dp[2];
-    path_eval(d, w, lane == 1 ? s_t : s, L, p, dp);
-    double dir = atan2(dp[1], dp[0]);                       // lane 0: chi; lane 1: look-ahead direction
-    double tgt = atan2(p[1] - py, p[0] - px);               // lane 1: target heading
-    const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(tgt, 1, AUV_WAVE);
-    if (lane == 0) {
-      const double chi = dir;
-      double ddx = p[0] - px, ddy = p[1] - py;
-      double sn, cs;
-      sincos(-chi, &sn, &cs);
-      double cte = sn * ddx + cs * ddy;
-      double la = auv_princip(la_dir - psi);
-      double he = auv_princip(tgt1 - psi);
-      double progress = s / L;
-      double maxp = inf[5];
-      if (progress > maxp) maxp = progress;
-      double gx = ws[1] - px, gy = ws[2] - py;
-      double goal = sqrt(gx * gx + gy * gy);
-      int reached = (goal <= d.cfg.min_goal_distance) || (progress >= d.cfg.min_path_progress);
-      double u = d.state[3 * n + e], v = d.state[4 * n + e], r = d.state[5 * n + e];
-      nv[0] = u, nv[1] = v, nv[2] = r, nv[3] = la, nv[4] = he, nv[5] = cte / 100, nv[6] = chi, nv[7] = s_t;
-      inf[0] = d.collision[e];
-      inf[1] = reached, inf[2] = goal, inf[3] = progress, inf[5] = maxp, inf[6] = s, inf[7] = 0.0;
-      // environment.py:276-280; lane 0 also emits the float32 copies of its own six values so
-      // that no lane re-reads, within this kernel, global memory another lane has just written
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        double c6 = auv_clip(nv[i], -1.0, 1.0);
-        ob[i] = c6;
-        if (obs_out) obs_out[(size_t)e * D + i] = (float)c6;   // (a reset pass overwrites the row)
-      }
+  }
+  auv_wave_lds_sync();
+  AUV_STAMP()
+  MinIdx best;
+  best.d = 1.7976931348623157e308;
+  best.j = 0x7fffffff;
+  for (int a = 0; a < n_act; a++) {
+    const int j = list[a] * AUV_CHUNK + lane;
+    if (j < P - 1) {
+      double2 A = xy[j], B = xy[j + 1];
+      double dd = auv_pt_seg_dist(px, py, A.x, A.y, B.x, B.y);
+      if (dd < best.d) best.d = dd, best.j = j;
     }
   }
-
+  best = wave_min_first(best);
   AUV_STAMP()
-  if (mode != 1) {
+  const int bj = best.j;
+  // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure (all lanes, uniform)
+  double2 A = xy[bj], B = xy[bj + 1];
+  double dx = B.x - A.x, dy = B.y - A.y, len2 = dx * dx + dy * dy;
+  double seglen = sqrt(len2);
+  double pf = (len2 == 0.0) ? 0.0 : ((px - A.x) * dx + (py - A.y) * dy) / len2;
+  double cum = d.poly_cum[p0 + bj];
+  const double s = pf <= 0.0 ? cum : (pf <= 1.0 ? cum + pf * seglen : cum + seglen);
+  double s_t = s + d.cfg.look_ahead_distance;
+  if (L < s_t) s_t = L;
+  // vessel.py:471-515 -- lane 0 evaluates the spline at s, lane 1 at s_t (same instructions)
+  double p[2], dp[2];
+  path_eval(d, w, lane == 1 ? s_t : s, L, p, dp);
+  double dir = atan2(dp[1], dp[0]);                       // lane 0: chi; lane 1: look-ahead direction
+  double tgt = atan2(p[1] - py, p[0] - px);               // lane 1: target heading
+  const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(tgt, 1, AUV_WAVE);
+  if (lane == 0) {
+    const double chi = dir;
+    double ddx = p[0] - px, ddy = p[1] - py;
+    double sn, cs;
+    sincos(-chi, &sn, &cs);
+    double cte = sn * ddx + cs * ddy;
+    double la = auv_princip(la_dir - psi);
+    double he = auv_princip(tgt1 - psi);
+    double progress = s / L;
+    double maxp = inf[5];
+    if (progress > maxp) maxp = progress;
+    double gx = ws[1] - px, gy = ws[2] - py;
+    double goal = sqrt(gx * gx + gy * gy);
+    int reached = (goal <= d.cfg.min_goal_distance) || (progress >= d.cfg.min_path_progress);
+    double u = d.state[3 * n + e], v = d.state[4 * n + e], r = d.state[5 * n + e];
+    nv[0] = u, nv[1] = v, nv[2] = r, nv[3] = la, nv[4] = he, nv[5] = cte / 100, nv[6] = chi, nv[7] = s_t;
+    inf[1] = reached, inf[2] = goal, inf[3] = progress, inf[5] = maxp, inf[6] = s, inf[7] = 0.0;
+    // environment.py:276-280; lane 0 also emits the float32 copies of its own six values
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double c6 = auv_clip(nv[i], -1.0, 1.0);
+      ob[i] = c6;
+      if (obs_out) obs_out[(size_t)e * D + i] = (float)c6;
+    }
+  }
+  AUV_STAMP()
+  AUV_STAMP_FLUSH(e, 8)   // 8:bounds 9:list 10:scan 11:nav
+}
+
+// ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----
+// full = false: only publish the collision flag and the float32 LiDAR observations (reset path)
+__device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, const bool full,
+                              float* __restrict__ obs_out, float* __restrict__ reward_out,
+                              uint8_t* __restrict__ done_out) {
+  const int S = d.cfg.n_sensors;
+  int4 cnt = d.counters[e];
+  const int w = d.world_idx[e];
+  double* inf = d.info64 + 8 * (size_t)e;
+  const double* nv = d.nav64 + 8 * (size_t)e;
+  const double* ob = d.obs64 + (size_t)e * (6 + S);
+  const int D = 6 + (d.cfg.use_lidar ? S : 0);
+  const int collision = d.collision[e];
+  if (lane == 0) inf[0] = collision;
+  if (full) {
     // ---- reward (rewarder.py) ----
     double num = 0.0, den = 0.0;
     const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
@@ -229,7 +293,6 @@ __device__ void k3_env(const AuvDev& d, const int e, const int lane, const int m
     if (lane == 0) {
       const double lambda = 0.5, eta = 0.0, gamma_y_e = 5.0, penalty_yawrate = 10.0, neutral_speed = 0.05,
                    max_speed = 2.0;
-      const int collision = d.collision[e];
       double reward;
       if (collision) {
         reward = -10000.0 * (1 - lambda);
@@ -269,24 +332,23 @@ __device__ void k3_env(const AuvDev& d, const int e, const int lane, const int m
       }
       do_reset = done && d.cfg.auto_reset;
       if (!do_reset) d.counters[e] = cnt;
+      if (e == 0 && d.ring_slots > 1) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;   // next action slot
     }
     do_reset = __shfl(do_reset, 0, AUV_WAVE);
-    AUV_STAMP()
-    AUV_STAMP_FLUSH(e, 8)   // 8:bounds 9:list 10:scan 11:nav 12:reward
     if (do_reset) {
-      // VecEnv auto-reset: rebind to the next world of the bank; the reset observation is
-      // produced by the follow-up reset pass (k2_lidar_fresh + k3_observe_fresh).
-      restore_env(d, e, (int)(((long long)w + d.n) % d.n_worlds), lane, __shfl(cnt.z, 0, AUV_WAVE));
+      // VecEnv auto-reset: rebind to the next world of the bank and copy its reset rows
+      restore_env(d, e, (int)(((long long)w + d.n) % d.n_worlds), lane, __shfl(cnt.z, 0, AUV_WAVE), obs_out);
       return;
     }
   }
-
-  // ---- observation row, float32 (environment.py:139-143, :263-280): closeness part written by K2 ----
-  if (obs_out && mode != 2) {
+  // ---- LiDAR part of the float32 observation row (closeness written in fp64 by K2) ----
+  if (obs_out)
     for (int i = 6 + lane; i < D; i += AUV_WAVE) obs_out[(size_t)e * D + i] = (float)ob[i];
-  }
 }
 
+// mode 0: navigate + observe + reward + done (+ auto-reset bookkeeping)
+// mode 1: navigate + observe only (reset path)
+// mode 2: reward + done only, from the buffers as they stand (test hook)
 __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, float* __restrict__ obs_out,
                                                            float* __restrict__ reward_out,
                                                            uint8_t* __restrict__ done_out) {
@@ -294,30 +356,71 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, f
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
   if (e >= d.n) return;
-  k3_env(d, e, lane, mode, (int*)smem + (size_t)wave * d.nch_max, obs_out, reward_out, done_out);
+  if (mode != 2) k3_nav_env(d, e, lane, (int*)smem + (size_t)wave * d.nch_max, obs_out);
+  k3_reward_env(d, e, lane, mode != 1, mode == 2 ? nullptr : obs_out, reward_out, done_out);
 }
 
-// reset pass: first observation of the environments on the fresh list (mode 1)
+// the two halves as separate kernels for the step path (k3_nav overlaps with K2)
+__global__ void __launch_bounds__(AUV_BLOCK) k3_nav(AuvDev d, float* __restrict__ obs_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  if (e >= d.n) return;
+  k3_nav_env(d, e, lane, (int*)smem + (size_t)wave * d.nch_max, obs_out);
+}
+
+__global__ void __launch_bounds__(AUV_BLOCK) k3_reward(AuvDev d, float* __restrict__ obs_out,
+                                                       float* __restrict__ reward_out,
+                                                       uint8_t* __restrict__ done_out) {
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  if (e >= d.n) return;
+  k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out);
+}
+
+// reset pass: first observation of the environments on the fresh list
 __global__ void __launch_bounds__(AUV_BLOCK) k3_observe_fresh(AuvDev d, float* __restrict__ obs_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int nf = *d.fresh_count;
   int* list = (int*)smem + (size_t)wave * d.nch_max;
   for (int i = blockIdx.x * AUV_ENVS_PER_BLOCK + wave; i < nf; i += gridDim.x * AUV_ENVS_PER_BLOCK) {
-    k3_env(d, d.fresh_list[i], lane, 1, list, obs_out, nullptr, nullptr);
+    const int e = d.fresh_list[i];
+    k3_nav_env(d, e, lane, list, obs_out);
+    k3_reward_env(d, e, lane, false, obs_out, nullptr, nullptr);
     auv_wave_lds_sync();
   }
 }
 
-// reset(): restore reset-time state for masked envs and put them on the fresh list
+// reset(): restore reset-time state (and the precomputed first observation) for masked envs
 __global__ void __launch_bounds__(AUV_BLOCK) k_reset(AuvDev d, const uint8_t* __restrict__ mask,
-                                                     const int32_t* __restrict__ world_idx) {
+                                                     const int32_t* __restrict__ world_idx,
+                                                     float* __restrict__ obs_out) {
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
   if (e >= d.n) return;
   if (mask && !mask[e]) return;
   const int w = world_idx ? world_idx[e] : d.world_idx[e];
-  restore_env(d, e, w, lane, d.counters[e].z);
+  restore_env(d, e, w, lane, d.counters[e].z, obs_out);
+}
+
+// load-time pass: after K2/K3 produced the reset observation of the worlds currently bound to
+// the first `count` env slots, keep those rows per world
+__global__ void __launch_bounds__(AUV_BLOCK) k_harvest(AuvDev d, int count) {
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  if (e >= count) return;
+  const int S = d.cfg.n_sensors;
+  const int w = d.world_idx[e];
+  for (int i = lane; i < S; i += AUV_WAVE) d.w_lidar[(size_t)w * S + i] = d.lidar_d[(size_t)e * S + i];
+  for (int i = lane; i < 6 + S; i += AUV_WAVE) d.w_obs64[(size_t)w * (6 + S) + i] = d.obs64[(size_t)e * (6 + S) + i];
+  if (lane < 8) d.w_info[8 * (size_t)w + lane] = d.info64[8 * (size_t)e + lane];
+  else if (lane < 16) d.w_nav[8 * (size_t)w + lane - 8] = d.nav64[8 * (size_t)e + lane - 8];
+  for (int k = lane; k < d.k_max; k += AUV_WAVE) {
+    d.w_nearby[(size_t)w * d.k_max + k] = d.nearby[(size_t)e * d.k_max + k];
+    d.w_limits[(size_t)w * d.k_max + k] = d.limits[(size_t)e * d.k_max + k];
+  }
+  if (lane == 0) d.w_collision[w] = d.collision[e];
 }
 
 }  // namespace
@@ -329,11 +432,23 @@ void auv_launch_k3(const AuvDev& d, int mode, float* obs, float* reward, uint8_t
   hipLaunchKernelGGL(k3_nav_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), k3_lds_bytes(d), st, d, mode, obs, reward, done);
 }
 
+void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st) {
+  hipLaunchKernelGGL(k3_nav, dim3(env_grid(d)), dim3(AUV_BLOCK), k3_lds_bytes(d), st, d, obs);
+}
+
+void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st) {
+  hipLaunchKernelGGL(k3_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, obs, reward, done);
+}
+
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st) {
   int grid = env_grid(d) < AUV_FRESH_GRID ? env_grid(d) : AUV_FRESH_GRID;
   hipLaunchKernelGGL(k3_observe_fresh, dim3(grid), dim3(AUV_BLOCK), k3_lds_bytes(d), st, d, obs);
 }
 
-void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, hipStream_t st) {
-  hipLaunchKernelGGL(k_reset, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, mask, world_idx);
+void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, float* obs, hipStream_t st) {
+  hipLaunchKernelGGL(k_reset, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, mask, world_idx, obs);
+}
+
+void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st) {
+  hipLaunchKernelGGL(k_harvest, dim3((count + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK), dim3(AUV_BLOCK), 0, st, d, count);
 }

@@ -179,6 +179,13 @@ int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_d
                       float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 int auv_graph_launch(auv_handle_t* h, void* stream);
 
+/* Action ring: after this call `actions_dev` of auv_step / auv_graph_capture is a ring of
+ * n_slots consecutive [N][2] buffers; step k reads slot k % n_slots (the position lives on the
+ * device and is advanced by the step itself), so a policy can fill slot k+1 while step k runs
+ * and a replayed hipGraph needs no per-step argument update.  n_slots = 1 restores the plain
+ * buffer.  Invalidates a captured graph.                                                    */
+int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
+
 /* Mean duration (ms) of each kernel of the last auv_step_timed call, measured with HIP
  * events on `stream` around every launch: out_ms[0..3] = K1, K2, K3, reset-pass.           */
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,

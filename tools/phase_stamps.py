@@ -14,7 +14,17 @@ a = torch.rand((n, 2), device="cuda:0") * 2 - 1
 for i in range(30): env.step(a)
 torch.cuda.synchronize()
 st = env.read("STAMPS").cpu().numpy().astype(np.float64)
-names = ["K2.front", "K2.barrier1", "K2.pairs(4 envs)", "K2.barrier2", "K2.back", "-", "-", "-", "K3.bounds", "K3.list", "K3.scan", "K3.nav", "K3.reward"]
+names = ["K2.front", "K2.pairs", "K2.back", "-", "-", "K2 active segs", "K2 active obst", "-",
+         "K3.bounds", "K3.list", "K3.scan", "K3.nav", "K3.reward"]
 for i, nm in enumerate(names):
     if nm != "-": print("%-18s mean %9.0f  p50 %9.0f  max %9.0f ticks" % (nm, st[:, i].mean(), np.median(st[:, i]), st[:, i].max()) + '  argmax env %d' % st[:, i].argmax())
 print(env.step_timed(a))
+
+# wave timeline of K2 (100 MHz wall clock): start/end relative to the first wave start
+t0, t1 = st[:, 3], st[:, 4]
+base = t0.min()
+print("K2 wave start offsets (us): p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile((t0 - base) / 100.0, [50, 90, 100])))
+print("K2 wave end offsets   (us): p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile((t1 - base) / 100.0, [50, 90, 99, 100])))
+print("K2 wave durations     (us): p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile((t1 - t0) / 100.0, [50, 90, 99, 100])))
+late = np.argsort(t1)[-5:]
+print("last finishers: env", late, "dur us", (t1[late] - t0[late]) / 100.0, "start us", (t0[late] - base) / 100.0, "segs", st[late, 5], "obst", st[late, 6], "front/pairs/back ticks", st[late, 0], st[late, 1], st[late, 2])
