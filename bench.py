@@ -47,13 +47,13 @@ def parse():
 WORKLOADS = {
     # name: (generator, kwargs, n_sectors, n_sensors_per_sector, description)
     "polygons50": ("polygon_world", dict(n_polygons=50), 9, 20,
-                   "4096 envs x 180 sensors, 50 static polygon obstacles (BASELINE configs[2])"),
+                   "%d envs x 180 sensors per GPU, 50 static polygon obstacles (BASELINE configs[2])"),
     "circles20": ("static_circles_world", dict(n_circles=20), 8, 8,
-                  "4096 envs x 64 sensors, 20 static circular obstacles (BASELINE configs[1])"),
+                  "%d envs x 64 sensors per GPU, 20 static circular obstacles (BASELINE configs[1])"),
     "moving28": ("moving_obstacles_world", dict(), 9, 20,
-                 "envs x 180 sensors, 17 moving + 11 static obstacles (BASELINE configs[3] per-GPU shard)"),
+                 "%d envs x 180 sensors per GPU, 17 moving + 11 static obstacles (BASELINE configs[3] shard)"),
     "mixed47": ("polygon_world", dict(n_polygons=10, n_circles=20, n_moving=17), 16, 16,
-                "envs x 256 sensors, 20 circles + 10 polygons + 17 movers (BASELINE configs[4] per-GPU shard)"),
+                "%d envs x 256 sensors per GPU, 20 circles + 10 polygons + 17 movers (BASELINE configs[4] shard)"),
 }
 
 
@@ -102,6 +102,7 @@ def main():
     cfg = effective_reference_config(use_lidar=True)
     cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
     n_local = args.envs
+    desc = desc % n_local
     lo = rank * n_local                                    # weak scaling: fixed envs per GPU
     procs = args.procs or max(1, min(16, host_cores() // max(1, world)))
     t0 = time.time()
@@ -117,7 +118,7 @@ def main():
 
     from gym_auv_amd import distributed as D
     rank, world, local = D.init_from_env()
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))   # (modulo: single-GPU rehearsal of N ranks)
     torch.cuda.set_device(dev)
     from gym_auv_amd.batched_env import BatchedAuvEnv     # fails loudly without the HIP library
     env = BatchedAuvEnv(cfg, bank, n_local, device=dev, auto_reset=True)
@@ -178,7 +179,7 @@ def main():
     dom = max(names, key=lambda nm: per_kernel[nm]["avg_ms"])
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and n_local == 4096:        # the PMC passes were taken at 4096 envs per GPU
         try:
             traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
         except Exception:

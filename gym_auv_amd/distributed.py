@@ -22,7 +22,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # AUV_DIST_BACKEND=gloo rehearses the multi-rank path where RCCL cannot run
+            # (several ranks sharing one GPU, or no GPU at all)
+            backend = os.environ.get("AUV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -46,6 +48,9 @@ def gather_episode_stats(stats: Dict[str, torch.Tensor], n_max: Optional[int] = 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return {k: local[:, i] for i, k in enumerate(keys)}
     world = dist.get_world_size()
+    src_device = local.device
+    if dist.get_backend() == "gloo":
+        local = local.cpu()              # gloo collectives run on host tensors
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)
@@ -55,14 +60,14 @@ def gather_episode_stats(stats: Dict[str, torch.Tensor], n_max: Optional[int] = 
     padded[:local.shape[0]] = local
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded)
-    full = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    full = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0).to(src_device)
     return {k: full[:, i] for i, k in enumerate(keys)}
 
 
 def max_over_ranks(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
