@@ -21,11 +21,11 @@ AUV_CULL_REFERENCE, AUV_CULL_EXACT = 0, 1
 AUV_F32, AUV_F64 = 0, 1
 
 FIELDS = dict(STATE=0, LIDAR_D=1, OBS64=2, REWARD64=3, INFO64=4, WORLD_IDX=5, COUNTERS=6,
-              MOVER_STATE=7, NEARBY=8, EPISODE=9, CULL_LIMITS=10, NAV64=11, COLLISION=12, STAMPS=13)
+              MOVER_STATE=7, NEARBY=8, EPISODE=9, CULL_LIMITS=10, NAV64=11, COLLISION=12, STAMPS=13, STEP_INFO=14)
 FIELD_DTYPES = dict(STATE=np.float64, LIDAR_D=np.float64, OBS64=np.float64, REWARD64=np.float64,
                     INFO64=np.float64, WORLD_IDX=np.int32, COUNTERS=np.int32, MOVER_STATE=np.float64,
                     NEARBY=np.uint8, EPISODE=np.float64, CULL_LIMITS=np.int32, NAV64=np.float64,
-                    COLLISION=np.uint8, STAMPS=np.int64)
+                    COLLISION=np.uint8, STAMPS=np.int64, STEP_INFO=np.float64)
 
 
 class AuvLibraryError(RuntimeError):

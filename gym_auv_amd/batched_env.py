@@ -171,7 +171,7 @@ class BatchedAuvEnv:
         n, S = self.n_envs, self.n_sensors
         return dict(STATE=(6, n), LIDAR_D=(n, S), OBS64=(n, 6 + S), REWARD64=(n,), INFO64=(n, 8),
                     WORLD_IDX=(n,), COUNTERS=(n, 4), MOVER_STATE=(n, self.m_max, 4), NEARBY=(n, self.k_max),
-                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,), STAMPS=(n, 16))[name]
+                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,), STAMPS=(n, 16), STEP_INFO=(n, 4))[name]
 
     def read(self, name: str) -> torch.Tensor:
         t = torch.empty(self.field_shape(name), dtype=_TORCH_DTYPES[FIELD_DTYPES[name]], device=self.device)
@@ -196,10 +196,10 @@ class BatchedAuvEnv:
 
 
 class _LazyInfo(dict):
-    """info of the batched step: tensors fetched from the device only when a key is read
-    (keys as environment.py:336-340)."""
-    _KEYS = {"collision": 0, "reached_goal": 1, "goal_distance": 2, "progress": 3,
-             "cumulative_reward": 4, "max_progress": 5, "vessel_arclength": 6}
+    """info of the batched step (keys as environment.py:336-340): tensors fetched from the
+    device only when a key is read.  Values belong to the step that was taken: for an env that
+    finished and was auto-reset they are the terminal ones."""
+    _KEYS = {"collision": 0, "reached_goal": 1, "goal_distance": 2, "progress": 3}
 
     def __init__(self, env):
         super().__init__()
@@ -210,7 +210,7 @@ class _LazyInfo(dict):
         if key not in self._KEYS:
             raise KeyError(key)
         if self._info is None:
-            self._info = self._env.read("INFO64")
+            self._info = self._env.read("STEP_INFO")
         v = self._info[:, self._KEYS[key]]
         self[key] = v
         return v

@@ -237,6 +237,7 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   rc |= dev_alloc(ep, &d.episode, n * 4);
   rc |= dev_alloc(ep, &d.limits, n * k_max);
   rc |= dev_alloc(ep, &d.collision, n);
+  rc |= dev_alloc(ep, &d.step_info, n * 4);
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
   rc |= dev_alloc(ep, &d.stamps, n * 16);
@@ -380,6 +381,7 @@ static void* field_ptr(const auv_handle_t* h, int32_t field, size_t* bytes) {
     case AUV_FIELD_NAV64: *bytes = 8 * 8 * n; return d.nav64;
     case AUV_FIELD_COLLISION: *bytes = n; return d.collision;
     case AUV_FIELD_STAMPS: *bytes = 8 * 16 * n; return d.stamps;
+    case AUV_FIELD_STEP_INFO: *bytes = 8 * 4 * n; return d.step_info;
   }
   *bytes = 0;
   return nullptr;

@@ -323,6 +323,10 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
       const int done = collision || (inf[1] != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
                        (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);
       cnt.x = t_step + 1;
+      {
+        double* si = d.step_info + 4 * (size_t)e;          // environment.py:336-340
+        si[0] = collision, si[1] = inf[1], si[2] = inf[2], si[3] = inf[3];
+      }
       if (reward_out) reward_out[e] = (float)reward;
       if (done_out) done_out[e] = (uint8_t)done;
       if (done) {

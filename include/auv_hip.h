@@ -132,8 +132,12 @@ enum {
                                  look_ahead_heading_error, heading_error, cross_track_error/100,
                                  path_direction, target_arclength        (vessel.py:518-536) */
   AUV_FIELD_COLLISION = 12,  /* [N] uint8  Vessel._collision                                */
-  AUV_FIELD_STAMPS = 13      /* [N][16] uint64 per-phase cycle counts; zeros unless the library
+  AUV_FIELD_STAMPS = 13,     /* [N][16] uint64 per-phase cycle counts; zeros unless the library
                                  was built with STAMPS=1 (diagnostic)                       */
+  AUV_FIELD_STEP_INFO = 14   /* [N][4] the `info` dict of the last step() as the reference
+                                 returns it (environment.py:336-340): collision, reached_goal,
+                                 goal_distance, progress -- of the step that was taken, i.e. the
+                                 terminal values for an env that has just been auto-reset      */
 };
 
 /* Create an environment batch of n_envs on device `device_id`.            (environment.py:29-164) */

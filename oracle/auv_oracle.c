@@ -48,6 +48,7 @@ typedef struct oracle {
   double* episode;    /* [N][4] */
   int32_t* limits;    /* [N][Kmax][2] */
   uint8_t* collision; /* [N] */
+  double* step_info;  /* [N][4] */
 } oracle_t;
 
 /* ---------------------------------------------------------------- utils/geomutils.py:4-5 */
@@ -558,7 +559,7 @@ int oracle_create(const auv_config_t* cfg, int32_t n_envs, oracle_t** out) {
 static void free_env_buffers(oracle_t* o) {
   free(o->state), free(o->world_idx), free(o->counters), free(o->lidar_d), free(o->obs64);
   free(o->reward64), free(o->info64), free(o->nav64), free(o->mover), free(o->nearby);
-  free(o->episode), free(o->limits), free(o->collision);
+  free(o->episode), free(o->limits), free(o->collision), free(o->step_info);
 }
 
 int oracle_destroy(oracle_t* o) {
@@ -593,6 +594,7 @@ int oracle_load_worlds(oracle_t* o, const auv_world_bank_t* bank) {
   o->episode = (double*)zalloc(sizeof(double) * 4 * n);
   o->limits = (int32_t*)zalloc(sizeof(int32_t) * (size_t)n * o->k_max * 2);
   o->collision = (uint8_t*)zalloc(n);
+  o->step_info = (double*)zalloc(sizeof(double) * 4 * n);
   for (int e = 0; e < n; e++) o->world_idx[e] = e % W;
   return 0;
 }
@@ -634,6 +636,10 @@ static void finish_step(oracle_t* o, int e, uint8_t* done_out) {
              (inf[4] < c->min_cumulative_reward && !c->test_mode); /* environment.py:375-384 */
   o->counters[4 * e] = t_step + 1;
   done_out[e] = (uint8_t)done;
+  { /* info dict of this step, environment.py:336-340 */
+    double* si = o->step_info + 4 * (size_t)e;
+    si[0] = o->collision[e], si[1] = inf[1], si[2] = inf[2], si[3] = inf[3];
+  }
   if (done) {
     double* ep = o->episode + 4 * (size_t)e;
     ep[0] = inf[4], ep[1] = t_step + 1, ep[2] = o->collision[e], ep[3] = inf[1];
@@ -706,6 +712,7 @@ static void* field_ptr(oracle_t* o, int field, size_t* bytes) {
     case AUV_FIELD_CULL_LIMITS: *bytes = 4 * n * o->k_max * 2; return o->limits;
     case AUV_FIELD_NAV64: *bytes = 8 * 8 * n; return o->nav64;
     case AUV_FIELD_COLLISION: *bytes = n; return o->collision;
+    case AUV_FIELD_STEP_INFO: *bytes = 8 * 4 * n; return o->step_info;
   }
   *bytes = 0;
   return NULL;

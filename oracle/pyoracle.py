@@ -110,7 +110,7 @@ class Oracle:
         return dict(STATE=(6, n), LIDAR_D=(n, S), OBS64=(n, 6 + S), REWARD64=(n,), INFO64=(n, 8),
                     WORLD_IDX=(n,), COUNTERS=(n, 4), MOVER_STATE=(n, self.m_max, 4),
                     NEARBY=(n, self.k_max), EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2),
-                    NAV64=(n, 8), COLLISION=(n,))[name]
+                    NAV64=(n, 8), COLLISION=(n,), STEP_INFO=(n, 4))[name]
 
     def read(self, name):
         out = np.empty(self._shape(name), dtype=FIELD_DTYPES[name])

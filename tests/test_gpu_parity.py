@@ -208,10 +208,11 @@ def test_batched_step_vs_oracle_with_auto_reset(S, ns, nps):
         a = rs.uniform([-1, -0.15], [1, 0.15], (n, 2))
         if t == 3:
             a[5] = np.nan
-        obs, rew, done, _ = env.step(torch.as_tensor(a, device="cuda:0"))
+        obs, rew, done, info = env.step(torch.as_tensor(a, device="cuda:0"))
         o_obs, o_rew, o_done = ora.step(a)
         np.testing.assert_array_equal(_np(done), o_done)
-        for f in ("STATE", "LIDAR_D", "OBS64", "REWARD64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE"):
+        np.testing.assert_array_equal(_np(info["collision"]), ora.read("STEP_INFO")[:, 0])   # terminal info survives the reset
+        for f in ("STATE", "LIDAR_D", "OBS64", "REWARD64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "STEP_INFO"):
             np.testing.assert_allclose(_np(env.read(f)), ora.read(f), rtol=0, atol=ATOL, err_msg="%s step %d" % (f, t))
         for f in ("WORLD_IDX", "COUNTERS", "NEARBY", "COLLISION", "CULL_LIMITS"):
             g, o = _np(env.read(f)), ora.read(f)

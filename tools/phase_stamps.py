@@ -15,7 +15,7 @@ for i in range(30): env.step(a)
 torch.cuda.synchronize()
 st = env.read("STAMPS").cpu().numpy().astype(np.float64)
 names = ["K2.front", "K2.pairs", "K2.back", "-", "-", "K2 active segs", "K2 active obst", "-",
-         "K3.bounds", "K3.list", "K3.scan", "K3.nav", "K3.reward"]
+         "K3.bounds", "K3.list", "K3.scan", "K3.nav", "K2.front A+C", "K2.front B", "K2.front scan"]
 for i, nm in enumerate(names):
     if nm != "-": print("%-18s mean %9.0f  p50 %9.0f  max %9.0f ticks" % (nm, st[:, i].mean(), np.median(st[:, i]), st[:, i].max()) + '  argmax env %d' % st[:, i].argmax())
 print(env.step_timed(a))
