@@ -166,6 +166,23 @@ class BatchedAuvEnv:
                                    self._stream(), ms), "auv_step_timed")
         return [float(x) for x in ms]
 
+    # ------------------------------------------------------------------------------ optional post-kernel
+    def feasibility_pooling(self, width: Optional[float] = None):
+        """Sector-wise feasible distances of the current ranges (sensor.py:251-296); returns
+        (distances [N, n_sectors] float64, closeness [N, n_sectors] float32)."""
+        from .pooling import sector_starts
+        v = self.config.vessel
+        if width is None:
+            width = v.vessel_width * v.feasibility_width_multiplier
+        if getattr(self, "_sector_start", None) is None:
+            self._sector_start = torch.as_tensor(sector_starts(v.n_sectors, v.n_sensors_per_sector), device=self.device)
+        dist = torch.empty((self.n_envs, v.n_sectors), dtype=torch.float64, device=self.device)
+        clos = torch.empty((self.n_envs, v.n_sectors), dtype=torch.float32, device=self.device)
+        _check(_LIB.auv_feasibility_pooling(self._h, C.c_void_p(self._sector_start.data_ptr()), v.n_sectors,
+                                            float(width), C.c_void_p(dist.data_ptr()), C.c_void_p(clos.data_ptr()),
+                                            self._stream()), "auv_feasibility_pooling")
+        return dist, clos
+
     # ------------------------------------------------------------------------------ field access
     def field_shape(self, name: str):
         n, S = self.n_envs, self.n_sensors

@@ -23,6 +23,8 @@ void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world
 void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
 hipError_t auv_k2_prepare(const AuvDev& d);
+void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
+                   float* out_closeness, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -409,6 +411,16 @@ int auv_write(auv_handle_t* h, int32_t field, const void* src_dev, size_t bytes,
   void* p = field_ptr(h, field, &b);
   if (!p || !src_dev || bytes != b) return fail(AUV_EINVAL, "auv_write: field %d expects %zu bytes, got %zu", field, b, bytes);
   HIP_TRY(hipMemcpyAsync(p, src_dev, b, hipMemcpyDefault, (hipStream_t)stream));
+  return AUV_OK;
+}
+
+int auv_feasibility_pooling(auv_handle_t* h, const int32_t* sector_start_dev, int32_t n_sectors, double width,
+                            double* out_dist_dev, float* out_closeness_dev, void* stream) {
+  REQUIRE_READY(h);
+  if (!sector_start_dev || n_sectors < 1 || n_sectors > h->d.cfg.n_sensors || !(width >= 0.0))
+    return fail(AUV_EINVAL, "auv_feasibility_pooling: bad arguments");
+  auv_launch_k4(h->d, sector_start_dev, n_sectors, width, out_dist_dev, out_closeness_dev, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
   return AUV_OK;
 }
 

@@ -195,6 +195,15 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                    float* reward_dev, uint8_t* done_dev, void* stream, float* out_ms4);
 
+/* Feasibility pooling (optional post-kernel on the current LiDAR ranges):
+ * for every env and sector k (sensors sector_start[k] .. sector_start[k+1]-1) the feasible
+ * distance of LidarPreprocessor._feasibility_pooling (sensor.py:251-296) with opening width
+ * `width` (= vessel_width * feasibility_width_multiplier) and sensor spacing 2*pi/S.
+ * sector_start_dev: [n_sectors+1] int32; out_dist_dev: [N][n_sectors] fp64 (nullable);
+ * out_closeness_dev: [N][n_sectors] f32 closeness of those distances (nullable).            */
+int auv_feasibility_pooling(auv_handle_t* h, const int32_t* sector_start_dev, int32_t n_sectors, double width,
+                            double* out_dist_dev, float* out_closeness_dev, void* stream);
+
 int32_t auv_abi_version(void);
 const char* auv_last_error(void);
 

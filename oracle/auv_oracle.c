@@ -750,3 +750,58 @@ int oracle_set_threads(int n) {
   return 1;
 #endif
 }
+
+/* SURVEY 8(f) F3 -- sensor.py:251-296 `_feasibility_pooling` for one sector, as written:
+ * ascending order of range (insertion sort of indices), first range without an opening. */
+static double feasibility_pooling_sector(const double* m, int N, double width, double theta) {
+  int idx[4096];
+  for (int i = 0; i < N; i++) {
+    int j = i;
+    while (j > 0 && m[idx[j - 1]] > m[i]) idx[j] = idx[j - 1], j--;
+    idx[j] = i;
+  }
+  double mmax = 0.0;
+  for (int i = 0; i < N; i++)
+    if (m[i] > mmax) mmax = m[i];
+  for (int q = 0; q < N; q++) {
+    const int id = idx[q];
+    const double d = m[id] * theta;
+    double opening_width = 0, opening_span = 0, opening_start = -theta * (N - 1) / 2;
+    int found_opening = 0;
+    for (int isensor = 0; isensor < N; isensor++) {
+      const int survives = m[isensor] > m[id] + width;
+      if (survives) {
+        opening_width += d;
+        opening_span += theta;
+        if (opening_width > width) {
+          const double opening_center = opening_start + opening_span / 2;
+          if (fabs(opening_center) < theta * (N - 1) / 4) found_opening = 1;
+        }
+      } else {
+        opening_width += 0.5 * d;
+        opening_span += 0.5 * theta;
+        if (opening_width > width) {
+          const double opening_center = opening_start + opening_span / 2;
+          if (fabs(opening_center) < theta * (N - 1) / 4) found_opening = 1;
+        }
+        opening_width = 0;
+        opening_span = 0;
+        opening_start = -theta * (N - 1) / 2 + isensor * theta;
+      }
+    }
+    if (!found_opening) return m[id] > 0 ? m[id] : 0;
+  }
+  return mmax > 0 ? mmax : 0;
+}
+
+/* sensor.py:215-238 `preprocess` (distances only): out[N][n_sectors] */
+int oracle_feasibility_pooling(oracle_t* o, const int32_t* sector_start, int32_t n_sectors, double width, double* out) {
+  int S = o->cfg.n_sensors;
+  if (S > 4096) return AUV_EINVAL;
+  double theta = 2 * PI / S;
+  for (int e = 0; e < o->n; e++)
+    for (int k = 0; k < n_sectors; k++)
+      out[(size_t)e * n_sectors + k] = feasibility_pooling_sector(o->lidar_d + (size_t)e * S + sector_start[k],
+                                                                  sector_start[k + 1] - sector_start[k], width, theta);
+  return 0;
+}

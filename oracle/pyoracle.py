@@ -46,6 +46,7 @@ def _load():
         lib.oracle_field_bytes.restype = sz
         lib.oracle_kmax.argtypes = [vp]
         lib.oracle_set_threads.argtypes = [C.c_int]
+        lib.oracle_feasibility_pooling.argtypes = [vp, vp, i32, C.c_double, vp]
         lib.oracle_mmax.argtypes = [vp]
         _lib = lib
     return _lib
@@ -103,6 +104,12 @@ class Oracle:
         done = np.zeros(self.n, dtype=np.uint8)
         assert self.lib.oracle_nav_reward(self.h, int(mode), done.ctypes.data) == 0
         return done
+
+    def feasibility_pooling(self, sector_start, width):
+        st = np.ascontiguousarray(sector_start, dtype=np.int32)
+        out = np.empty((self.n, len(st) - 1), dtype=np.float64)
+        assert self.lib.oracle_feasibility_pooling(self.h, st.ctypes.data, len(st) - 1, float(width), out.ctypes.data) == 0
+        return out
 
     # --- fields ------------------------------------------------------------------------
     def _shape(self, name):

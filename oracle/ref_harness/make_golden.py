@@ -12,6 +12,8 @@ stored below is produced by a reference function:
     G4 reward     ColavRewarder / PathFollowRewarder.calculate, BaseEnvironment._isdone
                                                  rewarder.py:78-241, environment.py:375-384
     G5 rollouts   BaseEnvironment.reset/step     environment.py:176-366
+    G6 pooling    LidarPreprocessor._feasibility_pooling, sector_partition_fun
+                                                 sensor.py:251-296, utils/sector_partitioning.py:4-9
 Each fixture records dt / min_goal_distance / use_lidar explicitly.
 GEOS primitives come from the shim, so GEOS numerics are "parity unpinned" (DESIGN.md).
 """
@@ -523,9 +525,48 @@ def gen_rollouts():
     np.savez_compressed(os.path.join(OUT, "g5_rollouts.npz"), **out)
 
 
+# =============================================================================== G6
+def gen_pooling():
+    """Feasibility pooling: the reference's own static method (sensor.py:251-296) and sector
+    partition function (utils/sector_partitioning.py:4-9) -- the class wiring around them is
+    broken at HEAD, the two functions themselves run."""
+    from gym_auv.objects.vessel.sensor import LidarPreprocessor
+    from gym_auv.utils.sector_partitioning import sector_partition_fun
+    rs = np.random.RandomState(6006)
+    out = {}
+    for S, ns, nps in ((180, 9, 20), (64, 8, 8), (256, 16, 16)):
+        cfg = make_cfg(n_sectors=ns, n_per_sector=nps)
+        holder = type("H", (), {"config": cfg})()
+        sect = np.array([sector_partition_fun(holder, i) for i in range(S)], dtype=np.int64)
+        out["S%d_sector_of_sensor" % S] = sect
+        starts = [0] + [int(np.argmax(sect == k)) for k in range(1, ns)]
+        width = cfg.vessel.vessel_width * cfg.vessel.feasibility_width_multiplier
+        theta = 2 * np.pi / S
+        n = 96
+        d = np.full((n, S), 150.0)
+        for i in range(n):
+            m = rs.rand(S) < rs.uniform(0.05, 0.9)
+            d[i, m] = rs.uniform(0, 150, m.sum())
+            if i % 5 == 0:                       # blocks of near returns (an obstacle face)
+                j = rs.randint(0, S - 12)
+                d[i, j:j + 12] = rs.uniform(2, 30)
+            if i % 11 == 0:
+                d[i] = rs.choice([5.0, 40.0, 150.0], S)   # many ties
+        res = np.empty((n, ns))
+        for i in range(n):
+            parts = np.split(d[i], starts[1:])
+            res[i] = [LidarPreprocessor._feasibility_pooling(p, width, theta) for p in parts]
+        out["S%d_d" % S] = d
+        out["S%d_feasible" % S] = res
+        out["S%d_starts" % S] = np.array(starts + [S], dtype=np.int64)
+        out["S%d_width_theta" % S] = np.array([width, theta])
+    np.savez_compressed(os.path.join(OUT, "g6_pooling.npz"), **out)
+    print("G6 pooling: sector sizes", {S: np.diff(out["S%d_starts" % S]).tolist() for S in (180, 64, 256)})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     if "g1" in which:
         gen_dynamics()
     if "g2" in which:
@@ -536,5 +577,7 @@ if __name__ == "__main__":
         gen_reward()
     if "g5" in which:
         gen_rollouts()
+    if "g6" in which:
+        gen_pooling()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
