@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""PPO on the batched MI355X environment, tensors never leave the GPU.
+
+Hyper-parameters follow the reference's training script (/root/reference/scripts/run.py:332-357:
+MlpPolicy [256, 128, 64], gamma 0.999, lambda 0.98, 4 epochs, 32 minibatches, ent_coef 0.01,
+lr 2e-4, clip 0.2); the rollout length is shortened because one batched step already yields
+thousands of transitions (the reference collected 8 envs x 1024 steps per update).
+
+    python examples/ppo.py --envs 4096 --updates 20 --rollout 32
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, obs_dim, act_dim=2, hidden=(256, 128, 64)):
+        super().__init__()
+        def mlp(out):
+            layers, d = [], obs_dim
+            for h in hidden:
+                layers += [nn.Linear(d, h), nn.Tanh()]
+                d = h
+            return nn.Sequential(*layers, nn.Linear(d, out))
+        self.pi, self.v = mlp(act_dim), mlp(1)
+        self.log_std = nn.Parameter(torch.full((act_dim,), -0.5))
+
+    def dist(self, obs):
+        return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
+
+
+def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print):
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    from gym_auv_amd.config import effective_reference_config
+    from gym_auv_amd.world import build_bank_parallel
+    torch.manual_seed(seed)
+    cfg = effective_reference_config(use_lidar=True)
+    bank = build_bank_parallel("moving_obstacles_world", range(5000, 5000 + min(envs, 512)), procs=min(8, os.cpu_count() or 1))
+    env = BatchedAuvEnv(cfg, bank, envs, device=device, auto_reset=True)
+    low = torch.as_tensor(env.action_space.low, device=device)
+    high = torch.as_tensor(env.action_space.high, device=device)
+    net = ActorCritic(env.obs_dim).to(device)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    gamma, lam, clip, ent_coef, epochs, n_mb = 0.999, 0.98, 0.2, 0.01, 4, 32
+    obs = env.reset().clone()
+    history = []
+    for upd in range(updates):
+        t0 = time.time()
+        O, A, LP, R, D, V = [], [], [], [], [], []
+        with torch.no_grad():
+            for _ in range(rollout):
+                dist = net.dist(obs)
+                a = dist.sample()
+                nobs, rew, done, _ = env.step(torch.max(torch.min(a, high), low))
+                O.append(obs), A.append(a), LP.append(dist.log_prob(a).sum(-1)), V.append(net.v(obs).squeeze(-1))
+                R.append(rew.clone() * 0.01), D.append(done.float())          # reward scale for the value net
+                obs = nobs.clone()
+            last_v = net.v(obs).squeeze(-1)
+            adv, gae = [None] * rollout, torch.zeros(envs, device=device)
+            for t in reversed(range(rollout)):
+                nv = last_v if t == rollout - 1 else V[t + 1]
+                delta = R[t] + gamma * nv * (1 - D[t]) - V[t]
+                gae = delta + gamma * lam * (1 - D[t]) * gae
+                adv[t] = gae
+        O, A, LP, V = torch.cat(O), torch.cat(A), torch.cat(LP), torch.cat(V)
+        ADV = torch.cat(adv)
+        RET = ADV + V
+        ADV = (ADV - ADV.mean()) / (ADV.std() + 1e-8)
+        n = O.shape[0]
+        for _ in range(epochs):
+            perm = torch.randperm(n, device=device)
+            for mb in perm.chunk(n_mb):
+                dist = net.dist(O[mb])
+                ratio = (dist.log_prob(A[mb]).sum(-1) - LP[mb]).exp()
+                pg = -torch.min(ratio * ADV[mb], ratio.clamp(1 - clip, 1 + clip) * ADV[mb]).mean()
+                vf = 0.5 * (net.v(O[mb]).squeeze(-1) - RET[mb]).pow(2).mean()
+                loss = pg + 0.5 * vf - ent_coef * dist.entropy().sum(-1).mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                nn.utils.clip_grad_norm_(net.parameters(), 0.5)
+                opt.step()
+        torch.cuda.synchronize()
+        mean_r = float(torch.stack(R).mean().item()) / 0.01
+        sps = envs * rollout / (time.time() - t0)
+        history.append((mean_r, float(loss.item()), sps))
+        log("update %3d  mean step reward %8.3f  loss %8.4f  %.2e env-steps/s incl. learning" % (upd, mean_r, loss.item(), sps))
+    env.close()
+    return history
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--updates", type=int, default=10)
+    ap.add_argument("--rollout", type=int, default=32)
+    a = ap.parse_args()
+    train(a.envs, a.updates, a.rollout)
