@@ -30,7 +30,8 @@ _lib = None
 def _load():
     global _lib
     if _lib is None:
-        lib = C.CDLL(build())
+        # AUV_ORACLE_LIB points the tests at another build of the same source (e.g. `make asan`)
+        lib = C.CDLL(os.environ.get("AUV_ORACLE_LIB") or build())
         vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
         lib.oracle_create.argtypes = [C.POINTER(AuvConfig), i32, C.POINTER(vp)]
         lib.oracle_destroy.argtypes = [vp]

@@ -1,0 +1,115 @@
+"""-m gpu: edge cases of the HIP path against the oracle -- ragged and extreme shapes that take
+the non-default code paths (odd sensor counts, env counts that do not fill a workgroup, no
+obstacles, hundreds of obstacles, boundaries larger than the LDS stage, paths longer than the
+register-resident chunk table, vessel inside / on top of obstacles)."""
+import numpy as np
+import pytest
+import torch
+
+from gym_auv_amd._capi import make_config
+from gym_auv_amd.config import effective_reference_config
+from gym_auv_amd import scenarios as sc
+from gym_auv_amd.world import build_world, pack_bank
+from gym_auv_amd.worldspec import WorldSpec
+
+pytestmark = pytest.mark.gpu
+FIELDS_F = ("STATE", "LIDAR_D", "OBS64", "REWARD64", "INFO64", "NAV64", "MOVER_STATE")
+FIELDS_I = ("NEARBY", "COLLISION", "CULL_LIMITS", "WORLD_IDX")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _run(cfg, specs, n, steps=30, seed=0, poses=None, **kw):
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    from oracle.pyoracle import Oracle
+    bank = pack_bank([build_world(s) for s in specs])
+    env = BatchedAuvEnv(cfg, bank, n, device="cuda:0", **kw)
+    ora = Oracle(make_config(cfg, **kw), n, bank)
+    np.testing.assert_allclose(_np(env.reset()), ora.reset()[:, :env.obs_dim], rtol=0, atol=1e-6)
+    if poses is not None:
+        st = ora.read("STATE")
+        st[:3] = np.asarray(poses, dtype=np.float64).T
+        env.write("STATE", st), ora.write("STATE", st)
+    rs = np.random.RandomState(seed)
+    for t in range(steps):
+        a = rs.uniform([-1, -0.15], [1, 0.15], (n, 2))
+        a[:, 0] = np.abs(a[:, 0])
+        obs, rew, done, _ = env.step(torch.as_tensor(a, device="cuda:0"))
+        o_obs, o_rew, o_done = ora.step(a)
+        np.testing.assert_array_equal(_np(done), o_done, err_msg="done step %d" % t)
+        for f in FIELDS_F:
+            np.testing.assert_allclose(_np(env.read(f)), ora.read(f), rtol=0, atol=1e-9, err_msg="%s step %d" % (f, t))
+        for f in FIELDS_I:
+            np.testing.assert_array_equal(_np(env.read(f)), ora.read(f), err_msg="%s step %d" % (f, t))
+        np.testing.assert_allclose(_np(obs), o_obs[:, :env.obs_dim], rtol=0, atol=1e-6)
+    return env, ora
+
+
+def _cfg(ns=9, nps=20, **kw):
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
+    for k, v in kw.items():
+        setattr(cfg.episode, k, v)
+    return cfg
+
+
+@pytest.mark.parametrize("n,ns,nps", [(1, 9, 20), (5, 9, 1), (7, 10, 10), (3, 3, 1), (130, 13, 7)])
+def test_ragged_env_and_sensor_counts(n, ns, nps):
+    specs = [sc.moving_obstacles_world(700 + i) for i in range(3)]
+    _run(_cfg(ns, nps, max_timesteps=11), specs, n, steps=25, auto_reset=True)
+
+
+def test_no_obstacles_with_lidar_on():
+    env, _ = _run(_cfg(), [sc.empty_scenario(), sc.moving_obstacles_world(5, 0, 0)], 6, steps=10, auto_reset=False)
+    assert (_np(env.read("LIDAR_D")) == 150.0).all() and not _np(env.read("COLLISION")).any()
+
+
+def test_lidar_off_observation_is_navigation_only():
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    cfg = effective_reference_config(use_lidar=False)
+    env, ora = _run(cfg, [sc.moving_obstacles_world(9)], 4, steps=10, rewarder="pathfollow", auto_reset=False)
+    assert env.obs.shape == (4, 6) and env.observation_space.shape == (6,)
+
+
+def test_hundreds_of_obstacles_testscenario2():
+    """278 circles: several passes of the obstacle phase and a >64 KiB LDS footprint."""
+    w = sc.test_scenario2()
+    rs = np.random.RandomState(1)
+    poses = [[w.circles[k, 0] + rs.normal(0, 20), w.circles[k, 1] + rs.normal(0, 20), rs.uniform(-3, 3)] for k in (3, 60, 150, 277)]
+    _run(_cfg(8, 8), [w], 4, steps=30, poses=poses, auto_reset=False)
+
+
+def test_boundary_larger_than_the_lds_stage():
+    """A 150-gon (filled) and a 300-gon: swept straight from HBM; vessel outside, inside, near."""
+    ang = np.linspace(0, 2 * np.pi, 150, endpoint=False)
+    big = np.stack([40 * np.cos(ang) * (1 + 0.2 * np.sin(5 * ang)), 40 * np.sin(ang) * (1 + 0.2 * np.sin(5 * ang))], axis=1) + [60, 0]
+    ang2 = np.linspace(0, 2 * np.pi, 300, endpoint=False)
+    huge = np.stack([25 * np.cos(ang2), 25 * np.sin(ang2)], axis=1) + [-70, 30]
+    small = np.array([[10, 40], [30, 40], [30, 60], [10, 60.0]])
+    w = WorldSpec(waypoints=np.array([[0.0, 400.0], [0.0, 0.0]]), vessel_init=np.array([0.0, 0.0, 0.0]),
+                  circles=np.array([[0.0, -60.0, 20.0]]), polygons=[big, huge, small])
+    poses = [[0, 0, 0.3], [60, 0, 1.0], [-70, 30, -2.0], [20, 50, 0.0], [5, -30, 1.5], [110, 5, 3.0]]
+    env, _ = _run(_cfg(), [w], 6, steps=20, poses=poses, auto_reset=False)
+
+
+def test_path_longer_than_register_chunk_table():
+    """3.4 km straight path: 34 000 vertices -> 531 chunks (> 256): generic two-pass route."""
+    w = WorldSpec(waypoints=np.array([[0.0, 2400.0], [0.0, 2400.0]]), vessel_init=np.array([1200.0, 1190.0, 0.7]),
+                  circles=np.array([[1230.0, 1220.0, 10.0]]))
+    poses = [[1200, 1190, 0.7], [10, -5, 0.0], [2395, 2402, 2.0], [600, 900, -1.0]]
+    _run(_cfg(8, 8), [w], 4, steps=15, poses=poses, auto_reset=False)
+
+
+def test_vessel_on_top_of_obstacle_centres():
+    """dist(p0, circle centre) == 0 (the 1e-8 guard), vessel inside rings / polygons / movers."""
+    w = sc.polygon_world(77, n_polygons=6, n_circles=5, n_moving=4)
+    built = build_world(w)
+    poses = [[w.circles[0, 0], w.circles[0, 1], 0.1], [w.circles[1, 0] + 1e-9, w.circles[1, 1], 2.0],
+             list(np.mean(w.polygons[0], axis=0)) + [1.0], list(np.mean(w.polygons[1], axis=0)) + [-1.0],
+             [w.movers[0].pos[0] + 0.3 * w.movers[0].width, w.movers[0].pos[1], 0.0], list(w.vessel_init)]
+    # the nearby-obstacle cache still holds the reset pose's list until vessel step 25
+    # (vessel.py:266), so most of these overlaps only register after the refresh
+    env, _ = _run(_cfg(), [w], 6, steps=30, poses=poses, auto_reset=False)
+    assert _np(env.read("EPISODE"))[:, 2].sum() >= 2          # those starts end in collisions
