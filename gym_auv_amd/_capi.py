@@ -104,11 +104,14 @@ def make_bank_struct(bank: Dict[str, np.ndarray]) -> Tuple[AuvWorldBank, list]:
 _lib = None
 
 
-def load_library(path: str = LIB_PATH) -> C.CDLL:
-    """dlopen libauv_hip.so and declare every prototype of include/auv_hip.h."""
+def load_library(path: str = None) -> C.CDLL:
+    """dlopen libauv_hip.so and declare every prototype of include/auv_hip.h.
+    AUV_HIP_LIB selects another build of the same library (A/B timing of kernel variants)."""
     global _lib
     if _lib is not None:
         return _lib
+    if path is None:
+        path = os.environ.get("AUV_HIP_LIB") or LIB_PATH
     if not os.path.exists(path):
         raise AuvLibraryError(
             "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "

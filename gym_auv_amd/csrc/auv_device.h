@@ -91,9 +91,20 @@ struct AuvDev {
 #endif
 
 __device__ __forceinline__ double auv_princip(double a) {
-  // ((a + pi) % (2 pi)) - pi with Python's sign convention (utils/geomutils.py:4-5)
-  double m = fmod(a + AUV_PI, 2.0 * AUV_PI);
-  if (m < 0.0) m += 2.0 * AUV_PI;
+  // ((a + pi) % (2 pi)) - pi with Python's sign convention (utils/geomutils.py:4-5).
+  // x = a + pi almost always lies within one period of [0, 2 pi); there fmod is the identity
+  // or one exact subtraction (Sterbenz), so the short cuts below are bit-identical to
+  // fmod(x, 2 pi) followed by the sign fix-up, without the slow fp64 fmod.
+  const double TWO_PI = 2.0 * AUV_PI;
+  const double x = a + AUV_PI;
+  double m;
+  if (x >= 0.0 && x < TWO_PI) m = x;
+  else if (x >= TWO_PI && x < 2.0 * TWO_PI) m = x - TWO_PI;
+  else if (x < 0.0 && x > -TWO_PI) m = x + TWO_PI;
+  else {
+    m = fmod(x, TWO_PI);
+    if (m < 0.0) m += TWO_PI;
+  }
   return m - AUV_PI;
 }
 

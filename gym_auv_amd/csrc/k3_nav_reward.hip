@@ -279,12 +279,21 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
     if (colav) {
       const double* dd = d.lidar_d + (size_t)e * S;
       const double dangle = 2 * AUV_PI / S;
-      for (int i = lane; i < S; i += AUV_WAVE) {
-        double angle = -AUV_PI + (i + 1) * dangle;          // body-frame beam angle (vessel.py:66-68)
-        double weight = 1 / (1 + fabs(10.0 * angle));        // gamma_theta
-        double raw = d.cfg.sensor_range * exp(-0.1 * dd[i]); // gamma_x; velocity channel == 0 (sensor.py:159)
-        num += weight * raw;
-        den += weight;
+      // beams without a return sit exactly at sensor_range: their exp() is one constant, so the
+      // transcendental is only evaluated in passes where some lane actually has a return
+      const double R = d.cfg.sensor_range;
+      const double raw_free = R * exp(-0.1 * R);
+      for (int i0 = 0; i0 < S; i0 += AUV_WAVE) {
+        const int i = i0 + lane;
+        const double di = (i < S) ? dd[i] : R;
+        double raw = raw_free;
+        if (__any(di != R)) raw = R * exp(-0.1 * di);       // gamma_x; velocity channel == 0 (sensor.py:159)
+        if (i < S) {
+          double angle = -AUV_PI + (i + 1) * dangle;        // body-frame beam angle (vessel.py:66-68)
+          double weight = 1 / (1 + fabs(10.0 * angle));      // gamma_theta
+          num += weight * raw;
+          den += weight;
+        }
       }
       num = auv_wave_sum(num);
       den = auv_wave_sum(den);
