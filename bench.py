@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="polygons50", choices=["polygons50", "circles20", "moving28", "mixed47"])
     ap.add_argument("--graph", type=int, default=0, help="replay a captured hipGraph per step (1) or launch eagerly (0, default: eager launches pipeline deeper than one graph replay per step on this stack)")
+    ap.add_argument("--step-mode", default="side_by_side", choices=["side_by_side", "one_kernel", "two_streams"],
+                    help="how a step is launched (include/auv_hip.h, AUV_STEP_*)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
     ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
@@ -58,8 +60,8 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(bank, cfg_S, world_of_env):
-    """Per-launch algorithmic HBM bytes of each kernel ('Kernels'): sums over the
-    envs of one rank, fp64 layout."""
+    """Per-launch algorithmic HBM bytes of each kernel of the step: what the
+    implemented algorithm has to move, summed over the envs of one rank, fp64 layout."""
     P = np.diff(bank["poly_off"])[world_of_env].astype(np.float64)
     K = np.diff(bank["obs_off"])[world_of_env].astype(np.float64)
     meta = bank["obs_meta"]
@@ -69,10 +71,14 @@ def algorithmic_bytes(bank, cfg_S, world_of_env):
     np.add.at(nseg_world, w_of_obs[static], meta[static, 2])
     G = nseg_world[world_of_env]
     S = float(cfg_S)
-    k1 = 144.0 * len(world_of_env)
-    k2 = (32.0 * G + 24.0 * K + 16.0 * K + 24.0 + 16.0 * S + K).sum()
-    k3 = (16.0 * P + 8.0 * S + 8.0 * (6 + S) + 4.0 * (6 + S) + 400.0).sum()
-    return dict(k1_dynamics=k1, k2_lidar=float(k2), k3_nav_reward=float(k3))
+    n = len(world_of_env)
+    k1 = 144.0 * n
+    lidar = (32.0 * G + 24.0 * K + 16.0 * K + 24.0 + 16.0 * S + K).sum()        # SURVEY 8(d) formula, 32-B segments
+    nch = np.ceil((P - 1) / 64.0)
+    nav = (32.0 * nch + 3 * 65 * 16.0 + 600.0).sum()                            # chunk circles + ~3 surviving chunks + knots/scalars
+    reward = (8.0 * S + 8.0 * S + 4.0 * (6 + S) + 300.0) * n                    # d in, closeness in, obs f32 out, bookkeeping
+    return dict(k1_dynamics=k1, k23_lidar_nav=float(lidar + nav), k3_reward=float(reward),
+                lidar_part=float(lidar), nav_part=float(nav), nav_bruteforce=float((16.0 * P).sum()))
 
 
 def host_cores():
@@ -122,6 +128,7 @@ def main():
     torch.cuda.set_device(dev)
     from gym_auv_amd.batched_env import BatchedAuvEnv     # fails loudly without the HIP library
     env = BatchedAuvEnv(cfg, bank, n_local, device=dev, auto_reset=True)
+    env.set_step_mode(args.step_mode)
     S = env.n_sensors
 
     g = torch.Generator(device=dev)
@@ -169,13 +176,14 @@ def main():
     kms /= n_prof
     world_of_env = env.read("WORLD_IDX").cpu().numpy()
     alg = algorithmic_bytes(bank, S, world_of_env)
-    names = ["k1_dynamics", "k2_lidar", "k3_nav_reward"]
+    names = ["k1_dynamics", "k23_lidar_nav", "k3_reward"]
     per_kernel = {}
     for j, nm in enumerate(names):
         gbs = alg[nm] / (kms[j] * 1e-3) / 1e9 if kms[j] > 0 else 0.0
         per_kernel[nm] = dict(avg_ms=round(float(kms[j]), 5), algorithmic_bytes=int(alg[nm]),
                               achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
-    per_kernel["reset_pass"] = dict(avg_ms=round(float(kms[3]), 5))
+    per_kernel["k23_lidar_nav"].update(lidar_bytes=int(alg["lidar_part"]), nav_bytes=int(alg["nav_part"]),
+                                       nav_bruteforce_bytes=int(alg["nav_bruteforce"]))
     dom = max(names, key=lambda nm: per_kernel[nm]["avg_ms"])
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -192,7 +200,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
                            parallelism="env-shard x%d (no step-path collective)" % world,
-                           hipgraph=bool(args.graph), world_gen_s=round(t_gen, 1),
+                           hipgraph=bool(args.graph), step_mode=args.step_mode, world_gen_s=round(t_gen, 1),
                            episodes_finished=int(stats["episodes"].sum().item())),
                roofline=roofline)
 

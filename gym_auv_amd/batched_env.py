@@ -121,6 +121,12 @@ class BatchedAuvEnv:
     def _lazy_info(self):
         return _LazyInfo(self)
 
+    def set_step_mode(self, mode: str):
+        """"side_by_side" (default): K1 -> [K2 + K3-nav in one launch] -> K3-reward;
+        "one_kernel": the whole step in one kernel; "two_streams": K3-nav forked beside K2."""
+        _check(_LIB.auv_set_step_mode(self._h, {"side_by_side": 0, "one_kernel": 1, "two_streams": 2}[mode]),
+               "auv_set_step_mode")
+
     # per-kernel entry points (parity tests)
     def step_dynamics(self, actions: torch.Tensor):
         a, dt = self._act(actions)
@@ -158,7 +164,8 @@ class BatchedAuvEnv:
         return self.obs, self.reward, self.done, self._lazy_info()
 
     def step_timed(self, actions: torch.Tensor):
-        """One step with HIP events around each kernel; returns ms for (K1, K2, K3, reset pass)."""
+        """One step (default launch shape) with HIP events around each kernel; returns ms for
+        (K1, K2+K3-nav side by side, K3-reward, 0)."""
         a, dt = self._act(actions)
         ms = (C.c_float * 4)()
         _check(_LIB.auv_step_timed(self._h, C.c_void_p(a.data_ptr()), dt, C.c_void_p(self.obs.data_ptr()),

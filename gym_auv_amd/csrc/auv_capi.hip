@@ -21,8 +21,15 @@ void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st);
 void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st);
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, float* obs, hipStream_t st);
 void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
+void auv_launch_ring_advance(const AuvDev& d, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
 hipError_t auv_k2_prepare(const AuvDev& d);
+bool auv_step_fused_ok(const AuvDev& d);
+bool auv_k23_ok(const AuvDev& d);
+void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st);
+hipError_t auv_step_fused_prepare(const AuvDev& d);
+void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
+                           hipStream_t st);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
                    float* out_closeness, hipStream_t st);
 
@@ -53,6 +60,8 @@ struct auv_handle {
   hipEvent_t ev_fork, ev_join;
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
+  int step_mode;                 // AUV_STEP_* (include/auv_hip.h)
+  int32_t ring_host_pos;         // action-ring slot of the next eager fused step
   hipEvent_t ev[6];
 };
 
@@ -104,6 +113,8 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->graph = nullptr;
   h->graph_exec = nullptr;
   h->cap_stream = nullptr;
+  h->step_mode = AUV_STEP_SIDE_BY_SIDE;
+  h->ring_host_pos = 0;
   h->aux_stream = nullptr;
   h->ev_fork = h->ev_join = nullptr;
   for (auto& e : h->ev) e = nullptr;
@@ -245,6 +256,7 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   rc |= dev_alloc(ep, &d.stamps, n * 16);
   rc |= dev_alloc(ep, &d.ring_pos, 4);
   d.ring_slots = 1;
+  d.ring_slot_host = -1;
   rc |= dev_alloc(ep, &d.w_obs64, (size_t)W * (6 + S));
   rc |= dev_alloc(ep, &d.w_lidar, (size_t)W * S);
   rc |= dev_alloc(ep, &d.w_info, (size_t)W * 8);
@@ -257,6 +269,7 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   std::vector<int32_t> wi(n);
   if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
   HIP_TRY(auv_k2_prepare(d));
+  HIP_TRY(auv_step_fused_prepare(d));
   if ((size_t)AUV_ENVS_PER_BLOCK * d.nch_max * 4 > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);
@@ -305,8 +318,28 @@ int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx
 // stream (they are independent given the new state), joined before K3-reward.  Works the same
 // eagerly and under stream capture (the fork/join events become graph edges).
 static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, float* obs, float* reward, uint8_t* done,
-                        hipStream_t st) {
-  auv_launch_k1(h->d, actions, dtype, st);   // also empties the fresh list
+                        hipStream_t st, bool capturing) {
+  if (h->step_mode == AUV_STEP_ONE_KERNEL && auv_step_fused_ok(h->d)) {
+    // the whole step in one kernel (csrc/k_step_fused.hip).  Eagerly the host names the action
+    // ring slot; a captured graph cannot change arguments, so it reads the device-side position
+    // and advances it with a tiny follow-up node.
+    AuvDev d = h->d;
+    if (d.ring_slots > 1 && !capturing) {
+      d.ring_slot_host = h->ring_host_pos;
+      h->ring_host_pos = (h->ring_host_pos + 1) % d.ring_slots;
+    }
+    auv_launch_step_fused(d, actions, dtype, obs, reward, done, st);
+    if (d.ring_slots > 1 && capturing) auv_launch_ring_advance(h->d, st);
+    return AUV_OK;
+  }
+  if (h->step_mode != AUV_STEP_TWO_STREAMS && auv_k23_ok(h->d)) {
+    // default: K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward, one stream
+    auv_launch_k1(h->d, actions, dtype, st);
+    auv_launch_k23(h->d, obs, st);
+    auv_launch_k3_reward(h->d, obs, reward, done, st);
+    return AUV_OK;
+  }
+  auv_launch_k1(h->d, actions, dtype, st);
   HIP_TRY(hipEventRecord(h->ev_fork, st));
   HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
   auv_launch_k3_nav(h->d, obs, h->aux_stream);
@@ -322,7 +355,7 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
   REQUIRE_READY(h);
   if (!actions_dev) return fail(AUV_EINVAL, "auv_step: null actions");
   if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_step: bad action dtype");
-  int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
+  int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream, false);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return AUV_OK;
@@ -334,8 +367,20 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(h->d.ring_pos, 0, sizeof(int32_t)));
   h->d.ring_slots = n_slots;
+  h->ring_host_pos = 0;
   if (h->graph_exec) {   // a captured graph has the old value baked into its kernel arguments
     HIP_TRY(hipGraphExecDestroy(h->graph_exec));
+    h->graph_exec = nullptr;
+  }
+  return AUV_OK;
+}
+
+int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
+  if (!h) return fail(AUV_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
+  h->step_mode = mode;
+  if (h->graph_exec) {
+    (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;
   }
   return AUV_OK;
@@ -439,7 +484,7 @@ int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_d
     h->graph = nullptr;
   }
   HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-  int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream);
+  int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream, true);
   hipError_t ce = hipStreamEndCapture(h->cap_stream, &h->graph);
   if (rc) return rc;
   HIP_TRY(ce);
@@ -461,14 +506,21 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   hipStream_t st = (hipStream_t)stream;
   for (auto& e : h->ev)
     if (!e) HIP_TRY(hipEventCreate(&e));
+  // the kernels of the default (side-by-side) step, each bracketed by events on `st`:
+  // K1 | K2 + K3-nav in one launch | K3-reward
   HIP_TRY(hipEventRecord(h->ev[0], st));
   auv_launch_k1(h->d, actions_dev, action_dtype, st);
   HIP_TRY(hipEventRecord(h->ev[1], st));
-  auv_launch_k2(h->d, 1, st);
+  if (auv_k23_ok(h->d)) {
+    auv_launch_k23(h->d, obs_dev, st);
+  } else {
+    auv_launch_k2(h->d, 1, st);
+    auv_launch_k3_nav(h->d, obs_dev, st);
+  }
   HIP_TRY(hipEventRecord(h->ev[2], st));
-  auv_launch_k3(h->d, 0, obs_dev, reward_dev, done_dev, st);
+  auv_launch_k3_reward(h->d, obs_dev, reward_dev, done_dev, st);
   HIP_TRY(hipEventRecord(h->ev[3], st));
-  HIP_TRY(hipEventRecord(h->ev[4], st));   // (no separate reset pass any more: resets copy per-world rows)
+  HIP_TRY(hipEventRecord(h->ev[4], st));
   HIP_TRY(hipEventSynchronize(h->ev[4]));
   for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[i], h->ev[i + 1]));
   return AUV_OK;

@@ -72,7 +72,15 @@ struct AuvDev {
   int32_t w_ready;     // 0 while the rows are being computed
   int32_t* ring_pos;    // [1]  current slot of the action ring (advanced once per step by K3)
   int32_t ring_slots;   // 1 = plain action buffer
+  int32_t ring_slot_host; // >= 0: the host names the slot (single-kernel step); -1: read ring_pos
   unsigned long long* stamps;  // [N][16] per-env phase cycle counts (diagnostic builds, -DAUV_STAMPS)
+};
+
+// State handed from one phase to the next inside the single-kernel step (registers instead of
+// a global-memory round trip): the advanced vessel state and the env's counters.
+struct EnvPre {
+  double s[6];     // x, y, psi, u, v, r after Vessel.step
+  int4 cnt;        // t_step, vessel step counter (already incremented), episodes, -
 };
 
 // In-kernel phase stamps (diagnostic build only: make STAMPS=1).  The stamp values leave the

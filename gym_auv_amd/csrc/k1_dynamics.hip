@@ -46,13 +46,14 @@ __device__ __forceinline__ Vec6 state_dot(const Vec6& y, double tau_u, double ta
   return o;
 }
 
+// Vessel.step for environment e.  Every calling lane computes the same thing; `store` selects
+// who writes the new state / step counter back.  Returns them for the phases that follow in
+// the single-kernel step.
 template <typename AT>
-__global__ void __launch_bounds__(AUV_WAVE) k1_dynamics(AuvDev d, const AT* __restrict__ actions) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= d.n) return;
-  if (e == 0) *d.fresh_count = 0;   // the auto-reset list of this step starts empty (consumed after K3)
+__device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const AT* __restrict__ actions, const bool store) {
   const size_t n = (size_t)d.n;
-  if (d.ring_slots > 1) actions += (size_t)(*d.ring_pos) * 2 * n;   // action ring: slot of this step
+  if (d.ring_slots > 1)   // action ring: slot of this step
+    actions += (size_t)(d.ring_slot_host >= 0 ? d.ring_slot_host : *d.ring_pos) * 2 * n;
   double a0 = (double)actions[2 * (size_t)e], a1 = (double)actions[2 * (size_t)e + 1];
   if (isnan(a0) || isnan(a1)) a0 = a1 = 0.0;
   const double tu = auv_clip(a0, 0.0, 1.0) * d.cfg.thrust_max;
@@ -89,13 +90,31 @@ __global__ void __launch_bounds__(AUV_WAVE) k1_dynamics(AuvDev d, const AT* __re
     t.v[i] = y.v[i] + h * (16.0 * s1.v[i] / 135.0 + 6656.0 * s3.v[i] / 12825.0 +
                            28561.0 * s4.v[i] / 56430.0 - 9.0 * s5.v[i] / 50.0 + 2.0 * s6.v[i] / 55.0);
   t.v[2] = auv_princip(t.v[2]);
+  EnvPre pre;
+  pre.cnt = d.counters[e];
+  pre.cnt.y += 1;   // Vessel._step_counter (vessel.py:247)
 #pragma unroll
-  for (int i = 0; i < 6; i++) d.state[i * n + e] = t.v[i];
-  d.counters[e].y += 1;   // Vessel._step_counter (vessel.py:247)
+  for (int i = 0; i < 6; i++) pre.s[i] = t.v[i];
+  if (store) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) d.state[i * n + e] = t.v[i];
+    d.counters[e].y = pre.cnt.y;
+  }
+  return pre;
 }
+
+#ifndef AUV_DEVICE_FUNCS_ONLY
+template <typename AT>
+__global__ void __launch_bounds__(AUV_WAVE) k1_dynamics(AuvDev d, const AT* __restrict__ actions) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.n) return;
+  k1_env<AT>(d, e, actions, true);
+}
+#endif
 
 }  // namespace
 
+#ifndef AUV_DEVICE_FUNCS_ONLY
 void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st) {
   dim3 grid((d.n + AUV_WAVE - 1) / AUV_WAVE), block(AUV_WAVE);
   if (dtype == AUV_F64)
@@ -103,3 +122,4 @@ void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t 
   else
     hipLaunchKernelGGL(k1_dynamics<float>, grid, block, 0, st, d, (const float*)actions);
 }
+#endif

@@ -174,11 +174,13 @@ __device__ __forceinline__ void sweep_unstaged(const ObsLds& o, int tid, int nth
 }
 
 // phases A, C, B, S for one environment, by one wave
-__device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers) {
+__device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
+                        const EnvPre* pre = nullptr) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
-  const int4 cnt = d.counters[e];
-  const double px = d.state[0 * n + e], py = d.state[1 * n + e], psi = d.state[2 * n + e];
+  const int4 cnt = pre ? pre->cnt : d.counters[e];
+  const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
+               psi = pre ? pre->s[2] : d.state[2 * n + e];
   const int w = d.world_idx[e];
   const long long k0 = d.obs_off[w];
   const int K = (int)(d.obs_off[w + 1] - k0);
@@ -522,7 +524,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 }
 
 // phase E: outputs (vessel.py:88-95, :356-359)
-__device__ void k2_back(const AuvDev& d, const int e, const int lane, const Slice& L) {
+__device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L) {
   const int S = d.cfg.n_sensors;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   int col = 0;
@@ -546,8 +548,10 @@ __device__ void k2_back(const AuvDev& d, const int e, const int lane, const Slic
   }
   col = __any(col);
   if (lane == 0) d.collision[e] = (uint8_t)(col != 0);
+  return col != 0;
 }
 
+#ifndef AUV_DEVICE_FUNCS_ONLY
 // all environments: wave g handles env g
 __global__ void __launch_bounds__(AUV_BLOCK, 4) k2_lidar(AuvDev d, int advance_movers) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -592,8 +596,11 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
   }
 }
 
+#endif
+
 }  // namespace
 
+#ifndef AUV_DEVICE_FUNCS_ONLY
 size_t auv_k2_lds_bytes(const AuvDev& d) {
   return k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
 }
@@ -617,3 +624,4 @@ void auv_launch_k2_fresh(const AuvDev& d, hipStream_t st) {
   if (grid > AUV_FRESH_GRID) grid = AUV_FRESH_GRID;
   hipLaunchKernelGGL(k2_lidar_fresh, dim3(grid), dim3(AUV_BLOCK), auv_k2_lds_bytes(d), st, d);
 }
+#endif

@@ -125,13 +125,15 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
 
 // ---- navigation part (Vessel.navigate + the six navigation observations) ----------------------
 // Independent of the LiDAR sweep, so the step path runs it concurrently with K2.
-__device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* list, float* __restrict__ obs_out) {
+__device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* list, float* __restrict__ obs_out,
+                           const EnvPre* pre = nullptr) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const int w = d.world_idx[e];
   const double* ws = d.world_scalar + 8 * (size_t)w;
   const double L = ws[0];
-  const double px = d.state[0 * n + e], py = d.state[1 * n + e], psi = d.state[2 * n + e];
+  const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
+               psi = pre ? pre->s[2] : d.state[2 * n + e];
   double* inf = d.info64 + 8 * (size_t)e;
   double* nv = d.nav64 + 8 * (size_t)e;
   double* ob = d.obs64 + (size_t)e * (6 + S);
@@ -243,7 +245,8 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
     double gx = ws[1] - px, gy = ws[2] - py;
     double goal = sqrt(gx * gx + gy * gy);
     int reached = (goal <= d.cfg.min_goal_distance) || (progress >= d.cfg.min_path_progress);
-    double u = d.state[3 * n + e], v = d.state[4 * n + e], r = d.state[5 * n + e];
+    double u = pre ? pre->s[3] : d.state[3 * n + e], v = pre ? pre->s[4] : d.state[4 * n + e],
+           r = pre ? pre->s[5] : d.state[5 * n + e];
     nv[0] = u, nv[1] = v, nv[2] = r, nv[3] = la, nv[4] = he, nv[5] = cte / 100, nv[6] = chi, nv[7] = s_t;
     inf[1] = reached, inf[2] = goal, inf[3] = progress, inf[5] = maxp, inf[6] = s, inf[7] = 0.0;
     // environment.py:276-280; lane 0 also emits the float32 copies of its own six values
@@ -262,15 +265,15 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
 // full = false: only publish the collision flag and the float32 LiDAR observations (reset path)
 __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, const bool full,
                               float* __restrict__ obs_out, float* __restrict__ reward_out,
-                              uint8_t* __restrict__ done_out) {
+                              uint8_t* __restrict__ done_out, const EnvPre* pre = nullptr, const int collision_pre = -1) {
   const int S = d.cfg.n_sensors;
-  int4 cnt = d.counters[e];
+  int4 cnt = pre ? pre->cnt : d.counters[e];
   const int w = d.world_idx[e];
   double* inf = d.info64 + 8 * (size_t)e;
   const double* nv = d.nav64 + 8 * (size_t)e;
   const double* ob = d.obs64 + (size_t)e * (6 + S);
   const int D = 6 + (d.cfg.use_lidar ? S : 0);
-  const int collision = d.collision[e];
+  const int collision = collision_pre >= 0 ? collision_pre : d.collision[e];
   if (lane == 0) inf[0] = collision;
   if (full) {
     // ---- reward (rewarder.py) ----
@@ -345,7 +348,9 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
       }
       do_reset = done && d.cfg.auto_reset;
       if (!do_reset) d.counters[e] = cnt;
-      if (e == 0 && d.ring_slots > 1) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;   // next action slot
+      // next action slot (the single-kernel step advances the ring from the host or a follow-up node:
+      // other waves of that kernel may still be reading the position)
+      if (e == 0 && d.ring_slots > 1 && d.ring_slot_host < 0 && pre == nullptr) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
     }
     do_reset = __shfl(do_reset, 0, AUV_WAVE);
     if (do_reset) {
@@ -359,6 +364,7 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
     for (int i = 6 + lane; i < D; i += AUV_WAVE) obs_out[(size_t)e * D + i] = (float)ob[i];
 }
 
+#ifndef AUV_DEVICE_FUNCS_ONLY
 // mode 0: navigate + observe + reward + done (+ auto-reset bookkeeping)
 // mode 1: navigate + observe only (reset path)
 // mode 2: reward + done only, from the buffers as they stand (test hook)
@@ -436,8 +442,11 @@ __global__ void __launch_bounds__(AUV_BLOCK) k_harvest(AuvDev d, int count) {
   if (lane == 0) d.w_collision[w] = d.collision[e];
 }
 
+#endif
+
 }  // namespace
 
+#ifndef AUV_DEVICE_FUNCS_ONLY
 static size_t k3_lds_bytes(const AuvDev& d) { return (size_t)AUV_ENVS_PER_BLOCK * d.nch_max * sizeof(int); }
 static int env_grid(const AuvDev& d) { return (d.n + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK; }
 
@@ -462,6 +471,15 @@ void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world
   hipLaunchKernelGGL(k_reset, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, mask, world_idx, obs);
 }
 
+namespace {
+__global__ void k_ring_advance(AuvDev d) {
+  if (threadIdx.x == 0 && d.ring_slots > 1) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
+}
+}  // namespace
+
+void auv_launch_ring_advance(const AuvDev& d, hipStream_t st) { hipLaunchKernelGGL(k_ring_advance, dim3(1), dim3(64), 0, st, d); }
+
 void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st) {
   hipLaunchKernelGGL(k_harvest, dim3((count + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK), dim3(AUV_BLOCK), 0, st, d, count);
 }
+#endif

@@ -190,8 +190,17 @@ int auv_graph_launch(auv_handle_t* h, void* stream);
  * buffer.  Invalidates a captured graph.                                                    */
 int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 
-/* Mean duration (ms) of each kernel of the last auv_step_timed call, measured with HIP
- * events on `stream` around every launch: out_ms[0..3] = K1, K2, K3, reset-pass.           */
+/* How auv_step / auv_graph_capture run a step (same results, bit for bit):
+ *   AUV_STEP_SIDE_BY_SIDE (default)  K1 -> one launch whose workgroups do K2 for all envs and
+ *                                    K3-nav for all envs side by side -> K3-reward; one stream.
+ *   AUV_STEP_ONE_KERNEL              the whole step in one kernel, one wave per env running
+ *                                    K1 -> K3-nav -> K2 -> K3-reward back to back.
+ *   AUV_STEP_TWO_STREAMS             K1 -> { K2 || K3-nav on an auxiliary stream } -> K3-reward. */
+enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2 };
+int auv_set_step_mode(auv_handle_t* h, int32_t mode);
+
+/* One step in the default launch shape with HIP events on `stream` around every kernel:
+ * out_ms[0..3] = K1, [K2 + K3-nav side by side], K3-reward, 0.                               */
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                    float* reward_dev, uint8_t* done_dev, void* stream, float* out_ms4);
 

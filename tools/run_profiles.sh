@@ -11,6 +11,8 @@ cd $ROOT
 python bench.py --bank-cache /tmp/bank > $OUT/bench_polygons50.json 2> $OUT/bench_polygons50.err
 echo "headline: $(cut -c1-120 $OUT/bench_polygons50.json)"
 python bench.py --bank-cache /tmp/bank --graph 1 --cpu-baseline 0 > $OUT/bench_polygons50_graph.json 2>/dev/null
+python bench.py --bank-cache /tmp/bank --step-mode two_streams --cpu-baseline 0 > $OUT/bench_polygons50_two_streams.json 2>/dev/null
+python bench.py --bank-cache /tmp/bank --step-mode one_kernel --cpu-baseline 0 > $OUT/bench_polygons50_one_kernel.json 2>/dev/null
 python bench.py --bank-cache /tmp/bank --workload circles20 --cpu-baseline 0 > $OUT/bench_circles20.json 2>/dev/null
 python bench.py --bank-cache /tmp/bank --workload moving28 --cpu-baseline 0 > $OUT/bench_moving28.json 2>/dev/null
 python bench.py --bank-cache /tmp/bank --workload mixed47 --envs 8192 --cpu-baseline 0 > $OUT/bench_mixed47_8192.json 2>/dev/null
