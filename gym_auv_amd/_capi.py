@@ -41,7 +41,7 @@ class AuvConfig(C.Structure):
         ("max_timesteps", C.c_int32), ("n_sensors", C.c_int32),
         ("sensor_interval_load_obstacles", C.c_int32), ("use_lidar", C.c_int32),
         ("sensor_log_transform", C.c_int32), ("rewarder", C.c_int32), ("test_mode", C.c_int32),
-        ("cull_mode", C.c_int32), ("auto_reset", C.c_int32), ("reserved", C.c_int32),
+        ("cull_mode", C.c_int32), ("auto_reset", C.c_int32), ("obs_channels", C.c_int32),
     ]
 
 
@@ -63,9 +63,12 @@ class AuvWorldBank(C.Structure):
 def make_config(cfg: Config, rewarder: str = "colav", test_mode: bool = False,
                 cull: str = "reference", auto_reset: bool = False) -> AuvConfig:
     v, e, s = cfg.vessel, cfg.episode, cfg.simulation
-    if v.use_dict_observation or v.sensor_use_feasibility_pooling or v.sensor_use_velocity_observations:
-        raise NotImplementedError("dict observations / feasibility pooling / velocity observations are outside "
-                                  "the accelerated step() path (SURVEY 8(f))")
+    if v.sensor_use_feasibility_pooling:
+        raise NotImplementedError("feasibility pooling is not part of step() (its wiring is broken in the reference, "
+                                  "SURVEY 8(f) F3); use BatchedAuvEnv.feasibility_pooling() on the ranges")
+    if v.sensor_use_velocity_observations and not v.use_lidar:
+        raise ValueError("sensor_use_velocity_observations needs use_lidar (the reference raises on [].flatten(), "
+                         "environment.py:260,271-272)")
     return AuvConfig(
         dt=s.t_step_size, min_goal_distance=e.min_goal_distance, min_path_progress=e.min_path_progress,
         min_cumulative_reward=e.min_cumulative_reward, sensor_range=v.sensor_range,
@@ -75,7 +78,7 @@ def make_config(cfg: Config, rewarder: str = "colav", test_mode: bool = False,
         use_lidar=int(bool(v.use_lidar)), sensor_log_transform=int(bool(v.sensor_log_transform)),
         rewarder={"colav": AUV_REWARD_COLAV, "pathfollow": AUV_REWARD_PATHFOLLOW}[rewarder],
         test_mode=int(test_mode), cull_mode={"reference": AUV_CULL_REFERENCE, "exact": AUV_CULL_EXACT}[cull],
-        auto_reset=int(auto_reset), reserved=0)
+        auto_reset=int(auto_reset), obs_channels=3 if v.sensor_use_velocity_observations else 1)
 
 
 def make_bank_struct(bank: Dict[str, np.ndarray]) -> Tuple[AuvWorldBank, list]:

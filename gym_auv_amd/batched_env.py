@@ -44,7 +44,9 @@ class BatchedAuvEnv:
         self.device = torch.device(device)
         self.n_envs = int(n_envs)
         self.n_sensors = config.vessel.n_sensors
-        self.obs_dim = 6 + (self.n_sensors if config.vessel.use_lidar else 0)
+        # 6 navigation features + closeness per beam (+ 2 velocity channels the reference hard-wires
+        # to zero, sensor.py:159) -- config.py:80-98, environment.py:112-114, :263-280
+        self.obs_dim = 6 + (config.vessel.n_lidar_observations if config.vessel.use_lidar else 0)
         self._cfg_struct = make_config(config, rewarder=rewarder, test_mode=test_mode, cull=cull,
                                        auto_reset=auto_reset)
         if isinstance(worlds, dict):

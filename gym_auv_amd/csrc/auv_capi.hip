@@ -100,6 +100,7 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   if (!cfg || !out || n_envs <= 0) return fail(AUV_EINVAL, "auv_create: bad arguments");
   if (cfg->n_sensors < 0 || cfg->n_sensors > 4096) return fail(AUV_EINVAL, "n_sensors out of range");
   if (cfg->sensor_interval_load_obstacles <= 0) return fail(AUV_EINVAL, "sensor_interval_load_obstacles <= 0");
+  if (cfg->obs_channels != 1 && cfg->obs_channels != 3) return fail(AUV_EINVAL, "obs_channels must be 1 or 3");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device_id < 0 || device_id >= ndev) return fail(AUV_EINVAL, "device %d not present (%d visible)", device_id, ndev);

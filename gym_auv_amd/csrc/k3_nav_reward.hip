@@ -85,7 +85,8 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const double* ws2 = d.world_scalar + 8 * (size_t)w2;
-  const int D = 6 + (d.cfg.use_lidar ? S : 0);
+  const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
+  const int DL = 6 + (d.cfg.use_lidar ? S : 0);                                        // columns this path writes
   if (lane == 0) {
     d.world_idx[e] = w2;
     d.state[0 * n + e] = ws2[3], d.state[1 * n + e] = ws2[4], d.state[2 * n + e] = ws2[5];
@@ -113,7 +114,7 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
   for (int i = lane; i < 6 + S; i += AUV_WAVE) {
     const double v = d.w_obs64[(size_t)w2 * (6 + S) + i];
     d.obs64[(size_t)e * (6 + S) + i] = v;
-    if (obs_out && i < D) obs_out[(size_t)e * D + i] = (float)v;
+    if (obs_out && i < DL) obs_out[(size_t)e * D + i] = (float)v;
   }
   if (lane < 8) d.info64[8 * (size_t)e + lane] = d.w_info[8 * (size_t)w2 + lane];
   else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = d.w_nav[8 * (size_t)w2 + lane - 8];
@@ -137,7 +138,7 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   double* inf = d.info64 + 8 * (size_t)e;
   double* nv = d.nav64 + 8 * (size_t)e;
   double* ob = d.obs64 + (size_t)e * (6 + S);
-  const int D = 6 + (d.cfg.use_lidar ? S : 0);
+  const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
 
   AUV_STAMP_DECL
   // ---- nearest point on the dense polyline (path.py:84-93), exact with chunk pruning ----
@@ -272,7 +273,8 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
   double* inf = d.info64 + 8 * (size_t)e;
   const double* nv = d.nav64 + 8 * (size_t)e;
   const double* ob = d.obs64 + (size_t)e * (6 + S);
-  const int D = 6 + (d.cfg.use_lidar ? S : 0);
+  const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
+  const int DL = 6 + (d.cfg.use_lidar ? S : 0);                                        // columns this path writes
   const int collision = collision_pre >= 0 ? collision_pre : d.collision[e];
   if (lane == 0) inf[0] = collision;
   if (full) {
@@ -361,7 +363,7 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
   }
   // ---- LiDAR part of the float32 observation row (closeness written in fp64 by K2) ----
   if (obs_out)
-    for (int i = 6 + lane; i < D; i += AUV_WAVE) obs_out[(size_t)e * D + i] = (float)ob[i];
+    for (int i = 6 + lane; i < DL; i += AUV_WAVE) obs_out[(size_t)e * D + i] = (float)ob[i];
 }
 
 #ifndef AUV_DEVICE_FUNCS_ONLY

@@ -59,10 +59,16 @@ class AuvEnv:
         self._cte = []
         self.rng = None
         self.seed()
-        S = env_config.vessel.n_sensors if env_config.vessel.use_lidar else 0
-        from .spaces import Box
+        v = env_config.vessel
+        n_obs = 6 + (v.n_lidar_observations if v.use_lidar else 0)         # environment.py:112-114
+        from .spaces import Box, Dict
         self._action_space = Box(low=np.array([-1, -0.15]), high=np.array([1, 0.15]), dtype=np.float32)
-        self._observation_space = Box(low=np.array([-1] * (6 + S)), high=np.array([1] * (6 + S)), dtype=np.float32)
+        if v.use_dict_observation:                                          # environment.py:116-137
+            self._observation_space = Dict({
+                "proprioceptive": Box(low=-1.0, high=1.0, shape=(6,), dtype=np.float32),
+                "lidar": Box(low=-1.0, high=1.0, shape=v.lidar_shape, dtype=np.float32)})
+        else:
+            self._observation_space = Box(low=np.array([-1] * n_obs), high=np.array([1] * n_obs), dtype=np.float32)
         self.reset()
 
     @property
@@ -107,9 +113,17 @@ class AuvEnv:
         self._env.reset()
         return self._obs()
 
-    def _obs(self) -> np.ndarray:
+    def _obs(self):
         # the reference returns float64 although the space says float32 (environment.py:276-280)
-        return self._env.read("OBS64")[0, :self._env.obs_dim].cpu().numpy()
+        v = self.config.vessel
+        S = v.n_sensors
+        row = self._env.read("OBS64")[0].cpu().numpy()
+        flat = np.concatenate([row[:6 + (S if v.use_lidar else 0)],
+                               np.zeros(2 * S if (v.use_lidar and v.sensor_use_velocity_observations) else 0)])
+        if not v.use_dict_observation:
+            return flat
+        # environment.py:281-288: closeness row stacked over the (zero) velocity rows
+        return {"proprioceptive": flat[:6], "lidar": flat[6:].reshape(v.lidar_shape)}
 
     def step(self, action):
         a = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, 2), device=self._env.device)

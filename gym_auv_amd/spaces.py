@@ -31,3 +31,21 @@ class Box:
     def to_gym(self):
         import gym.spaces  # optional
         return gym.spaces.Box(low=self.low, high=self.high, dtype=self.dtype.type)
+
+
+class Dict:
+    """gym.spaces.Dict stand-in: a mapping of named sub-spaces."""
+
+    def __init__(self, spaces):
+        self.spaces = dict(spaces)
+        self.shape = None
+        self.dtype = None
+
+    def __getitem__(self, k):
+        return self.spaces[k]
+
+    def keys(self):
+        return self.spaces.keys()
+
+    def contains(self, x):
+        return set(x) == set(self.spaces) and all(self.spaces[k].contains(np.asarray(v, dtype=self.spaces[k].dtype)) for k, v in x.items())

@@ -67,7 +67,8 @@ typedef struct auv_config {
   int32_t cull_mode;              /* AUV_CULL_*                                        */
   int32_t auto_reset;             /* VecEnv semantics: a done env restarts on its next
                                      world of the bank inside the same step            */
-  int32_t reserved;
+  int32_t obs_channels;           /* 1: closeness only; 3: + two velocity channels, which the
+                                     reference hard-wires to zero (sensor.py:159, config.py:80-91) */
 } auv_config_t;
 
 /* World bank: W pre-generated scenario instances in CSR form (host pointers; copied to HBM

@@ -69,3 +69,37 @@ def test_seed_reproduces_world_and_rollout():
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2]
+
+
+def test_velocity_channels_and_dict_observation():
+    """sensor_use_velocity_observations appends 2*S zeros (the reference's velocity channel is
+    hard-wired to (0, 0), sensor.py:159); use_dict_observation splits the same data
+    (environment.py:116-137, :281-288).  Mirrors the intent of the reference's tests/test_config.py."""
+    import torch
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    from gym_auv_amd.env import AuvEnv
+    from gym_auv_amd.scenarios import moving_obstacles_world
+    from gym_auv_amd.world import build_world, pack_bank
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.sensor_use_velocity_observations = True
+    S = cfg.vessel.n_sensors
+    assert cfg.vessel.n_lidar_observations == 3 * S
+    bank = pack_bank([build_world(moving_obstacles_world(3))])
+    env = BatchedAuvEnv(cfg, bank, 5, device="cuda:0")
+    plain_cfg = effective_reference_config(use_lidar=True)
+    plain = BatchedAuvEnv(plain_cfg, bank, 5, device="cuda:0")
+    o, p = env.reset(), plain.reset()
+    assert o.shape == (5, 6 + 3 * S) and env.observation_space.shape == (6 + 3 * S,)
+    a = torch.rand((5, 2), device="cuda:0")
+    for _ in range(4):
+        o, r, d, _ = env.step(a)
+        p, r2, d2, _ = plain.step(a)
+        assert torch.equal(o[:, :6 + S], p) and torch.equal(r, r2)
+        assert (o[:, 6 + S:] == 0).all()
+    cfg.vessel.use_dict_observation = True
+    e = AuvEnv(cfg)
+    ob = e.reset()
+    assert set(ob) == {"proprioceptive", "lidar"} and ob["proprioceptive"].shape == (6,) and ob["lidar"].shape == (3, S)
+    ob, rew, done, info = e.step([0.5, 0.6])
+    assert (ob["lidar"][1:] == 0).all() and e.observation_space.contains(ob)
+    e.close()
