@@ -214,32 +214,34 @@ def main():
 
 
 def cpu_baseline(cfg, bank, n_local):
-    """The CPU oracle (C port of the reference algorithm, fp64, -O2) on this box's host cores,
-    on a bounded sample of the same workload: the first 256 envs/worlds for 40 steps on all
-    cores (OpenMP over envs) and 10 steps on 1 thread."""
+    """The CPU oracle (C port of the reference algorithm, fp64, -O2) on this box's host cores, on
+    a bounded sample of the same workload (~10 s of CPU work): the first 1024 envs/worlds for 2500
+    steps on all usable cores (OpenMP over envs), then 100 steps on 1 thread."""
     from gym_auv_amd._capi import make_config
     from oracle import pyoracle
-    n = min(256, n_local)
+    n = min(1024, n_local)
     ora = pyoracle.Oracle(make_config(cfg, auto_reset=True), n, bank)
     rs = np.random.RandomState(0)
     acts = rs.uniform([-1, -0.15], [1, 0.15], (8, n, 2))
     cores = pyoracle.set_threads(host_cores())
     ora.reset()
-    ora.step(acts[0])
-    steps = 40
+    for i in range(20):
+        ora.step(acts[i % 8])
+    steps = 2500
     t0 = time.perf_counter()
     for i in range(steps):
         ora.step(acts[i % 8])
     dt_all = time.perf_counter() - t0
     pyoracle.set_threads(1)
     t0 = time.perf_counter()
-    for i in range(10):
+    for i in range(100):
         ora.step(acts[i % 8])
     dt_one = time.perf_counter() - t0
     pyoracle.set_threads(cores)
     return dict(value=round(n * steps / dt_all, 1), unit="env-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d steps of the same workload (OpenMP over envs, %d threads)" % (n, steps, cores),
-                value_1thread=round(n * 10 / dt_one, 1))
+                sample="%d envs x %d steps of the same workload (OpenMP over envs, %d threads, %.1f s); "
+                       "1 thread: %d envs x 100 steps (%.1f s)" % (n, steps, cores, dt_all, n, dt_one),
+                value_1thread=round(n * 100 / dt_one, 1))
 
 
 if __name__ == "__main__":
