@@ -187,6 +187,21 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   d.m_max = m_max;
   int rc = 0;
   auto& bp = h->bank_allocs;
+  {
+    std::vector<int32_t> c_poly(W), c_knot(W), c_obs(W), c_mv(W), c_vt((size_t)(nM > 0 ? nM : 1));
+    for (int w = 0; w < W; w++) {
+      c_poly[w] = (int32_t)(b->poly_off[w + 1] - b->poly_off[w]);
+      c_knot[w] = (int32_t)(b->knot_off[w + 1] - b->knot_off[w]);
+      c_obs[w] = (int32_t)(b->obs_off[w + 1] - b->obs_off[w]);
+      c_mv[w] = (int32_t)(b->mv_off[w + 1] - b->mv_off[w]);
+    }
+    for (int64_t m = 0; m < nM; m++) c_vt[m] = (int32_t)(b->mv_vtab_off[m + 1] - b->mv_vtab_off[m]);
+    rc |= dev_upload(bp, &d.poly_cnt, c_poly.data(), (size_t)W);
+    rc |= dev_upload(bp, &d.knot_cnt, c_knot.data(), (size_t)W);
+    rc |= dev_upload(bp, &d.obs_cnt, c_obs.data(), (size_t)W);
+    rc |= dev_upload(bp, &d.mv_cnt, c_mv.data(), (size_t)W);
+    rc |= dev_upload(bp, &d.mv_vtab_len, c_vt.data(), c_vt.size());
+  }
   rc |= dev_upload(bp, &d.poly_off, b->poly_off, (size_t)W + 1);
   rc |= dev_upload(bp, &d.poly_xy, b->poly_xy, (size_t)nP);
   rc |= dev_upload(bp, &d.poly_cum, b->poly_cum, (size_t)nP);
@@ -194,12 +209,14 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
     // derived data: bounding circle of every run of AUV_CHUNK polyline segments (K3's exact
     // pruning).  Radius inflated so that rounding can never exclude a chunk that matters.
     std::vector<int64_t> coff((size_t)W + 1, 0);
+    std::vector<int32_t> ccnt((size_t)W, 0);
     std::vector<double> cbound;
     int nch_max = 1;
     for (int w = 0; w < W; w++) {
       const int64_t p0 = b->poly_off[w], P = b->poly_off[w + 1] - p0;
       const int64_t nch = (P - 1 + AUV_CHUNK - 1) / AUV_CHUNK;
       coff[w + 1] = coff[w] + nch;
+      ccnt[w] = (int32_t)nch;
       if (nch > nch_max) nch_max = (int)nch;
       for (int64_t c = 0; c < nch; c++) {
         const int64_t v0 = c * AUV_CHUNK, v1 = (v0 + AUV_CHUNK < P - 1 ? v0 + AUV_CHUNK : P - 1);
@@ -221,6 +238,7 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
     }
     d.nch_max = nch_max;
     rc |= dev_upload(bp, &d.chunk_off, coff.data(), (size_t)W + 1);
+    rc |= dev_upload(bp, &d.chunk_cnt, ccnt.data(), (size_t)W);
     rc |= dev_upload(bp, &d.chunk_bound, cbound.data(), cbound.size() / 4);
   }
   rc |= dev_upload(bp, &d.knot_off, b->knot_off, (size_t)W + 1);

@@ -23,7 +23,15 @@ struct AuvDev {
   int32_t n;        // environments
   int32_t n_worlds;
   int32_t k_max, m_max;
-  // ---- world bank (HBM, read-only during step) ----
+  // ---- world bank (HBM, read-only during step).  Every table is addressed by a start offset
+  // and a count per world, so the same kernels serve a packed CSR upload (auv_load_worlds) and
+  // the fixed-capacity slots that on-device generation fills (auv_generate_worlds) ----
+  const int32_t* poly_cnt;     // [W] vertices of the dense polyline
+  const int32_t* chunk_cnt;    // [W] bounding-circle chunks
+  const int32_t* knot_cnt;     // [W] PCHIP knots
+  const int32_t* obs_cnt;      // [W] obstacles
+  const int32_t* mv_cnt;       // [W] movers
+  const int32_t* mv_vtab_len;  // [sum M] velocity-table entries per mover
   const int64_t* poly_off;
   const double2* poly_xy;
   const double* poly_cum;

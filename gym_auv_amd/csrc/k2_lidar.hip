@@ -183,9 +183,9 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
                psi = pre ? pre->s[2] : d.state[2 * n + e];
   const int w = d.world_idx[e];
   const long long k0 = d.obs_off[w];
-  const int K = (int)(d.obs_off[w + 1] - k0);
+  const int K = d.obs_cnt[w];
   const long long m0 = d.mv_off[w];
-  const int M = (int)(d.mv_off[w + 1] - m0);
+  const int M = d.mv_cnt[w];
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   const double dangle = 2 * AUV_PI / S;
   if (lane == 0) {
@@ -200,7 +200,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     if (advance_movers) {
       const double dt = d.cfg.dt;
       const long long voff = d.mv_vtab_off[m0 + m];
-      const int vlen = (int)(d.mv_vtab_off[m0 + m + 1] - voff);
+      const int vlen = d.mv_vtab_len[m0 + m];
       st.w += dt;
       int idx = (int)floor(st.w);
       if (idx >= (int)par_m.w - 1) {

@@ -53,7 +53,7 @@ __device__ __forceinline__ MinIdx wave_min_first(MinIdx v) {
 // SciPy PPoly: interval search (knots are near-uniform: guess then walk) + power-basis eval
 __device__ __forceinline__ void path_eval(const AuvDev& d, int w, double s, double L, double xy[2], double dxy[2]) {
   const long long k0 = d.knot_off[w];
-  const int nk = (int)(d.knot_off[w + 1] - k0);
+  const int nk = d.knot_cnt[w];
   const double* x = d.knot_s + k0;
   int i;
   if (!(s >= x[0])) {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
     }
   }
   const long long m0 = d.mv_off[w2];
-  const int M = (int)(d.mv_off[w2 + 1] - m0);
+  const int M = d.mv_cnt[w2];
   for (int m = lane; m < M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = d.mv_init[m0 + m];
   if (!d.w_ready) {
     for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
@@ -143,10 +143,10 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   AUV_STAMP_DECL
   // ---- nearest point on the dense polyline (path.py:84-93), exact with chunk pruning ----
   const long long p0 = d.poly_off[w];
-  const int P = (int)(d.poly_off[w + 1] - p0);
+  const int P = d.poly_cnt[w];
   const double2* xy = d.poly_xy + p0;
   const long long c0 = d.chunk_off[w];
-  const int nch = (int)(d.chunk_off[w + 1] - c0);
+  const int nch = d.chunk_cnt[w];
   const double4* cb = d.chunk_bound + c0;
   // up to 4 chunks per lane stay in registers (paths up to 16 k vertices); their loads are
   // issued together.  Longer paths take the generic two-pass route below.
