@@ -142,6 +142,9 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_set_action_ring": (C.c_int, [vp, i32]),
         "auv_set_step_mode": (C.c_int, [vp, i32]),
         "auv_feasibility_pooling": (C.c_int, [vp, vp, i32, C.c_double, vp, vp, vp]),
+        "auv_generate_worlds": (C.c_int, [vp, i32, i32, i32, vp, i32, vp, vp, i32]),
+        "auv_bank_bytes": (sz, [vp, i32]),
+        "auv_read_bank": (C.c_int, [vp, i32, vp, sz, vp]),
         "auv_abi_version": (i32, []),
         "auv_last_error": (C.c_char_p, []),
     }
@@ -161,4 +164,17 @@ EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset",
                     "auv_step_dynamics", "auv_lidar", "auv_nav_reward", "auv_read", "auv_write",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",
+                    "auv_generate_worlds", "auv_bank_bytes", "auv_read_bank",
                     "auv_abi_version", "auv_last_error"]
+
+# tables of a generated bank (auv_read_bank): id, dtype, trailing shape ('P' = AUV_GEN_POLY_CAP,
+# 'K' / 'M' / 'G' = obstacles / movers / segment slots per world)
+GEN_POLY_CAP = 16384
+GEN_CAND = 8
+BANK_TABLES = {
+    "POLY_CNT": (0, np.int32, ()), "POLY_XY": (1, np.float64, ("P", 2)), "POLY_CUM": (2, np.float64, ("P",)),
+    "KNOT_S": (3, np.float64, (1000,)), "KNOT_COEF": (4, np.float64, (1000, 8)), "WORLD_SCALAR": (5, np.float64, (8,)),
+    "OBS_META": (6, np.int32, ("K", 4)), "OBS_CULL": (7, np.float64, ("K", 3)), "SEG": (8, np.float64, ("G", 4)),
+    "MV_PARAM": (9, np.float64, ("M", 4)), "MV_INIT": (10, np.float64, ("M", 4)), "MV_VTAB": (11, np.float64, ("M", 2)),
+    "CHUNK_BOUND": (12, np.float64, ("C", 4)),
+}

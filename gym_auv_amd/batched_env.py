@@ -19,6 +19,7 @@ import torch
 from . import _capi
 from ._capi import FIELD_DTYPES, FIELDS, AuvLibraryError, load_library, make_bank_struct, make_config
 from .config import Config
+from .devgen import GeneratedWorlds
 from .spaces import Box
 from .world import BuiltWorld, build_world, pack_bank
 from .worldspec import WorldSpec
@@ -49,19 +50,24 @@ class BatchedAuvEnv:
         self.obs_dim = 6 + (config.vessel.n_lidar_observations if config.vessel.use_lidar else 0)
         self._cfg_struct = make_config(config, rewarder=rewarder, test_mode=test_mode, cull=cull,
                                        auto_reset=auto_reset)
-        if isinstance(worlds, dict):
-            bank = worlds
-        else:
-            bank = pack_bank([w if isinstance(w, BuiltWorld) else build_world(w) for w in worlds])
-        self.n_worlds = int(bank["n_worlds"])
-        self.k_max = max(1, int(bank["k_max"]))
-        self.m_max = max(1, int(bank["m_max"]))
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _check(_LIB.auv_create(C.byref(self._cfg_struct), self.n_envs, idx, C.byref(self._h)), "auv_create")
-        bs, keep = make_bank_struct(bank)
-        _check(_LIB.auv_load_worlds(self._h, C.byref(bs)), "auv_load_worlds")
-        del keep
+        self._gen = None
+        if isinstance(worlds, GeneratedWorlds):
+            # worlds built on the device from random draws (devgen.py); no host-side bank at all
+            self.generate(worlds)
+        else:
+            if isinstance(worlds, dict):
+                bank = worlds
+            else:
+                bank = pack_bank([w if isinstance(w, BuiltWorld) else build_world(w) for w in worlds])
+            self.n_worlds = int(bank["n_worlds"])
+            self.k_max = max(1, int(bank["k_max"]))
+            self.m_max = max(1, int(bank["m_max"]))
+            bs, keep = make_bank_struct(bank)
+            _check(_LIB.auv_load_worlds(self._h, C.byref(bs)), "auv_load_worlds")
+            del keep
         # observation_space / action_space exactly as environment.py:101-106, :139-143
         self.action_space = Box(low=np.array([-1, -0.15]), high=np.array([1, 0.15]), dtype=np.float32)
         self.observation_space = Box(low=np.array([-1] * self.obs_dim), high=np.array([1] * self.obs_dim),
@@ -191,6 +197,44 @@ class BatchedAuvEnv:
                                             float(width), C.c_void_p(dist.data_ptr()), C.c_void_p(clos.data_ptr()),
                                             self._stream()), "auv_feasibility_pooling")
         return dist, clos
+
+    # ------------------------------------------------------------------------------ on-device worlds
+    def generate(self, spec: "GeneratedWorlds", draws: Optional[torch.Tensor] = None):
+        """(Re)build the whole world bank on the device (auv_generate_worlds) and reset every
+        environment.  `draws` overrides the spec's seeded draws ([W, n_draws] float64, device)."""
+        from . import devgen
+        if draws is None:
+            draws = devgen.sample_draws(spec.n_worlds, spec.n_moving, spec.n_static, seed=spec.seed, device=self.device)
+        draws = draws.to(device=self.device, dtype=torch.float64).contiguous()
+        nd = devgen.n_draws(spec.n_moving, spec.n_static)
+        if tuple(draws.shape) != (spec.n_worlds, nd):
+            raise ValueError("draws must have shape (%d, %d), got %s" % (spec.n_worlds, nd, tuple(draws.shape)))
+        unit, nseg = devgen.ring_tables()
+        unit = np.ascontiguousarray(unit, dtype=np.float64)
+        nseg = np.ascontiguousarray(nseg, dtype=np.int32)
+        torch.cuda.current_stream(self.device).synchronize()
+        _check(_LIB.auv_generate_worlds(self._h, spec.n_worlds, spec.n_moving, spec.n_static,
+                                        C.c_void_p(draws.data_ptr()), nd, unit.ctypes.data_as(C.c_void_p),
+                                        nseg.ctypes.data_as(C.c_void_p), len(nseg)), "auv_generate_worlds")
+        self._gen = spec
+        self.n_worlds = spec.n_worlds
+        self.k_max = max(1, spec.n_moving + spec.n_static)
+        self.m_max = max(1, spec.n_moving)
+        self._graph_actions = None
+        return draws
+
+    def read_bank(self, name: str) -> torch.Tensor:
+        """A table of the generated bank, [W, ...] in slot layout (see _capi.BANK_TABLES)."""
+        if self._gen is None:
+            raise RuntimeError("read_bank: the bank was uploaded from the host, not generated")
+        tid, dtype, tail = _capi.BANK_TABLES[name]
+        dims = dict(P=_capi.GEN_POLY_CAP, K=self.k_max, M=self.m_max, G=64 * max(1, self._gen.n_static),
+                    C=_capi.GEN_POLY_CAP // 64)
+        shape = (self.n_worlds,) + tuple(dims.get(x, x) for x in tail)
+        t = torch.empty(shape, dtype=_TORCH_DTYPES[dtype], device=self.device)
+        nbytes = t.numel() * t.element_size()
+        _check(_LIB.auv_read_bank(self._h, tid, C.c_void_p(t.data_ptr()), nbytes, self._stream()), "auv_read_bank(%s)" % name)
+        return t
 
     # ------------------------------------------------------------------------------ field access
     def field_shape(self, name: str):

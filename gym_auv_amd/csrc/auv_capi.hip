@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "auv_device.h"
+#include "auv_generate.h"
 
 void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st);
 void auv_launch_k2(const AuvDev& d, int advance_movers, hipStream_t st);
@@ -63,6 +64,9 @@ struct auv_handle {
   int step_mode;                 // AUV_STEP_* (include/auv_hip.h)
   int32_t ring_host_pos;         // action-ring slot of the next eager fused step
   hipEvent_t ev[6];
+  // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
+  int gen_worlds, gen_moving, gen_static, gen_grid;
+  GenOut gen;
 };
 
 template <typename T>
@@ -91,6 +95,80 @@ static void free_pool(std::vector<void*>& pool) {
   pool.clear();
 }
 
+// Second half of loading / generating a world bank: environment buffers sized for the bank,
+// the per-world reset rows, and the initial binding env e -> world e % W.
+static int finish_bank(auv_handle* h, bool alloc_env) {
+  AuvDev& d = h->d;
+  const int W = d.n_worlds, k_max = d.k_max, m_max = d.m_max;
+  const size_t n = (size_t)d.n, S = (size_t)d.cfg.n_sensors;
+  int rc = 0;
+  if (alloc_env) {
+  free_pool(h->env_allocs);
+  auto& ep = h->env_allocs;
+  rc |= dev_alloc(ep, &d.state, 6 * n);
+  rc |= dev_alloc(ep, &d.world_idx, n);
+  rc |= dev_alloc(ep, &d.counters, n);
+  rc |= dev_alloc(ep, &d.lidar_d, n * S);
+  rc |= dev_alloc(ep, &d.obs64, n * (6 + S));
+  rc |= dev_alloc(ep, &d.reward64, n);
+  rc |= dev_alloc(ep, &d.info64, n * 8);
+  rc |= dev_alloc(ep, &d.nav64, n * 8);
+  rc |= dev_alloc(ep, &d.mover, n * m_max);
+  rc |= dev_alloc(ep, &d.nearby, n * k_max);
+  rc |= dev_alloc(ep, &d.episode, n * 4);
+  rc |= dev_alloc(ep, &d.limits, n * k_max);
+  rc |= dev_alloc(ep, &d.collision, n);
+  rc |= dev_alloc(ep, &d.step_info, n * 4);
+  rc |= dev_alloc(ep, &d.fresh_count, 4);
+  rc |= dev_alloc(ep, &d.fresh_list, n);
+  rc |= dev_alloc(ep, &d.stamps, n * 16);
+  rc |= dev_alloc(ep, &d.ring_pos, 4);
+  d.ring_slots = 1;
+  d.ring_slot_host = -1;
+  rc |= dev_alloc(ep, &d.w_obs64, (size_t)W * (6 + S));
+  rc |= dev_alloc(ep, &d.w_lidar, (size_t)W * S);
+  rc |= dev_alloc(ep, &d.w_info, (size_t)W * 8);
+  rc |= dev_alloc(ep, &d.w_nav, (size_t)W * 8);
+  rc |= dev_alloc(ep, &d.w_nearby, (size_t)W * k_max);
+  rc |= dev_alloc(ep, &d.w_limits, (size_t)W * k_max);
+  rc |= dev_alloc(ep, &d.w_collision, (size_t)W);
+  if (rc) return AUV_EHIP;
+  }
+  d.w_ready = 0;
+  std::vector<int32_t> wi(n);
+  if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
+  HIP_TRY(auv_k2_prepare(d));
+  HIP_TRY(auv_step_fused_prepare(d));
+  if ((size_t)AUV_ENVS_PER_BLOCK * d.nch_max * 4 > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
+  if (h->graph_exec) {
+    (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+  }
+  // ---- reset rows: the first observation of every world (navigate + perceive at its initial
+  // pose) is a constant of the world; compute it once, N worlds at a time, with the step's own
+  // kernels (reset state -> K2 -> K3 on the fresh list), and keep the rows per world.
+  for (int w0 = 0; w0 < W; w0 += d.n) {
+    const int count = (W - w0 < d.n) ? (W - w0) : d.n;
+    for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(w0 + (int)(e % (size_t)count));
+    HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d.fresh_count, 0, sizeof(int32_t)));
+    auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);   // w_ready == 0: everything goes on the fresh list
+    auv_launch_k2_fresh(d, nullptr);
+    auv_launch_k3_fresh(d, nullptr, nullptr);
+    auv_launch_harvest(d, count, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  d.w_ready = 1;
+  // initial binding e -> world e % W, reset-time state (the first reset() call is then a copy)
+  for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(e % (size_t)W);
+  HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d.counters, 0, n * sizeof(int4)));
+  auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);
+  HIP_TRY(hipDeviceSynchronize());
+  h->worlds_loaded = true;
+  return AUV_OK;
+}
+
 extern "C" {
 
 int32_t auv_abi_version(void) { return AUV_ABI_VERSION; }
@@ -116,6 +194,7 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->cap_stream = nullptr;
   h->step_mode = AUV_STEP_SIDE_BY_SIDE;
   h->ring_host_pos = 0;
+  h->gen_worlds = 0;
   h->aux_stream = nullptr;
   h->ev_fork = h->ev_join = nullptr;
   for (auto& e : h->ev) e = nullptr;
@@ -152,10 +231,8 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   free_pool(h->bank_allocs);
-  free_pool(h->env_allocs);
   AuvDev& d = h->d;
   const int W = b->n_worlds;
-  const size_t n = (size_t)d.n, S = (size_t)d.cfg.n_sensors;
   // host-side validation of every offset the kernels will trust
   int k_max = 1, m_max = 1;
   const int64_t nP = b->poly_off[W], nK = b->knot_off[W], nO = b->obs_off[W], nM = b->mv_off[W];
@@ -255,68 +332,8 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   rc |= dev_upload(bp, &d.mv_vtab_off, b->mv_vtab_off, (size_t)nM + 1);
   rc |= dev_upload(bp, &d.mv_vtab, b->mv_vtab, (size_t)b->mv_vtab_off[nM]);
   if (rc) return AUV_EHIP;
-  auto& ep = h->env_allocs;
-  rc |= dev_alloc(ep, &d.state, 6 * n);
-  rc |= dev_alloc(ep, &d.world_idx, n);
-  rc |= dev_alloc(ep, &d.counters, n);
-  rc |= dev_alloc(ep, &d.lidar_d, n * S);
-  rc |= dev_alloc(ep, &d.obs64, n * (6 + S));
-  rc |= dev_alloc(ep, &d.reward64, n);
-  rc |= dev_alloc(ep, &d.info64, n * 8);
-  rc |= dev_alloc(ep, &d.nav64, n * 8);
-  rc |= dev_alloc(ep, &d.mover, n * m_max);
-  rc |= dev_alloc(ep, &d.nearby, n * k_max);
-  rc |= dev_alloc(ep, &d.episode, n * 4);
-  rc |= dev_alloc(ep, &d.limits, n * k_max);
-  rc |= dev_alloc(ep, &d.collision, n);
-  rc |= dev_alloc(ep, &d.step_info, n * 4);
-  rc |= dev_alloc(ep, &d.fresh_count, 4);
-  rc |= dev_alloc(ep, &d.fresh_list, n);
-  rc |= dev_alloc(ep, &d.stamps, n * 16);
-  rc |= dev_alloc(ep, &d.ring_pos, 4);
-  d.ring_slots = 1;
-  d.ring_slot_host = -1;
-  rc |= dev_alloc(ep, &d.w_obs64, (size_t)W * (6 + S));
-  rc |= dev_alloc(ep, &d.w_lidar, (size_t)W * S);
-  rc |= dev_alloc(ep, &d.w_info, (size_t)W * 8);
-  rc |= dev_alloc(ep, &d.w_nav, (size_t)W * 8);
-  rc |= dev_alloc(ep, &d.w_nearby, (size_t)W * k_max);
-  rc |= dev_alloc(ep, &d.w_limits, (size_t)W * k_max);
-  rc |= dev_alloc(ep, &d.w_collision, (size_t)W);
-  d.w_ready = 0;
-  if (rc) return AUV_EHIP;
-  std::vector<int32_t> wi(n);
-  if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
-  HIP_TRY(auv_k2_prepare(d));
-  HIP_TRY(auv_step_fused_prepare(d));
-  if ((size_t)AUV_ENVS_PER_BLOCK * d.nch_max * 4 > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
-  if (h->graph_exec) {
-    (void)hipGraphExecDestroy(h->graph_exec);
-    h->graph_exec = nullptr;
-  }
-  // ---- reset rows: the first observation of every world (navigate + perceive at its initial
-  // pose) is a constant of the world; compute it once, N worlds at a time, with the step's own
-  // kernels (reset state -> K2 -> K3 on the fresh list), and keep the rows per world.
-  for (int w0 = 0; w0 < W; w0 += d.n) {
-    const int count = (W - w0 < d.n) ? (W - w0) : d.n;
-    for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(w0 + (int)(e % (size_t)count));
-    HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(d.fresh_count, 0, sizeof(int32_t)));
-    auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);   // w_ready == 0: everything goes on the fresh list
-    auv_launch_k2_fresh(d, nullptr);
-    auv_launch_k3_fresh(d, nullptr, nullptr);
-    auv_launch_harvest(d, count, nullptr);
-    HIP_TRY(hipDeviceSynchronize());
-  }
-  d.w_ready = 1;
-  // initial binding e -> world e % W, reset-time state (the first reset() call is then a copy)
-  for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(e % (size_t)W);
-  HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(d.counters, 0, n * sizeof(int4)));
-  auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);
-  HIP_TRY(hipDeviceSynchronize());
-  h->worlds_loaded = true;
-  return AUV_OK;
+  h->gen_worlds = 0;
+  return finish_bank(h, true);
 }
 
 #define REQUIRE_READY(h)                                                          \
@@ -324,6 +341,138 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
     if (!(h)) return fail(AUV_EINVAL, "null handle");                             \
     if (!(h)->worlds_loaded) return fail(AUV_ESTATE, "auv_load_worlds not called"); \
   } while (0)
+
+int auv_generate_worlds(auv_handle_t* h, int32_t n_worlds, int32_t n_moving, int32_t n_static, const double* draws_dev,
+                        int32_t n_draws, const double* ring_unit, const int32_t* nseg_by_radius, int32_t n_radius) {
+  if (!h || n_worlds <= 0 || n_moving < 0 || n_static < 0 || !draws_dev)
+    return fail(AUV_EINVAL, "auv_generate_worlds: bad arguments");
+  if (n_moving + n_static > 256) return fail(AUV_EINVAL, "auv_generate_worlds: more than 256 obstacles per world");
+  const int expect = 11 + n_moving * (3 * GEN_CAND + 2) + n_static * 3 * GEN_CAND;
+  if (n_draws != expect) return fail(AUV_EINVAL, "auv_generate_worlds: %d draws per world, expected %d", n_draws, expect);
+  HIP_TRY(hipSetDevice(h->device));
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, draws_dev) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+    (void)hipGetLastError();
+    return fail(AUV_EINVAL, "auv_generate_worlds: draws must be device memory");
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  AuvDev& d = h->d;
+  GenOut& g = h->gen;
+  const int W = n_worlds, K = n_moving + n_static, M = n_moving;
+  const bool same_shape = h->gen_worlds == W && h->gen_moving == n_moving && h->gen_static == n_static;
+  if (!same_shape) {
+    if (!ring_unit || !nseg_by_radius || n_radius < 2) return fail(AUV_EINVAL, "auv_generate_worlds: ring tables missing");
+    for (int r = 0; r < n_radius; r++) {
+      const int ns = nseg_by_radius[r];
+      if (ns != 4 && ns != 8 && ns != 16 && ns != 32 && ns != 64) return fail(AUV_EINVAL, "nseg_by_radius[%d] = %d", r, ns);
+    }
+    h->worlds_loaded = false;
+    h->gen_worlds = 0;
+    free_pool(h->bank_allocs);
+    auto& bp = h->bank_allocs;
+    memset(&g, 0, sizeof(g));
+    g.p_cap = AUV_GEN_POLY_CAP;
+    g.g_cap = 64 * (n_static > 0 ? n_static : 1);
+    g.n_moving = n_moving, g.n_static = n_static, g.n_draws = n_draws, g.n_radius = n_radius;
+    g.dt = d.cfg.dt, g.vessel_width = d.cfg.vessel_width;
+    const size_t Wz = (size_t)W, Kz = (size_t)(K > 0 ? K : 1), Mz = (size_t)(M > 0 ? M : 1);
+    const size_t nch = (size_t)g.p_cap / AUV_CHUNK;
+    int rc = 0;
+    rc |= dev_alloc(bp, &g.poly_cnt, Wz);
+    rc |= dev_alloc(bp, &g.chunk_cnt, Wz);
+    rc |= dev_alloc(bp, &g.knot_cnt, Wz);
+    rc |= dev_alloc(bp, &g.obs_cnt, Wz);
+    rc |= dev_alloc(bp, &g.mv_cnt, Wz);
+    rc |= dev_alloc(bp, &g.mv_vtab_len, Wz * Mz);
+    rc |= dev_alloc(bp, &g.poly_xy, Wz * g.p_cap);
+    rc |= dev_alloc(bp, &g.poly_cum, Wz * g.p_cap);
+    rc |= dev_alloc(bp, &g.chunk_bound, Wz * nch);
+    rc |= dev_alloc(bp, &g.knot_s, Wz * GEN_NK);
+    rc |= dev_alloc(bp, &g.knot_coef, Wz * GEN_NK * 8);
+    rc |= dev_alloc(bp, &g.world_scalar, Wz * 8);
+    rc |= dev_alloc(bp, &g.obs_meta, Wz * Kz);
+    rc |= dev_alloc(bp, &g.obs_cull, Wz * Kz * 3);
+    rc |= dev_alloc(bp, &g.seg, Wz * g.g_cap);
+    rc |= dev_alloc(bp, &g.mv_param, Wz * Mz);
+    rc |= dev_alloc(bp, &g.mv_init, Wz * Mz);
+    rc |= dev_alloc(bp, &g.mv_vtab, Wz * Mz);
+    h->gen_grid = W < 1024 ? W : 1024;
+    rc |= dev_alloc(bp, &g.scratch, (size_t)h->gen_grid * auv_gen_scratch_doubles());
+    rc |= dev_upload(bp, &g.ring_unit, ring_unit, (size_t)65 * 2);
+    rc |= dev_upload(bp, &g.nseg_by_radius, nseg_by_radius, (size_t)n_radius);
+    // slot offsets: every world owns a fixed-capacity slice of each table
+    std::vector<int64_t> o_poly(Wz + 1), o_chunk(Wz + 1), o_knot(Wz + 1), o_obs(Wz + 1), o_mv(Wz + 1), o_vt(Wz * Mz + 1);
+    for (size_t w = 0; w <= Wz; w++) {
+      o_poly[w] = (int64_t)(w * g.p_cap), o_chunk[w] = (int64_t)(w * nch), o_knot[w] = (int64_t)(w * GEN_NK);
+      o_obs[w] = (int64_t)(w * K), o_mv[w] = (int64_t)(w * M);
+    }
+    for (size_t m = 0; m <= Wz * Mz; m++) o_vt[m] = (int64_t)m;
+    rc |= dev_upload(bp, &d.poly_off, o_poly.data(), Wz + 1);
+    rc |= dev_upload(bp, &d.chunk_off, o_chunk.data(), Wz + 1);
+    rc |= dev_upload(bp, &d.knot_off, o_knot.data(), Wz + 1);
+    rc |= dev_upload(bp, &d.obs_off, o_obs.data(), Wz + 1);
+    rc |= dev_upload(bp, &d.mv_off, o_mv.data(), Wz + 1);
+    rc |= dev_upload(bp, &d.mv_vtab_off, o_vt.data(), Wz * Mz + 1);
+    if (rc) return AUV_EHIP;
+    d.poly_cnt = g.poly_cnt, d.chunk_cnt = g.chunk_cnt, d.knot_cnt = g.knot_cnt, d.obs_cnt = g.obs_cnt;
+    d.mv_cnt = g.mv_cnt, d.mv_vtab_len = g.mv_vtab_len;
+    d.poly_xy = g.poly_xy, d.poly_cum = g.poly_cum, d.chunk_bound = g.chunk_bound;
+    d.knot_s = g.knot_s, d.knot_coef = g.knot_coef, d.world_scalar = g.world_scalar;
+    d.obs_meta = g.obs_meta, d.obs_cull = g.obs_cull, d.seg = g.seg;
+    d.mv_param = g.mv_param, d.mv_init = g.mv_init, d.mv_vtab = g.mv_vtab;
+    d.n_worlds = W;
+    d.k_max = K > 0 ? K : 1;
+    d.m_max = M > 0 ? M : 1;
+    d.nch_max = (int)nch;
+  }
+  auv_launch_generate(g, draws_dev, 0, W, h->gen_grid, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  int rc = finish_bank(h, !same_shape);
+  if (rc) return rc;
+  h->gen_worlds = W, h->gen_moving = n_moving, h->gen_static = n_static;
+  return AUV_OK;
+}
+
+static const void* bank_ptr(const auv_handle_t* h, int32_t table, size_t* bytes) {
+  const AuvDev& d = h->d;
+  // sizes are only known for a generated (slot) bank; a packed upload is already on the host
+  if (!h->gen_worlds) return nullptr;
+  const GenOut& g = h->gen;
+  const size_t W = (size_t)h->gen_worlds, K = (size_t)d.k_max, M = (size_t)d.m_max;
+  switch (table) {
+    case AUV_B_POLY_CNT: *bytes = W * 4; return d.poly_cnt;
+    case AUV_B_POLY_XY: *bytes = W * g.p_cap * 16; return d.poly_xy;
+    case AUV_B_POLY_CUM: *bytes = W * g.p_cap * 8; return d.poly_cum;
+    case AUV_B_KNOT_S: *bytes = W * GEN_NK * 8; return d.knot_s;
+    case AUV_B_KNOT_COEF: *bytes = W * GEN_NK * 64; return d.knot_coef;
+    case AUV_B_WORLD_SCALAR: *bytes = W * 64; return d.world_scalar;
+    case AUV_B_OBS_META: *bytes = W * K * 16; return d.obs_meta;
+    case AUV_B_OBS_CULL: *bytes = W * K * 24; return d.obs_cull;
+    case AUV_B_SEG: *bytes = W * g.g_cap * 32; return d.seg;
+    case AUV_B_MV_PARAM: *bytes = W * M * 32; return d.mv_param;
+    case AUV_B_MV_INIT: *bytes = W * M * 32; return d.mv_init;
+    case AUV_B_MV_VTAB: *bytes = W * M * 16; return d.mv_vtab;
+    case AUV_B_CHUNK_BOUND: *bytes = W * (g.p_cap / AUV_CHUNK) * 32; return d.chunk_bound;
+    default: return nullptr;
+  }
+}
+
+size_t auv_bank_bytes(const auv_handle_t* h, int32_t table) {
+  size_t bytes = 0;
+  if (!h || !h->worlds_loaded) return 0;
+  return bank_ptr(h, table, &bytes) ? bytes : 0;
+}
+
+int auv_read_bank(auv_handle_t* h, int32_t table, void* dst_dev, size_t bytes, void* stream) {
+  REQUIRE_READY(h);
+  size_t have = 0;
+  const void* p = bank_ptr(h, table, &have);
+  if (!p) return fail(AUV_EINVAL, "auv_read_bank: table %d not available (only generated banks can be read back)", table);
+  if (bytes != have) return fail(AUV_EINVAL, "auv_read_bank: table %d is %zu bytes, caller passed %zu", table, have, bytes);
+  HIP_TRY(hipMemcpyAsync(dst_dev, p, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return AUV_OK;
+}
 
 int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx_dev, float* obs_dev, void* stream) {
   REQUIRE_READY(h);

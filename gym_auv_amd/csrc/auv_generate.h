@@ -1,0 +1,34 @@
+// auv_generate.h -- arguments of the on-device scenario generator (k5_generate.hip), shared with
+// the C-ABI translation unit.
+#pragma once
+#include "auv_device.h"
+
+#define GEN_NK 1000          // resampled knots per PCHIP pass (path.py:29-31)
+#define GEN_CAND AUV_GEN_CAND   // candidate placements per obstacle (devgen.CAND)
+
+struct GenOut {              // writable views of the bank tables (fixed-capacity slots)
+  int32_t *poly_cnt, *chunk_cnt, *knot_cnt, *obs_cnt, *mv_cnt, *mv_vtab_len;
+  double2* poly_xy;
+  double* poly_cum;
+  double4* chunk_bound;
+  double* knot_s;
+  double* knot_coef;
+  double* world_scalar;
+  int4* obs_meta;
+  double* obs_cull;
+  double4* seg;
+  double4* mv_param;
+  double4* mv_init;
+  double2* mv_vtab;
+  // capacities / parameters
+  int32_t p_cap, g_cap, n_moving, n_static, n_draws, n_radius;
+  double dt, vessel_width;
+  const double* ring_unit;        // [65][2]
+  const int32_t* nseg_by_radius;  // [n_radius]
+  double* scratch;                // per workgroup: GEN_SCRATCH doubles
+};
+
+#define GEN_SCRATCH ((GEN_NK + GEN_NK * 8) + 4 * GEN_NK)
+
+size_t auv_gen_scratch_doubles(void);
+void auv_launch_generate(const GenOut& g, const double* draws, int w_first, int n_worlds, int grid, hipStream_t st);

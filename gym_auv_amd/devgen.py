@@ -1,0 +1,137 @@
+"""On-device scenario generation: MovingObstacles-type worlds are built on
+the GPU from device-resident random draws, straight into fixed-capacity world slots in HBM, so a
+fresh world per episode no longer needs the host.
+
+The algorithm is the reference's `MovingObstacles._generate`
+(/root/reference/gym_auv/envs/movingobstacles.py:28-95), `RandomCurveThroughOrigin` / `Path`
+(objects/path.py:19-40, :96-120: three PCHIP re-parameterisations + dense polyline) and
+`helpers.generate_obstacle` (utils/helpers.py:5-35), with one documented difference: the
+rejection loop of generate_obstacle draws from a pool of CAND pre-drawn candidates per obstacle
+(first accepted wins; if none is accepted the last one is taken) instead of looping unboundedly.
+
+`world_from_draws` is the host mirror consuming the SAME draws; tests compare the device-built
+tables with `build_world(world_from_draws(...))`.  Stream parity with NumPy's generators is a
+property of `scenarios.moving_obstacles_world`, not of this module (the draws come from the
+torch generator on the device).
+"""
+import functools
+import math
+from dataclasses import dataclass
+from typing import Tuple
+
+import numpy as np
+
+from .obstacles import QUADRANT_SEGMENTS, SIMPLIFY_TOLERANCE, circle_ring, douglas_peucker_keep
+from .path import Path
+from .scenarios import VESSEL_WIDTH, _linear_mover, _princip
+from .worldspec import WorldSpec
+
+CAND = 8                 # candidate placements per obstacle
+R_TABLE = 256            # circle radii are max(1, Poisson) integers; table of segment counts by radius
+
+
+@dataclass(frozen=True)
+class GeneratedWorlds:
+    """`worlds=` argument of BatchedAuvEnv asking for a bank built on the device: n_worlds
+    MovingObstacles-type scenarios (defaults of envs/movingobstacles.py:45-48: 17 movers, 11
+    circles) from the torch generator seeded with `seed` on the env's GPU."""
+    n_worlds: int
+    n_moving: int = 17
+    n_static: int = 11
+    seed: int = 0
+
+
+def n_draws(n_moving: int, n_static: int) -> int:
+    return 11 + n_moving * (3 * CAND + 2) + n_static * 3 * CAND
+
+
+def sample_draws(n_worlds: int, n_moving: int, n_static: int, seed: int = 0, device="cpu"):
+    """[W, ND] float64 draws: U[0,1) everywhere except the candidate triples (z ~ N(0,1), u, Poisson)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nd = n_draws(n_moving, n_static)
+    d = torch.rand((n_worlds, nd), generator=g, device=device, dtype=torch.float64)
+    col = 11
+    for mean, count, extra in ((10.0, n_moving, 2), (30.0, n_static, 0)):
+        for _ in range(count):
+            for _c in range(CAND):
+                d[:, col] = torch.randn((n_worlds,), generator=g, device=device, dtype=torch.float64)
+                d[:, col + 2] = torch.poisson(torch.full((n_worlds,), mean, device=device, dtype=torch.float64), generator=g)
+                col += 3
+            col += extra
+    assert col == nd
+    return d
+
+
+@functools.lru_cache(maxsize=1)
+def ring_tables() -> Tuple[np.ndarray, np.ndarray]:
+    """(unit ring [65, 2] = cos/sin of GEOS's accumulated vertex angles, nseg_by_radius [R_TABLE])
+    -- the Douglas-Peucker outcome on a circle is a uniform power-of-two subsample (checked here
+    for every integer radius), so a radius -> segment-count table reproduces the host builder."""
+    unit = circle_ring(0.0, 0.0, 1.0)
+    nseg = np.zeros(R_TABLE, dtype=np.int32)
+    for r in range(1, R_TABLE):
+        keep = douglas_peucker_keep(circle_ring(0.0, 0.0, float(r)), SIMPLIFY_TOLERANCE)
+        n = len(keep) - 1
+        stride = (4 * QUADRANT_SEGMENTS) // n
+        assert n in (4, 8, 16, 32, 64) and np.array_equal(keep, np.arange(0, 4 * QUADRANT_SEGMENTS + 1, stride)), r
+        nseg[r] = n
+    nseg[0] = nseg[1]
+    return unit, nseg
+
+
+def _place(row, base, path: Path, pose, width, sigma):
+    goal = path(path.length)
+    c, s = math.cos(-pose[2]), math.sin(-pose[2])
+    pos = radius = None
+    for k in range(CAND):
+        z, u, pois = row[base + 3 * k], row[base + 3 * k + 1], row[base + 3 * k + 2]
+        disp = sigma * z
+        arclen = (0.1 + 0.8 * u) * path.length
+        pos = path(arclen)
+        ang = _princip(path.get_direction(arclen) - np.pi / 2)
+        pos = pos + disp * np.array([np.cos(ang), np.sin(ang)])
+        radius = max(1.0, pois)
+        dx, dy = pos[0] - pose[0], pos[1] - pose[1]
+        vessel_dist = math.sqrt((c * dx - s * dy) ** 2 + (s * dx + c * dy) ** 2) - width - radius
+        goal_dist = math.sqrt((pos[0] - goal[0]) ** 2 + (pos[1] - goal[1]) ** 2) - radius
+        if min(vessel_dist, goal_dist) > 0:
+            break
+    return pos, radius
+
+
+def world_from_draws(row: np.ndarray, n_moving: int = 17, n_static: int = 11, dt: float = 0.5,
+                     vessel_width: float = VESSEL_WIDTH) -> WorldSpec:
+    """Host mirror of the device generator for one row of draws."""
+    row = np.asarray(row, dtype=np.float64)
+    nwaypoints = int(np.floor(4 * row[0] + 2))
+    length = 800.0
+    theta0 = 2 * np.pi * (row[1] - 0.5)
+    start = 0.5 * length * np.array([np.cos(theta0), np.sin(theta0)])
+    end = -start
+    half = nwaypoints // 2
+    head, tail = [], []
+    for k in range(half):
+        jit1 = length / (half + 1) * (row[2 + 2 * k] - 0.5)
+        jit2 = length / (half + 1) * (row[3 + 2 * k] - 0.5)
+        head.append((half - k) * start / (half + 1) + jit1)
+        tail.insert(0, (half - k) * end / (half + 1) + jit2)
+    path = Path(np.array([start] + head + [np.zeros(2)] + tail + [end]).T)
+    p0 = path(0)
+    pose = np.array([p0[0] + 50 * (row[8] - 0.5), p0[1] + 50 * (row[9] - 0.5),
+                     _princip(path.get_direction(0) + 2 * np.pi * (row[10] - 0.5))])
+    movers, circles = [], []
+    col = 11
+    for _ in range(n_moving):
+        pos, radius = _place(row, col, path, pose, vessel_width, 500.0)
+        direction = row[col + 3 * CAND] * 2 * np.pi
+        speed = 1.0 + (3.0 - 1.0) * row[col + 3 * CAND + 1]
+        movers.append(_linear_mover(pos, radius, direction, speed, dt))
+        col += 3 * CAND + 2
+    for _ in range(n_static):
+        pos, radius = _place(row, col, path, pose, vessel_width, 250.0)
+        circles.append([pos[0], pos[1], radius])
+        col += 3 * CAND
+    return WorldSpec(waypoints=path.init_waypoints, vessel_init=pose,
+                     circles=np.asarray(circles, dtype=np.float64).reshape(-1, 3), movers=movers, name="devgen")

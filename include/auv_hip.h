@@ -214,6 +214,50 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
 int auv_feasibility_pooling(auv_handle_t* h, const int32_t* sector_start_dev, int32_t n_sectors, double width,
                             double* out_dist_dev, float* out_closeness_dev, void* stream);
 
+/* On-device scenario generation: build n_worlds MovingObstacles-type worlds on
+ * the GPU, one workgroup per world, straight into fixed-capacity world slots, then compute their
+ * reset rows and reset every environment -- the device-side replacement of
+ * MovingObstacles._generate (envs/movingobstacles.py:28-95: RandomCurveThroughOrigin path with its
+ * three PCHIP passes, objects/path.py:19-40,96-120; vessel start; helpers.generate_obstacle
+ * placements, utils/helpers.py:5-35; VesselObstacle / CircularObstacle tables,
+ * objects/obstacles.py:90-113,144-215).  Replaces any previous bank, like auv_load_worlds.
+ *   draws_dev [n_worlds][n_draws] fp64 DEVICE memory, n_draws = 11 + n_moving*(3*C+2) + n_static*3*C
+ *   with C = AUV_GEN_CAND: row = u_nwaypoints, u_angle, 6 waypoint jitters, start ux, uy, upsi, then
+ *   per mover C x (z ~ N(0,1), u, Poisson(10)) + u_direction + u_speed, then per circle
+ *   C x (z, u, Poisson(30)); u ~ U[0,1).  The unbounded rejection loop of generate_obstacle is
+ *   a pool of C candidates (first accepted wins, else the last one).
+ *   ring_unit [65][2], nseg_by_radius [n_radius] HOST tables: unit ring of the GEOS point buffer
+ *   and the number of segments Douglas-Peucker(0.3) leaves for an integer radius (4..64, power
+ *   of two); needed on the first call of a given shape, ignored afterwards.
+ * A second call with the same (n_worlds, n_moving, n_static) regenerates in place without
+ * allocating.  Synchronous.                                                                   */
+#define AUV_GEN_CAND 8
+#define AUV_GEN_POLY_CAP 16384   /* polyline vertices per generated world slot (path <= 1638 m) */
+int auv_generate_worlds(auv_handle_t* h, int32_t n_worlds, int32_t n_moving, int32_t n_static,
+                        const double* draws_dev, int32_t n_draws, const double* ring_unit,
+                        const int32_t* nseg_by_radius, int32_t n_radius);
+
+/* Read a table of a GENERATED bank back (device-to-device copy; slot layout: world w owns
+ * [w*cap, (w+1)*cap) of each table, counts in AUV_B_POLY_CNT / OBS_META).  For tests and for
+ * checkpointing generated worlds.                                                              */
+enum {
+  AUV_B_POLY_CNT = 0,     /* [W] int32                      */
+  AUV_B_POLY_XY = 1,      /* [W][AUV_GEN_POLY_CAP][2]       */
+  AUV_B_POLY_CUM = 2,     /* [W][AUV_GEN_POLY_CAP]          */
+  AUV_B_KNOT_S = 3,       /* [W][1000]                      */
+  AUV_B_KNOT_COEF = 4,    /* [W][1000][8]                   */
+  AUV_B_WORLD_SCALAR = 5, /* [W][8]                         */
+  AUV_B_OBS_META = 6,     /* [W][K][4] int32                */
+  AUV_B_OBS_CULL = 7,     /* [W][K][3]                      */
+  AUV_B_SEG = 8,          /* [W][64*n_static][4]            */
+  AUV_B_MV_PARAM = 9,     /* [W][M][4]                      */
+  AUV_B_MV_INIT = 10,     /* [W][M][4]                      */
+  AUV_B_MV_VTAB = 11,     /* [W][M][2]                      */
+  AUV_B_CHUNK_BOUND = 12  /* [W][AUV_GEN_POLY_CAP/64][4]    */
+};
+size_t auv_bank_bytes(const auv_handle_t* h, int32_t table);
+int auv_read_bank(auv_handle_t* h, int32_t table, void* dst_dev, size_t bytes, void* stream);
+
 int32_t auv_abi_version(void);
 const char* auv_last_error(void);
 
