@@ -243,10 +243,13 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   if (!d.cfg.use_lidar) return 0;   // lidar_d stays at sensor_range from reset; collision stays 0
 
   // ---- phase C: ray vectors, vessel.py:66-68, :317 ------------------------------------
+  // cos / sin of (beam angle + psi) by the addition theorem from the per-config table of beam
+  // angles (built at load time): one sincos per environment instead of one per ray
+  double sin_psi, cos_psi;
+  sincos(psi, &sin_psi, &cos_psi);
   for (int i = lane; i < S; i += AUV_WAVE) {
-    double ang = (-AUV_PI + (i + 1) * dangle) + psi;
-    double s, c;
-    sincos(ang, &s, &c);
+    const double2 b = d.beam_cs[i];                       // cos, sin of -pi + (i + 1) * dangle
+    const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
     // end point minus origin, formed exactly as the reference forms the end point
     double ex = px + c * R, ey = py + s * R;
     L.rayv[i] = make_double2(ex - px, ey - py);
@@ -395,9 +398,17 @@ __device__ __forceinline__ int inside_flag_wave(double px, double py, SegPtr g, 
 
 // phases S + D for one environment, by one wave, in batches of <= K2_SEG_CAP boundary segments
 __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int lane, const int n_act,
-                                   const double psi) {
+                                   const double psi, unsigned long long* sub = nullptr) {
   const int S = d.cfg.n_sensors;
   const double px = L.hdr->px, py = L.hdr->py;
+#ifdef AUV_STAMPS
+  unsigned long long c_stage = 0, c_prefix = 0, c_items = 0, n_it = 0, c0;
+#define SUB_T0() c0 = clock64();
+#define SUB_ADD(x) { unsigned long long c1 = clock64(); x += c1 - c0; c0 = c1; }
+#else
+#define SUB_T0()
+#define SUB_ADD(x)
+#endif
   for (int a0 = 0; a0 < n_act;) {
     const int base0 = L.sbase[a0];
     if (L.sbase[a0 + 1] - base0 > K2_SEG_CAP) {
@@ -417,6 +428,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
     const int T = L.sbase[a1] - base0;
 
     // ---- phase S: one flattened, coalesced pass over the batch's boundary segments ----
+    SUB_T0()
     for (int t = lane; t < T; t += AUV_WAVE) {
       int a = a0;
       while (t + base0 >= L.sbase[a + 1]) a++;
@@ -466,12 +478,18 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
       }
     }
     auv_wave_lds_sync();
+    SUB_ADD(c_stage)
 
     // ---- phase D (i): obstacles containing p0 -> distance 0 on every ray of their window ----
-    for (int a = a0; a < a1; a++) {
-      const ObsLds o = L.obs[L.act[a]];
-      if (o.kind != AUV_OBS_RING && L.par[a] != 0)
+    for (int ab = a0; ab < a1; ab += AUV_WAVE) {            // lanes <-> obstacles of the batch
+      const int al = ab + lane;
+      unsigned long long in_mask = __ballot(al < a1 && L.par[al] != 0 && L.obs[L.act[al]].kind != AUV_OBS_RING);
+      while (in_mask) {                                      // (rare) whole wave per containing obstacle
+        const int a = ab + __ffsll((long long)in_mask) - 1;
+        in_mask &= in_mask - 1;
+        const ObsLds o = L.obs[L.act[a]];
         for (int q = lane; q < o.count; q += AUV_WAVE) atomicMin(&L.dbits[wrap_ray(o.start + q, S)], 0ull);
+      }
     }
     // ---- phase D (ii): work items = (staged segment, run of <= K2_ITEM_RAYS rays of its span),
     //      lanes <-> items, so a segment seen under a wide angle is shared by several lanes ----
@@ -495,6 +513,10 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
     }
     if (lane == 0) L.ioff[0] = 0;
     auv_wave_lds_sync();
+    SUB_ADD(c_prefix)
+#ifdef AUV_STAMPS
+    n_it += n_items;
+#endif
     for (int it = lane; it < n_items; it += AUV_WAVE) {
       int lo = 0, hi = T;                                  // largest t with ioff[t] <= it
       while (hi - lo > 1) {
@@ -510,17 +532,30 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
       const bool all = o.count >= S;
       const int start_w = wrap_ray(o.start, S);
       const int j0 = (it - (int)L.ioff[t]) * K2_ITEM_RAYS;
-      const int j1 = (j0 + K2_ITEM_RAYS < sp.y) ? j0 + K2_ITEM_RAYS : sp.y;
-      for (int j = j0; j < j1; j++) {
-        const int r = wrap_ray(sp.x + j, S);
+      // the item's rays are fetched together (independent LDS loads), then tested
+      double2 rv[K2_ITEM_RAYS];
+      int rr[K2_ITEM_RAYS];
+#pragma unroll
+      for (int jj = 0; jj < K2_ITEM_RAYS; jj++) {
+        int r = wrap_ray(sp.x + j0 + jj, S);
         int x = r - start_w;                                  // position of ray r inside the window
         if (x < 0) x += S;
-        if (all || x < o.count) test_pair(w, tn, L.rayv[r], &L.dbits[r]);
+        const bool ok = (j0 + jj < sp.y) && (all || x < o.count);
+        r = ok ? r : -1;
+        rr[jj] = r;
+        rv[jj] = L.rayv[r < 0 ? 0 : r];
       }
+#pragma unroll
+      for (int jj = 0; jj < K2_ITEM_RAYS; jj++)
+        if (rr[jj] >= 0) test_pair(w, tn, rv[jj], &L.dbits[rr[jj]]);
     }
     auv_wave_lds_sync();
+    SUB_ADD(c_items)
     a0 = a1;
   }
+#ifdef AUV_STAMPS
+  if (sub) sub[0] = c_stage, sub[1] = c_prefix, sub[2] = c_items, sub[3] = n_it;
+#endif
 }
 
 // phase E: outputs (vessel.py:88-95, :356-359)
@@ -541,8 +576,11 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
       di = sqrt(dx * dx + dy * dy);
     }
     d.lidar_d[(size_t)e * S + i] = di;
-    double cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0)
-                                           : 1 - auv_clip(di / R, 0.0, 1.0);
+    // a beam without a return sits exactly at R: closeness 1 - x/x = 0, so the logarithm is only
+    // evaluated in passes where some lane has a return
+    double cl = 0.0;
+    if (__any(t <= 1.0))
+      cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0) : 1 - auv_clip(di / R, 0.0, 1.0);
     d.obs64[(size_t)e * (6 + S) + 6 + i] = auv_clip(cl, -1.0, 1.0);
     col |= (di < W);
   }

@@ -9,6 +9,8 @@
 // tail of one environment's LiDAR sweep overlap the other phases of its neighbours.
 // The new state and counters are handed from phase to phase in registers (EnvPre), so no lane
 // re-reads global memory that another lane of the wave has just written.
+#include <cstdlib>
+
 #define AUV_DEVICE_FUNCS_ONLY
 #include "k1_dynamics.hip"
 #include "k2_lidar.hip"
@@ -47,23 +49,64 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
 // new vessel state, so they run side by side (the LiDAR workgroups are dispatched first and fill
 // the chip; navigation workgroups move in as those retire) -- the concurrency of two streams
 // without the ~8 us a cross-stream event wait costs on each side.
-__global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* __restrict__ obs_out) {
+template <bool PAIRED>
+__global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* __restrict__ obs_out,
+                                                              float* __restrict__ reward_out,
+                                                              uint8_t* __restrict__ done_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int S = d.cfg.n_sensors;
-  const int nb = (d.n + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK;
+  const int epb = blockDim.x / AUV_WAVE;                            // environments (waves) per workgroup
+  const int nb = (d.n + epb - 1) / epb;
   const bool nav_role = (int)blockIdx.x >= nb;                      // workgroup-uniform
-  const int e = ((int)blockIdx.x - (nav_role ? nb : 0)) * AUV_ENVS_PER_BLOCK + wave;
+  const int e = ((int)blockIdx.x - (nav_role ? nb : 0)) * epb + wave;
   if (e >= d.n) return;
   unsigned char* slice = smem + wave * k2_slice_bytes(S, d.k_max, d.m_max);
   if (nav_role) {
+#ifdef AUV_STAMPS
+    const unsigned long long t_nav0 = wall_clock64();
+#endif
     k3_nav_env(d, e, lane, (int*)slice, obs_out);
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 12] = t_nav0, d.stamps[(size_t)e * 16 + 13] = wall_clock64();
+#endif
   } else {
     const Slice L = carve(slice, S, d.k_max, d.m_max);
+    AUV_STAMP_DECL
+#ifdef AUV_STAMPS
+    const unsigned long long t_real0 = wall_clock64();
+#endif
     const int n_act = k2_front(d, e, lane, L, 1);
     if (d.cfg.use_lidar) {
+      AUV_STAMP()
+#ifdef AUV_STAMPS
+      unsigned long long sub[4] = {0, 0, 0, 0};
+      k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e], sub);
+      if (lane == 0) d.stamps[(size_t)e * 16 + 7] = sub[0], d.stamps[(size_t)e * 16 + 14] = sub[1], d.stamps[(size_t)e * 16 + 15] = sub[2], d.stamps[(size_t)e * 16 + 6] = sub[3];
+#else
       k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
+#endif
+      AUV_STAMP()
       k2_back(d, e, lane, L);
+      AUV_STAMP()
+      AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
+#ifdef AUV_STAMPS
+      if (lane == 0) d.stamps[(size_t)e * 16 + 3] = t_real0, d.stamps[(size_t)e * 16 + 4] = wall_clock64();
+      if (lane == 0) d.stamps[(size_t)e * 16 + 5] = (unsigned long long)L.sbase[n_act];
+#endif
+    }
+  }
+  if (PAIRED) {
+    // Two waves (in different workgroups) produce this environment's inputs of the reward phase;
+    // whichever finishes second runs it.  Release: every lane's stores, then one agent-scope
+    // counter increment; the counter only ever grows (2 per step), its parity tells who is second.
+    __threadfence();
+    unsigned old = 0;
+    if (lane == 0) old = atomicAdd(d.pair_flag + e, 1u);
+    old = __shfl(old, 0, AUV_WAVE);
+    if (old & 1u) {
+      __threadfence();                                            // acquire the other wave's stores
+      k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out);
     }
   }
 }
@@ -86,16 +129,40 @@ void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, floa
 // K3-nav's chunk list lives at the start of the wave's slice there
 bool auv_k23_ok(const AuvDev& d) { return (size_t)d.nch_max * sizeof(int) <= k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
 
+// Workgroup shape of the side-by-side launch: ONE wave (one environment) per workgroup, so a wave
+// slot is handed on the moment an environment's sweep ends instead of when the slowest of four
+// does -- the navigation workgroups queued behind the LiDAR ones start (and end) earlier.
+static int k23_epb() {
+  static int epb = 0;
+  if (!epb) {
+    const char* v = getenv("AUV_K23_EPB");
+    epb = v ? atoi(v) : 1;
+    if (epb != 1 && epb != 2 && epb != 4) epb = 1;
+  }
+  return epb;
+}
+
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st) {
-  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
-  const int nb = (d.n + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK;
-  hipLaunchKernelGGL(k23_lidar_nav, dim3(2 * nb), dim3(AUV_BLOCK), lds, st, d, obs);
+  const int epb = k23_epb();
+  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * epb;
+  const int nb = (d.n + epb - 1) / epb;
+  hipLaunchKernelGGL(k23_lidar_nav<false>, dim3(2 * nb), dim3(AUV_WAVE * epb), lds, st, d, obs, nullptr, nullptr);
+}
+
+// ... and with the reward phase run by the second of an environment's two waves to finish
+void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st) {
+  const int epb = k23_epb();
+  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * epb;
+  const int nb = (d.n + epb - 1) / epb;
+  hipLaunchKernelGGL(k23_lidar_nav<true>, dim3(2 * nb), dim3(AUV_WAVE * epb), lds, st, d, obs, reward, done);
 }
 
 hipError_t auv_step_fused_prepare(const AuvDev& d) {
   const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
   if (b <= 64 * 1024) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k23_lidar_nav<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
