@@ -19,7 +19,7 @@ void auv_launch_k2_fresh(const AuvDev& d, hipStream_t st);
 void auv_launch_k3(const AuvDev& d, int mode, float* obs, float* reward, uint8_t* done, hipStream_t st);
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st);
 void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st);
-void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st);
+void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st);
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, float* obs, hipStream_t st);
 void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
 void auv_launch_ring_advance(const AuvDev& d, hipStream_t st);
@@ -125,6 +125,8 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.stamps, n * 16);
   rc |= dev_alloc(ep, &d.ring_pos, 4);
   rc |= dev_alloc(ep, &d.pair_flag, n);
+  rc |= dev_alloc(ep, &d.rew_path, n);
+  rc |= dev_alloc(ep, &d.rew_lidar, n);
   {
     std::vector<double> bcs(2 * (S ? S : 1), 0.0);
     const double dangle = 2 * AUV_PI / (double)(S ? S : 1);
@@ -521,7 +523,7 @@ static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, flo
     // default: K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward, one stream
     auv_launch_k1(h->d, actions, dtype, st);
     auv_launch_k23(h->d, obs, st);
-    auv_launch_k3_reward(h->d, obs, reward, done, st);
+    auv_launch_k3_reward(h->d, obs, reward, done, h->d.cfg.use_lidar ? 0 : 1, st);
     return AUV_OK;
   }
   auv_launch_k1(h->d, actions, dtype, st);
@@ -531,7 +533,7 @@ static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, flo
   HIP_TRY(hipEventRecord(h->ev_join, h->aux_stream));
   auv_launch_k2(h->d, 1, st);
   HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-  auv_launch_k3_reward(h->d, obs, reward, done, st);   // a done env with auto-reset copies its next world's reset rows
+  auv_launch_k3_reward(h->d, obs, reward, done, 1, st);   // a done env with auto-reset copies its next world's reset rows
   return AUV_OK;
 }
 
@@ -703,7 +705,7 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
     auv_launch_k3_nav(h->d, obs_dev, st);
   }
   HIP_TRY(hipEventRecord(h->ev[2], st));
-  auv_launch_k3_reward(h->d, obs_dev, reward_dev, done_dev, st);
+  auv_launch_k3_reward(h->d, obs_dev, reward_dev, done_dev, (auv_k23_ok(h->d) && h->d.cfg.use_lidar) ? 0 : 1, st);
   HIP_TRY(hipEventRecord(h->ev[3], st));
   HIP_TRY(hipEventRecord(h->ev[4], st));
   HIP_TRY(hipEventSynchronize(h->ev[4]));

@@ -558,13 +558,21 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 #endif
 }
 
-// phase E: outputs (vessel.py:88-95, :356-359)
-__device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L) {
+// phase E: outputs (vessel.py:88-95, :356-359) and, while the ranges are in registers, the LiDAR
+// term of the Colav reward (rewarder.py:205-222: sum of gamma_theta-weighted R exp(-0.1 d) over
+// the beams; the velocity channel is identically zero, sensor.py:159) and the float32 closeness
+// columns of the observation row.
+__device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, float* __restrict__ obs_out = nullptr) {
   const int S = d.cfg.n_sensors;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   int col = 0;
   const double logR = log(1 + R);
   const double px = L.hdr->px, py = L.hdr->py;
+  const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
+  const double dangle = 2 * AUV_PI / S;
+  const double raw_free = R * exp(-0.1 * R);
+  const int D = 6 + S * (d.cfg.obs_channels == 3 ? 3 : 1);   // row stride of obs_out (use_lidar is on here)
+  double num = 0.0, den = 0.0;
   for (int i = lane; i < S; i += AUV_WAVE) {
     const double t = u2d(L.dbits[i]);
     double di = R;                                          // sensor.py:156
@@ -576,16 +584,34 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
       di = sqrt(dx * dx + dy * dy);
     }
     d.lidar_d[(size_t)e * S + i] = di;
-    // a beam without a return sits exactly at R: closeness 1 - x/x = 0, so the logarithm is only
-    // evaluated in passes where some lane has a return
+    // a beam without a return sits exactly at R: closeness 1 - x/x = 0 and its exp() is one
+    // constant, so the transcendentals are only evaluated in passes where some lane has a return
+    const bool any_return = __any(t <= 1.0);
     double cl = 0.0;
-    if (__any(t <= 1.0))
+    if (any_return)
       cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0) : 1 - auv_clip(di / R, 0.0, 1.0);
-    d.obs64[(size_t)e * (6 + S) + 6 + i] = auv_clip(cl, -1.0, 1.0);
+    cl = auv_clip(cl, -1.0, 1.0);
+    d.obs64[(size_t)e * (6 + S) + 6 + i] = cl;
+    if (obs_out) obs_out[(size_t)e * D + 6 + i] = (float)cl;
+    if (colav) {
+      double raw = raw_free;
+      if (__any(di != R)) raw = R * exp(-0.1 * di);         // gamma_x
+      const double angle = -AUV_PI + (i + 1) * dangle;      // body-frame beam angle (vessel.py:66-68)
+      const double weight = 1 / (1 + fabs(10.0 * angle));    // gamma_theta
+      num += weight * raw;
+      den += weight;
+    }
     col |= (di < W);
   }
   col = __any(col);
-  if (lane == 0) d.collision[e] = (uint8_t)(col != 0);
+  if (colav) {
+    num = auv_wave_sum(num);
+    den = auv_wave_sum(den);
+  }
+  if (lane == 0) {
+    d.collision[e] = (uint8_t)(col != 0);
+    if (colav) d.rew_lidar[e] = (S > 0) ? -num / den : 0.0;
+  }
   return col != 0;
 }
 

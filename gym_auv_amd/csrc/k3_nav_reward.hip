@@ -76,6 +76,42 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, int w, double s, doub
   }
 }
 
+// path-following term of the reward (rewarder.py:110-118, :196-203)
+__device__ __forceinline__ double reward_path_term(const AuvDev& d, double u, double v, double heading_error,
+                                                   double cross_track_error, double progress, double max_progress) {
+  const double gamma_y_e = 5.0, max_speed = 2.0;
+  const double speed = sqrt(u * u + v * v);
+  const double ctp = exp(-gamma_y_e * fabs(cross_track_error));
+  double path_reward = (1 + cos(heading_error) * speed / max_speed) * (1 + ctp) - 1;
+  if (d.cfg.rewarder == AUV_REWARD_COLAV && progress < max_progress) path_reward = fmin(path_reward, 0.0);
+  return path_reward;
+}
+
+// LiDAR term of the Colav reward from the ranges in HBM (rewarder.py:205-222), whole wave; the
+// same arithmetic, lane assignment and summation order as the fused form at the end of K2
+__device__ __forceinline__ double reward_lidar_term_wave(const AuvDev& d, const double* __restrict__ dd, int lane) {
+  const int S = d.cfg.n_sensors;
+  const double dangle = 2 * AUV_PI / S;
+  const double R = d.cfg.sensor_range;
+  const double raw_free = R * exp(-0.1 * R);
+  double num = 0.0, den = 0.0;
+  for (int i0 = 0; i0 < S; i0 += AUV_WAVE) {
+    const int i = i0 + lane;
+    const double di = (i < S) ? dd[i] : R;
+    double raw = raw_free;
+    if (__any(di != R)) raw = R * exp(-0.1 * di);       // gamma_x; velocity channel == 0 (sensor.py:159)
+    if (i < S) {
+      double angle = -AUV_PI + (i + 1) * dangle;        // body-frame beam angle (vessel.py:66-68)
+      double weight = 1 / (1 + fabs(10.0 * angle));      // gamma_theta
+      num += weight * raw;
+      den += weight;
+    }
+  }
+  num = auv_wave_sum(num);
+  den = auv_wave_sum(den);
+  return (S > 0) ? -num / den : 0.0;
+}
+
 // restore reset-time state of env e bound to world w2 (environment.py:203-245, vessel.py:189-224).
 // The reset observation (navigate + perceive at the initial pose) is a per-world constant that
 // was computed once at load time; here it is copied.  While those rows are being computed
@@ -250,6 +286,9 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
            r = pre ? pre->s[5] : d.state[5 * n + e];
     nv[0] = u, nv[1] = v, nv[2] = r, nv[3] = la, nv[4] = he, nv[5] = cte / 100, nv[6] = chi, nv[7] = s_t;
     inf[1] = reached, inf[2] = goal, inf[3] = progress, inf[5] = maxp, inf[6] = s, inf[7] = 0.0;
+    // path-following term of the reward: everything it needs is at hand here, so the
+    // transcendentals stay out of the reward phase
+    d.rew_path[e] = reward_path_term(d, u, v, he, cte / 100, progress, maxp);
     // environment.py:276-280; lane 0 also emits the float32 copies of its own six values
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -264,9 +303,13 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
 
 // ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----
 // full = false: only publish the collision flag and the float32 LiDAR observations (reset path)
+// from_buffers: form the two reward terms here from NAV64 / INFO64 / LIDAR_D as they stand (the
+//               per-function test hook) instead of taking what K2 / the navigation phase left
+// lidar_obs:    emit the float32 closeness columns (false when K2 has already written them)
 __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, const bool full,
                               float* __restrict__ obs_out, float* __restrict__ reward_out,
-                              uint8_t* __restrict__ done_out, const EnvPre* pre = nullptr, const int collision_pre = -1) {
+                              uint8_t* __restrict__ done_out, const EnvPre* pre = nullptr, const int collision_pre = -1,
+                              const bool from_buffers = false, const bool lidar_obs = true) {
   const int S = d.cfg.n_sensors;
   int4 cnt = pre ? pre->cnt : d.counters[e];
   const int w = d.world_idx[e];
@@ -278,51 +321,29 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
   const int collision = collision_pre >= 0 ? collision_pre : d.collision[e];
   if (lane == 0) inf[0] = collision;
   if (full) {
-    // ---- reward (rewarder.py) ----
-    double num = 0.0, den = 0.0;
+    // ---- reward (rewarder.py:78-140, :167-241): the LiDAR term was formed by K2 (rew_lidar), the
+    // path-following term by the navigation phase (rew_path); here they are only combined ----
     const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
-    if (colav) {
-      const double* dd = d.lidar_d + (size_t)e * S;
-      const double dangle = 2 * AUV_PI / S;
-      // beams without a return sit exactly at sensor_range: their exp() is one constant, so the
-      // transcendental is only evaluated in passes where some lane actually has a return
-      const double R = d.cfg.sensor_range;
-      const double raw_free = R * exp(-0.1 * R);
-      for (int i0 = 0; i0 < S; i0 += AUV_WAVE) {
-        const int i = i0 + lane;
-        const double di = (i < S) ? dd[i] : R;
-        double raw = raw_free;
-        if (__any(di != R)) raw = R * exp(-0.1 * di);       // gamma_x; velocity channel == 0 (sensor.py:159)
-        if (i < S) {
-          double angle = -AUV_PI + (i + 1) * dangle;        // body-frame beam angle (vessel.py:66-68)
-          double weight = 1 / (1 + fabs(10.0 * angle));      // gamma_theta
-          num += weight * raw;
-          den += weight;
-        }
-      }
-      num = auv_wave_sum(num);
-      den = auv_wave_sum(den);
-    }
+    // without a LiDAR sweep the ranges rest at sensor_range and K2 leaves no term: form it here
+    double lidar_term = 0.0;
+    if (colav && (from_buffers || !d.cfg.use_lidar)) lidar_term = reward_lidar_term_wave(d, d.lidar_d + (size_t)e * S, lane);
     int do_reset = 0;
     if (lane == 0) {
-      const double lambda = 0.5, eta = 0.0, gamma_y_e = 5.0, penalty_yawrate = 10.0, neutral_speed = 0.05,
-                   max_speed = 2.0;
+      const double lambda = 0.5, eta = 0.0, penalty_yawrate = 10.0, neutral_speed = 0.05, max_speed = 2.0;
       double reward;
       if (collision) {
         reward = -10000.0 * (1 - lambda);
       } else {
-        double u = nv[0], v = nv[1], yaw_rate = nv[2], heading_error = nv[4], cross_track_error = nv[5];
-        double speed = sqrt(u * u + v * v);
-        double ctp = exp(-gamma_y_e * fabs(cross_track_error));
-        double path_reward = (1 + cos(heading_error) * speed / max_speed) * (1 + ctp) - 1;
-        double living_penalty = lambda * (2 * neutral_speed + 1) + eta * neutral_speed;
+        const double u = nv[0], v = nv[1], yaw_rate = nv[2];
+        const double speed = sqrt(u * u + v * v);
+        const double path_reward = from_buffers ? reward_path_term(d, u, v, nv[4], nv[5], inf[3], inf[5]) : d.rew_path[e];
+        const double living_penalty = lambda * (2 * neutral_speed + 1) + eta * neutral_speed;
         if (!colav) {
           double slow_penalty = (speed < 0.1) ? -2 : 0;
           reward = path_reward - living_penalty + eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) +
                    slow_penalty;
         } else {
-          double closeness_reward = (S > 0) ? -num / den : 0.0;
-          if (inf[3] < inf[5]) path_reward = fmin(path_reward, 0.0);
+          const double closeness_reward = (from_buffers || !d.cfg.use_lidar) ? lidar_term : d.rew_lidar[e];
           double slow_penalty = (speed < 0.04) ? -2 : 0;
           reward = lambda * path_reward + (1 - lambda) * closeness_reward - living_penalty +
                    eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) + slow_penalty;
@@ -362,7 +383,7 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
     }
   }
   // ---- LiDAR part of the float32 observation row (closeness written in fp64 by K2) ----
-  if (obs_out)
+  if (obs_out && lidar_obs)
     for (int i = 6 + lane; i < DL; i += AUV_WAVE) obs_out[(size_t)e * D + i] = (float)ob[i];
 }
 
@@ -378,7 +399,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, f
   const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
   if (e >= d.n) return;
   if (mode != 2) k3_nav_env(d, e, lane, (int*)smem + (size_t)wave * d.nch_max, obs_out);
-  k3_reward_env(d, e, lane, mode != 1, mode == 2 ? nullptr : obs_out, reward_out, done_out);
+  k3_reward_env(d, e, lane, mode != 1, mode == 2 ? nullptr : obs_out, reward_out, done_out, nullptr, -1, mode == 2);
 }
 
 // the two halves as separate kernels for the step path (k3_nav overlaps with K2)
@@ -392,11 +413,11 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav(AuvDev d, float* __restrict_
 
 __global__ void __launch_bounds__(AUV_BLOCK) k3_reward(AuvDev d, float* __restrict__ obs_out,
                                                        float* __restrict__ reward_out,
-                                                       uint8_t* __restrict__ done_out) {
+                                                       uint8_t* __restrict__ done_out, int lidar_obs) {
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
   if (e >= d.n) return;
-  k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out);
+  k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, nullptr, -1, false, lidar_obs != 0);
 }
 
 // reset pass: first observation of the environments on the fresh list
@@ -460,8 +481,9 @@ void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st) {
   hipLaunchKernelGGL(k3_nav, dim3(env_grid(d)), dim3(AUV_BLOCK), k3_lds_bytes(d), st, d, obs);
 }
 
-void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st) {
-  hipLaunchKernelGGL(k3_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, obs, reward, done);
+// lidar_obs = 0: the LiDAR launch before it has written the float32 closeness columns itself
+void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st) {
+  hipLaunchKernelGGL(k3_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, obs, reward, done, lidar_obs);
 }
 
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st) {
