@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="polygons50", choices=["polygons50", "circles20", "moving28", "mixed47"])
     ap.add_argument("--graph", type=int, default=0, help="replay a captured hipGraph per step (1) or launch eagerly (0, default: eager launches pipeline deeper than one graph replay per step on this stack)")
-    ap.add_argument("--step-mode", default="side_by_side", choices=["side_by_side", "one_kernel", "two_streams", "paired"],
+    ap.add_argument("--step-mode", default="side_by_side", choices=["side_by_side", "one_kernel", "two_streams"],
                     help="how a step is launched (include/auv_hip.h, AUV_STEP_*)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")

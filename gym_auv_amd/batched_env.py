@@ -132,7 +132,7 @@ class BatchedAuvEnv:
     def set_step_mode(self, mode: str):
         """"side_by_side" (default): K1 -> [K2 + K3-nav in one launch] -> K3-reward;
         "one_kernel": the whole step in one kernel; "two_streams": K3-nav forked beside K2."""
-        _check(_LIB.auv_set_step_mode(self._h, {"side_by_side": 0, "one_kernel": 1, "two_streams": 2, "paired": 3}[mode]),
+        _check(_LIB.auv_set_step_mode(self._h, {"side_by_side": 0, "one_kernel": 1, "two_streams": 2}[mode]),
                "auv_set_step_mode")
 
     # per-kernel entry points (parity tests)

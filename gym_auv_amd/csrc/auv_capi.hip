@@ -28,7 +28,6 @@ hipError_t auv_k2_prepare(const AuvDev& d);
 bool auv_step_fused_ok(const AuvDev& d);
 bool auv_k23_ok(const AuvDev& d);
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st);
-void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st);
 hipError_t auv_step_fused_prepare(const AuvDev& d);
 void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st);
@@ -124,7 +123,6 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.fresh_list, n);
   rc |= dev_alloc(ep, &d.stamps, n * 16);
   rc |= dev_alloc(ep, &d.ring_pos, 4);
-  rc |= dev_alloc(ep, &d.pair_flag, n);
   rc |= dev_alloc(ep, &d.rew_path, n);
   rc |= dev_alloc(ep, &d.rew_lidar, n);
   {
@@ -513,12 +511,6 @@ static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, flo
     if (d.ring_slots > 1 && capturing) auv_launch_ring_advance(h->d, st);
     return AUV_OK;
   }
-  if (h->step_mode == AUV_STEP_PAIRED && auv_k23_ok(h->d)) {
-    // K1 -> one launch: K2 and K3-nav side by side, K3-reward by the second finisher of each env
-    auv_launch_k1(h->d, actions, dtype, st);
-    auv_launch_k23_paired(h->d, obs, reward, done, st);
-    return AUV_OK;
-  }
   if (h->step_mode != AUV_STEP_TWO_STREAMS && auv_k23_ok(h->d)) {
     // default: K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward, one stream
     auv_launch_k1(h->d, actions, dtype, st);
@@ -564,7 +556,7 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
 
 int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   if (!h) return fail(AUV_EINVAL, "null handle");
-  if (mode < 0 || mode > 3) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
+  if (mode < 0 || mode > 2) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
   h->step_mode = mode;
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);

@@ -81,7 +81,6 @@ struct AuvDev {
   double* rew_path;     // [N] path-following term of the reward, left by the navigation phase
   double* rew_lidar;    // [N] LiDAR term of the Colav reward, left by K2
   const double2* beam_cs; // [S] cos, sin of the body-frame beam angles -pi + (i + 1) 2 pi / S (vessel.py:66-68)
-  unsigned* pair_flag;  // [N]  grows by 2 per paired step: parity = which of the env's two waves is second
   int32_t* ring_pos;    // [1]  current slot of the action ring (advanced once per step by K3)
   int32_t ring_slots;   // 1 = plain action buffer
   int32_t ring_slot_host; // >= 0: the host names the slot (single-kernel step); -1: read ring_pos

@@ -49,20 +49,17 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
 // new vessel state, so they run side by side (the LiDAR workgroups are dispatched first and fill
 // the chip; navigation workgroups move in as those retire) -- the concurrency of two streams
 // without the ~8 us a cross-stream event wait costs on each side.
-template <bool PAIRED>
-__global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* __restrict__ obs_out,
-                                                              float* __restrict__ reward_out,
-                                                              uint8_t* __restrict__ done_out) {
+__global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* __restrict__ obs_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int S = d.cfg.n_sensors;
-  const int epb = blockDim.x / AUV_WAVE;                            // environments (waves) per workgroup
-  const int nb = (d.n + epb - 1) / epb;
+  const int wpb = blockDim.x / AUV_WAVE;                            // waves per workgroup
+  const int nb = (d.n + wpb - 1) / wpb;                             // LiDAR workgroups: one env per wave
   const bool nav_role = (int)blockIdx.x >= nb;                      // workgroup-uniform
-  const int e = ((int)blockIdx.x - (nav_role ? nb : 0)) * epb + wave;
-  if (e >= d.n) return;
   unsigned char* slice = smem + wave * k2_slice_bytes(S, d.k_max, d.m_max);
   if (nav_role) {
+    const int e = ((int)blockIdx.x - nb) * wpb + wave;
+    if (e >= d.n) return;
 #ifdef AUV_STAMPS
     const unsigned long long t_nav0 = wall_clock64();
 #endif
@@ -71,6 +68,8 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* _
     if (lane == 0) d.stamps[(size_t)e * 16 + 12] = t_nav0, d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif
   } else {
+    const int e = (int)blockIdx.x * wpb + wave;
+    if (e >= d.n) return;
     const Slice L = carve(slice, S, d.k_max, d.m_max);
     AUV_STAMP_DECL
 #ifdef AUV_STAMPS
@@ -96,19 +95,6 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* _
 #endif
     }
   }
-  if (PAIRED) {
-    // Two waves (in different workgroups) produce this environment's inputs of the reward phase;
-    // whichever finishes second runs it.  Release: every lane's stores, then one agent-scope
-    // counter increment; the counter only ever grows (2 per step), its parity tells who is second.
-    __threadfence();
-    unsigned old = 0;
-    if (lane == 0) old = atomicAdd(d.pair_flag + e, 1u);
-    old = __shfl(old, 0, AUV_WAVE);
-    if (old & 1u) {
-      __threadfence();                                            // acquire the other wave's stores
-      k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, nullptr, -1, false, !d.cfg.use_lidar);
-    }
-  }
 }
 
 }  // namespace
@@ -126,43 +112,33 @@ void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, floa
     hipLaunchKernelGGL(k_step<float>, grid, block, lds, st, d, (const float*)actions, obs, reward, done);
 }
 
-// K3-nav's chunk list lives at the start of the wave's slice there
+// the navigation role keeps its chunk list at the start of the wave's slice
 bool auv_k23_ok(const AuvDev& d) { return (size_t)d.nch_max * sizeof(int) <= k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
 
-// Workgroup shape of the side-by-side launch: ONE wave (one environment) per workgroup, so a wave
-// slot is handed on the moment an environment's sweep ends instead of when the slowest of four
-// does -- the navigation workgroups queued behind the LiDAR ones start (and end) earlier.
-static int k23_epb() {
-  static int epb = 0;
-  if (!epb) {
-    const char* v = getenv("AUV_K23_EPB");
-    epb = v ? atoi(v) : 1;
-    if (epb != 1 && epb != 2 && epb != 4) epb = 1;
+// Workgroup shape of the side-by-side launch: ONE wave per workgroup, so a wave slot is handed on
+// the moment an environment's sweep ends instead of when the slowest of four does -- the
+// navigation workgroups queued behind the LiDAR ones start (and end) earlier.
+static int k23_wpb() {
+  static int wpb = 0;
+  if (!wpb) {
+    const char* v = getenv("AUV_K23_WPB");
+    wpb = v ? atoi(v) : 1;
+    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = 1;
   }
-  return epb;
+  return wpb;
 }
 
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st) {
-  const int epb = k23_epb();
-  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * epb;
-  const int nb = (d.n + epb - 1) / epb;
-  hipLaunchKernelGGL(k23_lidar_nav<false>, dim3(2 * nb), dim3(AUV_WAVE * epb), lds, st, d, obs, nullptr, nullptr);
-}
-
-// ... and with the reward phase run by the second of an environment's two waves to finish
-void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st) {
-  const int epb = k23_epb();
-  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * epb;
-  const int nb = (d.n + epb - 1) / epb;
-  hipLaunchKernelGGL(k23_lidar_nav<true>, dim3(2 * nb), dim3(AUV_WAVE * epb), lds, st, d, obs, reward, done);
+  const int wpb = k23_wpb();
+  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * wpb;
+  const int nb = (d.n + wpb - 1) / wpb;
+  hipLaunchKernelGGL(k23_lidar_nav, dim3(2 * nb), dim3(AUV_WAVE * wpb), lds, st, d, obs);
 }
 
 hipError_t auv_step_fused_prepare(const AuvDev& d) {
   const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
   if (b <= 64 * 1024) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k23_lidar_nav<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;

@@ -196,11 +196,8 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
  *                                    K3-nav for all envs side by side -> K3-reward; one stream.
  *   AUV_STEP_ONE_KERNEL              the whole step in one kernel, one wave per env running
  *                                    K1 -> K3-nav -> K2 -> K3-reward back to back.
- *   AUV_STEP_TWO_STREAMS             K1 -> { K2 || K3-nav on an auxiliary stream } -> K3-reward.
- *   AUV_STEP_PAIRED                  K1 -> one launch: K2 and K3-nav side by side, and the reward /
- *                                    done / auto-reset phase of each env run by whichever of its
- *                                    two waves finishes second (device-scope counter).            */
-enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2, AUV_STEP_PAIRED = 3 };
+ *   AUV_STEP_TWO_STREAMS             K1 -> { K2 || K3-nav on an auxiliary stream } -> K3-reward. */
+enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2 };
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
 
 /* One step in the default launch shape with HIP events on `stream` around every kernel:

@@ -3,7 +3,7 @@ to check that k3_nav overlaps k2_lidar and to read the inter-kernel gaps."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-22:])
-      for r in rows if any(t in r["Kernel_Name"] for t in ("k1_", "k2_", "k3_", "copyBuffer"))]
+      for r in rows if any(t in r["Kernel_Name"] for t in ("k1_", "k2_", "k23_", "k3_", "k_step", "copyBuffer"))]
 ks.sort()
 k1 = [i for i, k in enumerate(ks) if "k1_" in k[2]]
 i0 = k1[-4]
