@@ -23,6 +23,7 @@ void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* d
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, float* obs, hipStream_t st);
 void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
 void auv_launch_ring_advance(const AuvDev& d, hipStream_t st);
+void auv_launch_refresh_desc(const AuvDev& d, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
 hipError_t auv_k2_prepare(const AuvDev& d);
 bool auv_step_fused_ok(const AuvDev& d);
@@ -107,6 +108,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   auto& ep = h->env_allocs;
   rc |= dev_alloc(ep, &d.state, 6 * n);
   rc |= dev_alloc(ep, &d.world_idx, n);
+  rc |= dev_alloc(ep, &d.env_desc, n);
   rc |= dev_alloc(ep, &d.counters, n);
   rc |= dev_alloc(ep, &d.lidar_d, n * S);
   rc |= dev_alloc(ep, &d.obs64, n * (6 + S));
@@ -635,6 +637,7 @@ int auv_write(auv_handle_t* h, int32_t field, const void* src_dev, size_t bytes,
   void* p = field_ptr(h, field, &b);
   if (!p || !src_dev || bytes != b) return fail(AUV_EINVAL, "auv_write: field %d expects %zu bytes, got %zu", field, b, bytes);
   HIP_TRY(hipMemcpyAsync(p, src_dev, b, hipMemcpyDefault, (hipStream_t)stream));
+  if (field == AUV_FIELD_WORLD_IDX) auv_launch_refresh_desc(h->d, (hipStream_t)stream);   // out-of-range entries keep their binding
   return AUV_OK;
 }
 

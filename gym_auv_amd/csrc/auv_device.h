@@ -16,6 +16,14 @@
 #define AUV_CHUNK 64           // polyline segments per bounding-circle chunk (= one wave pass)
 #define AUV_FRESH_GRID 256     // workgroups of the reset-pass kernels (they loop over the fresh list)
 
+// Where the tables of an environment's current world start and how long they are: one 64-byte
+// record per environment, rewritten whenever the environment is bound to a world, so the step
+// kernels reach their tables with one load instead of world_idx -> per-world offsets -> table.
+struct __attribute__((aligned(16))) EnvDesc {
+  long long k0, m0, p0, c0, kn0;   // first obstacle / mover / polyline vertex / chunk / knot
+  int K, M, P, nch, nk, w;         // counts, and the world index itself
+};
+
 // Everything the kernels read, by value in the kernel argument buffer (no constant memory,
 // no host round trip; hipGraph-capturable).
 struct AuvDev {
@@ -54,6 +62,7 @@ struct AuvDev {
   // ---- environment state (HBM, SoA where per-env scalars) ----
   double* state;       // [6][N]
   int32_t* world_idx;  // [N]
+  EnvDesc* env_desc;   // [N]  table starts / counts of the bound world (kept in step with world_idx)
   int4* counters;      // [N] t_step, step_counter, episodes, fresh-flag
   double* lidar_d;     // [N][S]
   double* obs64;       // [N][6+S]
@@ -108,6 +117,19 @@ struct EnvPre {
 #define AUV_STAMP()
 #define AUV_STAMP_FLUSH(e, base)
 #endif
+
+// One wave works on one environment: its index is the same in every lane.  Saying so lets the
+// compiler keep everything derived from it (table offsets, counts, the pose) in scalar registers
+// and fetch it through the scalar cache.
+__device__ __forceinline__ int auv_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ EnvDesc auv_make_desc(const AuvDev& d, int w) {
+  EnvDesc ed;
+  ed.k0 = d.obs_off[w], ed.m0 = d.mv_off[w], ed.p0 = d.poly_off[w], ed.c0 = d.chunk_off[w], ed.kn0 = d.knot_off[w];
+  ed.K = d.obs_cnt[w], ed.M = d.mv_cnt[w], ed.P = d.poly_cnt[w], ed.nch = d.chunk_cnt[w], ed.nk = d.knot_cnt[w];
+  ed.w = w;
+  return ed;
+}
 
 __device__ __forceinline__ double auv_princip(double a) {
   // ((a + pi) % (2 pi)) - pi with Python's sign convention (utils/geomutils.py:4-5).

@@ -181,11 +181,11 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   const int4 cnt = pre ? pre->cnt : d.counters[e];
   const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
                psi = pre ? pre->s[2] : d.state[2 * n + e];
-  const int w = d.world_idx[e];
-  const long long k0 = d.obs_off[w];
-  const int K = d.obs_cnt[w];
-  const long long m0 = d.mv_off[w];
-  const int M = d.mv_cnt[w];
+  const EnvDesc ed = d.env_desc[e];
+  const long long k0 = ed.k0;
+  const int K = ed.K;
+  const long long m0 = ed.m0;
+  const int M = ed.M;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   const double dangle = 2 * AUV_PI / S;
   if (lane == 0) {
@@ -266,6 +266,8 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     if (k < K) {
       const int4 meta = d.obs_meta[k0 + k];
       const bool mover = meta.x == AUV_OBS_MOVER;
+      // static cull circle (unused for movers)
+      const double scx = d.obs_cull[3 * (k0 + k)], scy = d.obs_cull[3 * (k0 + k) + 1], srho = d.obs_cull[3 * (k0 + k) + 2];
       ObsLds o;
       o.kind = meta.x;
       o.seg_off = mover ? meta.w * AUV_MOVER_NSEG : meta.y;
@@ -285,7 +287,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
           double4 c4 = L.mvcull[meta.w];
           cx = c4.x, cy = c4.y, rho = c4.z;
         } else {
-          cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
+          cx = scx, cy = scy, rho = srho;
         }
         const double dc = sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy));
         if (dc - rho - W >= R + 1e-9) {
@@ -318,7 +320,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
             double4 c4 = L.mvcull[meta.w];
             cx = c4.x, cy = c4.y, rho = c4.z;
           } else {
-            cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
+            cx = scx, cy = scy, rho = srho;
           }
           double relx = cx - px, rely = cy - py;
           double bearing = atan2(rely, relx) - psi;          // not wrapped (sensor.py:54)
@@ -621,7 +623,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k2_lidar(AuvDev d, int advance_m
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int S = d.cfg.n_sensors;
-  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
   AUV_STAMP_DECL
@@ -650,7 +652,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
   const int nf = *d.fresh_count;
   const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
   for (int i = blockIdx.x * AUV_ENVS_PER_BLOCK + wave; i < nf; i += gridDim.x * AUV_ENVS_PER_BLOCK) {
-    const int e = d.fresh_list[i];
+    const int e = auv_uniform(d.fresh_list[i]);
     const int n_act = k2_front(d, e, lane, L, 0);
     if (d.cfg.use_lidar) {
       k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);

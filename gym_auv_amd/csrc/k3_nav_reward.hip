@@ -51,9 +51,8 @@ __device__ __forceinline__ MinIdx wave_min_first(MinIdx v) {
 }
 
 // SciPy PPoly: interval search (knots are near-uniform: guess then walk) + power-basis eval
-__device__ __forceinline__ void path_eval(const AuvDev& d, int w, double s, double L, double xy[2], double dxy[2]) {
-  const long long k0 = d.knot_off[w];
-  const int nk = d.knot_cnt[w];
+__device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk, double s, double L, double xy[2],
+                                          double dxy[2]) {
   const double* x = d.knot_s + k0;
   int i;
   if (!(s >= x[0])) {
@@ -125,6 +124,7 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
   const int DL = 6 + (d.cfg.use_lidar ? S : 0);                                        // columns this path writes
   if (lane == 0) {
     d.world_idx[e] = w2;
+    d.env_desc[e] = auv_make_desc(d, w2);
     d.state[0 * n + e] = ws2[3], d.state[1 * n + e] = ws2[4], d.state[2 * n + e] = ws2[5];
     d.state[3 * n + e] = 0.0, d.state[4 * n + e] = 0.0, d.state[5 * n + e] = 0.0;
     d.counters[e] = make_int4(0, 0, episodes, 0);
@@ -166,7 +166,8 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
                            const EnvPre* pre = nullptr) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
-  const int w = d.world_idx[e];
+  const EnvDesc ed = d.env_desc[e];
+  const int w = ed.w;
   const double* ws = d.world_scalar + 8 * (size_t)w;
   const double L = ws[0];
   const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
@@ -178,11 +179,11 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
 
   AUV_STAMP_DECL
   // ---- nearest point on the dense polyline (path.py:84-93), exact with chunk pruning ----
-  const long long p0 = d.poly_off[w];
-  const int P = d.poly_cnt[w];
+  const long long p0 = ed.p0;
+  const int P = ed.P;
   const double2* xy = d.poly_xy + p0;
-  const long long c0 = d.chunk_off[w];
-  const int nch = d.chunk_cnt[w];
+  const long long c0 = ed.c0;
+  const int nch = ed.nch;
   const double4* cb = d.chunk_bound + c0;
   // up to 4 chunks per lane stay in registers (paths up to 16 k vertices); their loads are
   // issued together.  Longer paths take the generic two-pass route below.
@@ -264,7 +265,7 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   if (L < s_t) s_t = L;
   // vessel.py:471-515 -- lane 0 evaluates the spline at s, lane 1 at s_t (same instructions)
   double p[2], dp[2];
-  path_eval(d, w, lane == 1 ? s_t : s, L, p, dp);
+  path_eval(d, ed.kn0, ed.nk, lane == 1 ? s_t : s, L, p, dp);
   double dir = atan2(dp[1], dp[0]);                       // lane 0: chi; lane 1: look-ahead direction
   double tgt = atan2(p[1] - py, p[0] - px);               // lane 1: target heading
   const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(tgt, 1, AUV_WAVE);
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, f
                                                            uint8_t* __restrict__ done_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   if (mode != 2) k3_nav_env(d, e, lane, (int*)smem + (size_t)wave * d.nch_max, obs_out);
   k3_reward_env(d, e, lane, mode != 1, mode == 2 ? nullptr : obs_out, reward_out, done_out, nullptr, -1, mode == 2);
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, f
 __global__ void __launch_bounds__(AUV_BLOCK) k3_nav(AuvDev d, float* __restrict__ obs_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   k3_nav_env(d, e, lane, (int*)smem + (size_t)wave * d.nch_max, obs_out);
 }
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_reward(AuvDev d, float* __restri
                                                        float* __restrict__ reward_out,
                                                        uint8_t* __restrict__ done_out, int lidar_obs) {
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, nullptr, -1, false, lidar_obs != 0);
 }
@@ -427,7 +428,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_observe_fresh(AuvDev d, float* _
   const int nf = *d.fresh_count;
   int* list = (int*)smem + (size_t)wave * d.nch_max;
   for (int i = blockIdx.x * AUV_ENVS_PER_BLOCK + wave; i < nf; i += gridDim.x * AUV_ENVS_PER_BLOCK) {
-    const int e = d.fresh_list[i];
+    const int e = auv_uniform(d.fresh_list[i]);
     k3_nav_env(d, e, lane, list, obs_out);
     k3_reward_env(d, e, lane, false, obs_out, nullptr, nullptr);
     auv_wave_lds_sync();
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k_reset(AuvDev d, const uint8_t* __
                                                      const int32_t* __restrict__ world_idx,
                                                      float* __restrict__ obs_out) {
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   if (mask && !mask[e]) return;
   const int w = world_idx ? world_idx[e] : d.world_idx[e];
@@ -450,7 +451,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k_reset(AuvDev d, const uint8_t* __
 // the first `count` env slots, keep those rows per world
 __global__ void __launch_bounds__(AUV_BLOCK) k_harvest(AuvDev d, int count) {
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= count) return;
   const int S = d.cfg.n_sensors;
   const int w = d.world_idx[e];
@@ -496,10 +497,23 @@ void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world
 }
 
 namespace {
+// after a caller has overwritten WORLD_IDX directly: bring the descriptors back in step
+__global__ void k_refresh_desc(AuvDev d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.n) return;
+  int w = d.world_idx[e];
+  if (w < 0 || w >= d.n_worlds) d.world_idx[e] = w = d.env_desc[e].w;
+  d.env_desc[e] = auv_make_desc(d, w);
+}
+
 __global__ void k_ring_advance(AuvDev d) {
   if (threadIdx.x == 0 && d.ring_slots > 1) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
 }
 }  // namespace
+
+void auv_launch_refresh_desc(const AuvDev& d, hipStream_t st) {
+  hipLaunchKernelGGL(k_refresh_desc, dim3((d.n + 255) / 256), dim3(256), 0, st, d);
+}
 
 void auv_launch_ring_advance(const AuvDev& d, hipStream_t st) { hipLaunchKernelGGL(k_ring_advance, dim3(1), dim3(64), 0, st, d); }
 

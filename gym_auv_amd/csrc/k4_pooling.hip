@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k4_pooling(AuvDev d, const int32_t*
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int S = d.cfg.n_sensors;
-  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   double* x = (double*)(smem + (size_t)wave * ((size_t)S + 2 * (size_t)n_sectors) * 8);
   unsigned long long* mn = (unsigned long long*)(x + S);

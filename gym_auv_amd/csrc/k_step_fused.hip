@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int S = d.cfg.n_sensors;
-  const int e = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
   // K1: every lane advances the (same) vessel; lane 0 writes it back
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* _
   const bool nav_role = (int)blockIdx.x >= nb;                      // workgroup-uniform
   unsigned char* slice = smem + wave * k2_slice_bytes(S, d.k_max, d.m_max);
   if (nav_role) {
-    const int e = ((int)blockIdx.x - nb) * wpb + wave;
+    const int e = auv_uniform(((int)blockIdx.x - nb) * wpb + wave);
     if (e >= d.n) return;
 #ifdef AUV_STAMPS
     const unsigned long long t_nav0 = wall_clock64();
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* _
     if (lane == 0) d.stamps[(size_t)e * 16 + 12] = t_nav0, d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif
   } else {
-    const int e = (int)blockIdx.x * wpb + wave;
+    const int e = auv_uniform((int)blockIdx.x * wpb + wave);
     if (e >= d.n) return;
     const Slice L = carve(slice, S, d.k_max, d.m_max);
     AUV_STAMP_DECL
