@@ -257,8 +257,48 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   }
   auv_wave_lds_sync();
 
-  // ---- phase B: nearby list + cull windows; compaction of obstacles with a window ---------
-  const bool refresh = (cnt.y % d.cfg.sensor_interval_load_obstacles) == 0;   // vessel.py:266
+  // ---- phase B0 (every sensor_interval_load_obstacles-th vessel step, vessel.py:266-273): refresh
+  //      the cached nearby mask.  Kept apart from the cull-window pass below so that the exact
+  //      distance loops do not sit inside its register budget ----
+  const bool refresh = (cnt.y % d.cfg.sensor_interval_load_obstacles) == 0;
+  if (refresh) {
+    for (int k = lane; k < K; k += AUV_WAVE) {
+      const int4 meta = d.obs_meta[k0 + k];
+      const bool mover = meta.x == AUV_OBS_MOVER;
+      const int seg_off = mover ? meta.w * AUV_MOVER_NSEG : meta.y;
+      // Point.distance(boundary) - width < range (filled: 0 inside).  The boundary lies inside the
+      // obstacle's enclosing circle (c, rho), so
+      //   |p0 - c| - rho <= distance(p0, boundary) <= |p0 - c| + rho ;
+      // only obstacles the two bounds cannot classify need the exact distance (same answer,
+      // far fewer segment loops).  1e-9 m of slack keeps rounding on the exact side.
+      double cx, cy, rho;
+      if (mover) {
+        double4 c4 = L.mvcull[meta.w];
+        cx = c4.x, cy = c4.y, rho = c4.z;
+      } else {
+        cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
+      }
+      const double dc = sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy));
+      uint8_t near;
+      if (dc - rho - W >= R + 1e-9) {
+        near = 0;
+      } else if (dc + rho - W < R - 1e-9) {
+        near = 1;
+      } else {
+        bool in = false;
+        if (meta.x != AUV_OBS_RING)
+          in = mover ? point_in_polygon(px, py, L.mvseg + seg_off, meta.z)
+                     : point_in_polygon(px, py, d.seg + meta.y, meta.z);
+        const double dist = in ? 0.0
+                               : (mover ? point_boundary_distance(px, py, L.mvseg + seg_off, meta.z)
+                                        : point_boundary_distance(px, py, d.seg + meta.y, meta.z));
+        near = (dist - W < R) ? 1 : 0;
+      }
+      d.nearby[(size_t)e * d.k_max + k] = near;              // read back below by the same lane
+    }
+  }
+
+  // ---- phase B: cull windows of the nearby obstacles; compaction of obstacles with a window ----
   int n_act = 0;
   for (int kb = 0; kb < K; kb += AUV_WAVE) {
     const int k = kb + lane;
@@ -275,39 +315,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       o.start = 0;
       o.count = 0;
       o.pad = 0;
-      uint8_t near;
-      if (refresh) {
-        // vessel.py:266-273: Point.distance(boundary) - width < range (filled: 0 inside)
-        // The boundary lies inside the obstacle's enclosing circle (c, rho), so
-        //   |p0 - c| - rho <= distance(p0, boundary) <= |p0 - c| + rho ;
-        // only obstacles the two bounds cannot classify need the exact distance (same answer,
-        // far fewer segment loops).  1e-9 m of slack keeps rounding on the exact side.
-        double cx, cy, rho;
-        if (mover) {
-          double4 c4 = L.mvcull[meta.w];
-          cx = c4.x, cy = c4.y, rho = c4.z;
-        } else {
-          cx = scx, cy = scy, rho = srho;
-        }
-        const double dc = sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy));
-        if (dc - rho - W >= R + 1e-9) {
-          near = 0;
-        } else if (dc + rho - W < R - 1e-9) {
-          near = 1;
-        } else {
-          bool in = false;
-          if (meta.x != AUV_OBS_RING)
-            in = mover ? point_in_polygon(px, py, L.mvseg + o.seg_off, meta.z)
-                       : point_in_polygon(px, py, d.seg + meta.y, meta.z);
-          const double dist = in ? 0.0
-                                 : (mover ? point_boundary_distance(px, py, L.mvseg + o.seg_off, meta.z)
-                                          : point_boundary_distance(px, py, d.seg + meta.y, meta.z));
-          near = (dist - W < R) ? 1 : 0;
-        }
-        d.nearby[(size_t)e * d.k_max + k] = near;
-      } else {
-        near = d.nearby[(size_t)e * d.k_max + k];
-      }
+      const uint8_t near = d.nearby[(size_t)e * d.k_max + k];
       int2 lim = make_int2(INT32_MIN, INT32_MIN);
       if (near) {
         int start, stop;
