@@ -96,6 +96,41 @@ static void free_pool(std::vector<void*>& pool) {
   pool.clear();
 }
 
+// Winding of a closed boundary if rays from outside can only first-hit its front-facing edges
+// (true for any simple ring): +1 counter-clockwise, -1 clockwise, 0 = leave every edge in
+// (open, degenerate, self-touching or too long to check).  K2 then skips the back-facing half of
+// an obstacle's edges; see k2_lidar.hip, phase S.
+static int ring_winding(const double* seg, int nseg) {
+  if (nseg < 3 || nseg > 256) return 0;
+  double area2 = 0.0, scale = 0.0;
+  for (int i = 0; i < nseg; i++) {
+    const double* a = seg + 4 * (size_t)i;
+    const double* b = seg + 4 * (size_t)((i + 1) % nseg);
+    if (a[2] != b[0] || a[3] != b[1]) return 0;                   // not a closed chain
+    area2 += a[0] * a[3] - a[2] * a[1];
+    const double m = fabs(a[0]) + fabs(a[1]);
+    if (m > scale) scale = m;
+  }
+  if (!(fabs(area2) > 1e-9 * (1.0 + scale * scale))) return 0;
+  auto orient = [](const double* p, const double* q, const double* r) {
+    return (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0]);
+  };
+  const double tol = 1e-12 * (1.0 + scale * scale);
+  for (int i = 0; i < nseg; i++) {
+    const double* a = seg + 4 * (size_t)i;
+    if (a[0] == a[2] && a[1] == a[3]) return 0;                   // zero-length edge
+    for (int j = i + 2; j < nseg; j++) {
+      if (i == 0 && j == nseg - 1) continue;                       // neighbours through the closure
+      const double* b = seg + 4 * (size_t)j;
+      const double o1 = orient(a, a + 2, b), o2 = orient(a, a + 2, b + 2);
+      const double o3 = orient(b, b + 2, a), o4 = orient(b, b + 2, a + 2);
+      const bool apart = (o1 > tol && o2 > tol) || (o1 < -tol && o2 < -tol) || (o3 > tol && o4 > tol) || (o3 < -tol && o4 < -tol);
+      if (!apart) return 0;                                        // crossing or touching: not simple
+    }
+  }
+  return area2 > 0.0 ? 1 : -1;
+}
+
 // Second half of loading / generating a world bank: environment buffers sized for the bank,
 // the per-world reset rows, and the initial binding env e -> world e % W.
 static int finish_bank(auv_handle* h, bool alloc_env) {
@@ -336,7 +371,18 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   rc |= dev_upload(bp, &d.knot_coef, b->knot_coef, (size_t)nK * 8);
   rc |= dev_upload(bp, &d.world_scalar, b->world_scalar, (size_t)W * 8);
   rc |= dev_upload(bp, &d.obs_off, b->obs_off, (size_t)W + 1);
-  rc |= dev_upload(bp, &d.obs_meta, b->obs_meta, (size_t)nO);
+  {
+    // static obstacles: note the winding of simple rings in meta.w (-1 none, -2 CCW, -3 CW); the
+    // caller's meta.w is -1 for them and stays the mover index for movers
+    std::vector<int32_t> meta(b->obs_meta, b->obs_meta + 4 * (size_t)nO);
+    for (int64_t k = 0; k < nO; k++) {
+      int32_t* m = meta.data() + 4 * k;
+      if (m[0] == AUV_OBS_MOVER) continue;
+      const int wind = ring_winding(b->seg + 4 * (size_t)m[1], m[2]);
+      m[3] = wind > 0 ? -2 : (wind < 0 ? -3 : -1);
+    }
+    rc |= dev_upload(bp, &d.obs_meta, (const int4*)meta.data(), (size_t)nO);
+  }
   rc |= dev_upload(bp, &d.obs_cull, b->obs_cull, (size_t)nO * 3);
   rc |= dev_upload(bp, &d.seg, b->seg, (size_t)b->n_seg);
   rc |= dev_upload(bp, &d.mv_off, b->mv_off, (size_t)W + 1);

@@ -39,7 +39,7 @@ struct ObsLds {        // per-obstacle scratch in LDS (24 B)
   int nseg;
   int start;           // first ray index of the window (may be negative, > -2S)
   int count;           // number of rays in the window (0 = culled / not nearby)
-  int pad;
+  int wind;            // +1 / -1: simple ring, counter-clockwise / clockwise (back faces skipped); 0: keep all edges
 };
 
 struct EnvHdr {        // head of each wave's LDS slice: what the pair sweep needs to know
@@ -314,7 +314,13 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       o.nseg = meta.z;
       o.start = 0;
       o.count = 0;
-      o.pad = 0;
+      o.wind = mover ? -1 : (meta.w == -2 ? 1 : (meta.w == -3 ? -1 : 0));   // mover pentagon: clockwise
+      // a ring is hollow: from inside, every edge is seen from behind and all of them count.  Its
+      // cull circle is its circumcircle, so strictly outside that circle is strictly outside the ring.
+      if (meta.x == AUV_OBS_RING) {
+        const double rx = scx - px, ry = scy - py;
+        if (!(rx * rx + ry * ry > srho * srho * (1.0 + 1e-9))) o.wind = 0;
+      }
       const uint8_t near = d.nearby[(size_t)e * d.k_max + k];
       int2 lim = make_int2(INT32_MIN, INT32_MIN);
       if (near) {
@@ -448,7 +454,15 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
       const double wx = s.x - px, wy = s.y - py, sx = s.z - s.x, sy = s.w - s.y;
       L.stage[t] = make_double4(wx, wy, sx, sy);
       L.owner[t] = (unsigned short)a;
-      {
+      // A ray from outside a simple closed boundary first meets it on an edge that faces p0, and
+      // only the first meeting matters (min t; p0 inside is handled through the predicates below),
+      // so an edge seen from behind gets no work items.  tn = cross(a - p0, b - a) tells the side;
+      // edges p0 (nearly) lies on the line of stay in.
+      const double tn_side = wx * sy - wy * sx;
+      const bool back_face = (o.wind > 0 && tn_side > 1e-9) || (o.wind < 0 && tn_side < -1e-9);
+      if (back_face) {
+        L.span[t] = make_short2(0, 0);
+      } else {
         // conservative range of ray indices this segment can be hit by: the rays between the
         // bearings of its end points (shorter arc; a segment subtends < pi from any point off
         // its line), fp32 trigonometry, rays of slack on both sides (fp32 error ~1e-5 rays)

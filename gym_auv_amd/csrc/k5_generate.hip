@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) k5_generate(GenOut g, const double* __res
         if (ri >= g.n_radius) ri = g.n_radius - 1;
         const int nseg = g.nseg_by_radius[ri];
         const size_t so = (size_t)w * g.g_cap + (size_t)c * 64;
-        g.obs_meta[ko] = make_int4(AUV_OBS_RING, (int)so, nseg, -1);
+        g.obs_meta[ko] = make_int4(AUV_OBS_RING, (int)so, nseg, -3);   // -3: simple ring, clockwise (GEOS buffer order)
         g.obs_cull[3 * ko] = px, g.obs_cull[3 * ko + 1] = py, g.obs_cull[3 * ko + 2] = radius;
         // ring of the GEOS buffer, thinned to nseg segments (obstacles.py:101-106)
         const int stride = 64 / nseg;

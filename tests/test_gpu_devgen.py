@@ -65,7 +65,8 @@ def test_generated_tables_match_host_builder(nm, ns, seed):
             hm = hw.obs_meta
             np.testing.assert_array_equal(meta[w, :K, 0], hm[:, 0])
             np.testing.assert_array_equal(meta[w, :K, 2], hm[:, 2])
-            np.testing.assert_array_equal(meta[w, :K, 3], hm[:, 3])
+            # movers: index within the world; circles: -3 = simple clockwise ring (back-face flag set on the device)
+            np.testing.assert_array_equal(meta[w, :K, 3], np.where(hm[:, 0] == 0, -3, hm[:, 3]))
             np.testing.assert_allclose(cull[w, :K], hw.obs_cull, rtol=0, atol=1e-9)
             for k in range(ns):
                 so = meta[w, k, 1] - w * seg.shape[1]          # absolute slot offset -> world-relative
