@@ -94,6 +94,7 @@ __device__ __forceinline__ double point_boundary_distance(double px, double py, 
 }
 
 #define K2_SEG_CAP 96    // staged segments per wave and batch (slice <= 10 KiB -> 16 waves per CU)
+#define K2_RAW_CAP 192   // boundary segments looked at per batch; only the front-facing ones are staged
 #define K2_ITEM_RAYS 8    // rays per work item of the pair sweep
 
 // per-wave LDS slice (decreasing alignment):
@@ -427,8 +428,8 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 #endif
   for (int a0 = 0; a0 < n_act;) {
     const int base0 = L.sbase[a0];
-    if (L.sbase[a0 + 1] - base0 > K2_SEG_CAP) {
-      // a single boundary larger than the stage (never a circle or a mover): sweep it from HBM
+    if (L.sbase[a0 + 1] - base0 > K2_RAW_CAP) {
+      // a single boundary larger than a batch (never a circle or a mover): sweep it from HBM
       const ObsLds o = L.obs[L.act[a0]];
       const double4* g = d.seg + o.seg_off;
       if (o.kind != AUV_OBS_RING && inside_flag_wave(px, py, g, o.nseg, lane) != 0) {
@@ -440,67 +441,93 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
       continue;
     }
     int a1 = a0 + 1;
-    while (a1 < n_act && L.sbase[a1 + 1] - base0 <= K2_SEG_CAP) a1++;
-    const int T = L.sbase[a1] - base0;
+    while (a1 < n_act && L.sbase[a1 + 1] - base0 <= K2_RAW_CAP) a1++;
+    const int T_raw = L.sbase[a1] - base0;
 
-    // ---- phase S: one flattened, coalesced pass over the batch's boundary segments ----
+    // ---- phase S: one flattened, coalesced pass over the batch's boundary segments; the ones that
+    //      face p0 are compacted into the stage ----
     SUB_T0()
-    for (int t = lane; t < T; t += AUV_WAVE) {
+    int T = 0;                                             // staged segments
+    for (int tb = 0; tb < T_raw; tb += AUV_WAVE) {
+      const int t = tb + lane;
+      bool keep = false;
       int a = a0;
-      while (t + base0 >= L.sbase[a + 1]) a++;
-      const ObsLds o = L.obs[L.act[a]];
-      const int si = t + base0 - L.sbase[a];
-      const double4 s = (o.kind == AUV_OBS_MOVER) ? L.mvseg[o.seg_off + si] : d.seg[o.seg_off + si];
-      const double wx = s.x - px, wy = s.y - py, sx = s.z - s.x, sy = s.w - s.y;
-      L.stage[t] = make_double4(wx, wy, sx, sy);
-      L.owner[t] = (unsigned short)a;
-      // A ray from outside a simple closed boundary first meets it on an edge that faces p0, and
-      // only the first meeting matters (min t; p0 inside is handled through the predicates below),
-      // so an edge seen from behind gets no work items.  tn = cross(a - p0, b - a) tells the side;
-      // edges p0 (nearly) lies on the line of stay in.
-      const double tn_side = wx * sy - wy * sx;
-      const bool back_face = (o.wind > 0 && tn_side > 1e-9) || (o.wind < 0 && tn_side < -1e-9);
-      if (back_face) {
-        L.span[t] = make_short2(0, 0);
-      } else {
-        // conservative range of ray indices this segment can be hit by: the rays between the
-        // bearings of its end points (shorter arc; a segment subtends < pi from any point off
-        // its line), fp32 trigonometry, rays of slack on both sides (fp32 error ~1e-5 rays)
-        const float ax = (float)wx, ay = (float)wy, bx = (float)(s.z - px), by = (float)(s.w - py);
-        short2 sp;
-        if ((fabsf(ax) + fabsf(ay) < 1e-6f) || (fabsf(bx) + fabsf(by) < 1e-6f)) {
-          sp = make_short2(0, (short)S);                         // p0 (almost) on an end point: all rays
+      ObsLds o;
+      double4 wv = make_double4(0.0, 0.0, 0.0, 0.0);
+      short2 sp = make_short2(0, 0);
+      if (t < T_raw) {
+        while (t + base0 >= L.sbase[a + 1]) a++;
+        o = L.obs[L.act[a]];
+        const int si = t + base0 - L.sbase[a];
+        const double4 s = (o.kind == AUV_OBS_MOVER) ? L.mvseg[o.seg_off + si] : d.seg[o.seg_off + si];
+        const double wx = s.x - px, wy = s.y - py, sx = s.z - s.x, sy = s.w - s.y;
+        wv = make_double4(wx, wy, sx, sy);
+        // A ray from outside a simple closed boundary first meets it on an edge that faces p0, and
+        // only the first meeting matters (min t; p0 inside is handled through the predicates below),
+        // so an edge seen from behind is not staged.  tn = cross(a - p0, b - a) tells the side;
+        // edges p0 (nearly) lies on the line of stay in.
+        const double tn_side = wx * sy - wy * sx;
+        keep = !((o.wind > 0 && tn_side > 1e-9) || (o.wind < 0 && tn_side < -1e-9));
+        if (keep) {
+          // conservative range of ray indices this segment can be hit by: the rays between the
+          // bearings of its end points (shorter arc; a segment subtends < pi from any point off
+          // its line), fp32 trigonometry, rays of slack on both sides (fp32 error ~1e-5 rays)
+          const float ax = (float)wx, ay = (float)wy, bx = (float)(s.z - px), by = (float)(s.w - py);
+          if ((fabsf(ax) + fabsf(ay) < 1e-6f) || (fabsf(bx) + fabsf(by) < 1e-6f)) {
+            sp = make_short2(0, (short)S);                         // p0 (almost) on an end point: all rays
+          } else {
+            const float PI_F = 3.14159265358979f;
+            const float ta = atan2f(ay, ax), tb2 = atan2f(by, bx);
+            float dl = tb2 - ta;
+            if (dl > PI_F) dl -= 2.0f * PI_F;
+            if (dl <= -PI_F) dl += 2.0f * PI_F;
+            const float ts = dl >= 0.0f ? ta : tb2;
+            const float inv_da = (float)S / (2.0f * PI_F);
+            const float f = (ts - (float)psi + PI_F) * inv_da - 1.0f;   // fractional ray index of the arc start
+            const int n = (int)ceilf(fabsf(dl) * inv_da) + 4;
+            const int klo = ((int)floorf(f) - 1) % S;               // any representative; wrapped per ray
+            sp = make_short2((short)klo, (short)(n > S ? S : n));
+          }
+        }
+        if (o.kind != AUV_OBS_RING) {
+          // point-in-polygon predicates of this boundary segment (same tests as point_in_polygon)
+          const double dxa = px - s.x, dya = py - s.y;
+          const double len2 = sx * sx + sy * sy;
+          const double dot = dxa * sx + dya * sy;
+          bool on;
+          if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
+          else if (dot >= len2) on = (px == s.z && py == s.w);
+          else on = ((s.y - py) * sx - (s.x - px) * sy) == 0.0;
+          if (on) atomicOr(&L.par[a], 2);
+          if ((s.y > py) != (s.w > py)) {
+            const double xint = s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
+            if (px < xint) atomicXor(&L.par[a], 1);
+          }
+        }
+      }
+      const unsigned long long kmask = __ballot(keep);
+      const int pos = T + __popcll(kmask & ((1ull << lane) - 1ull));
+      if (keep) {
+        if (pos < K2_SEG_CAP) {
+          L.stage[pos] = wv;
+          L.owner[pos] = (unsigned short)a;
+          L.span[pos] = sp;
         } else {
-          const float PI_F = 3.14159265358979f;
-          const float ta = atan2f(ay, ax), tb = atan2f(by, bx);
-          float dl = tb - ta;
-          if (dl > PI_F) dl -= 2.0f * PI_F;
-          if (dl <= -PI_F) dl += 2.0f * PI_F;
-          const float ts = dl >= 0.0f ? ta : tb;
-          const float inv_da = (float)S / (2.0f * PI_F);
-          const float f = (ts - (float)psi + PI_F) * inv_da - 1.0f;   // fractional ray index of the arc start
-          const int n = (int)ceilf(fabsf(dl) * inv_da) + 4;
-          const int klo = ((int)floorf(f) - 1) % S;               // any representative; wrapped per ray
-          sp = make_short2((short)klo, (short)(n > S ? S : n));
-        }
-        L.span[t] = sp;
-      }
-      if (o.kind != AUV_OBS_RING) {
-        // point-in-polygon predicates of this boundary segment (same tests as point_in_polygon)
-        const double dxa = px - s.x, dya = py - s.y;
-        const double len2 = sx * sx + sy * sy;
-        const double dot = dxa * sx + dya * sy;
-        bool on;
-        if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
-        else if (dot >= len2) on = (px == s.z && py == s.w);
-        else on = ((s.y - py) * sx - (s.x - px) * sy) == 0.0;
-        if (on) atomicOr(&L.par[a], 2);
-        if ((s.y > py) != (s.w > py)) {
-          const double xint = s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
-          if (px < xint) atomicXor(&L.par[a], 1);
+          // (rare) more front-facing segments than the stage holds: this lane sweeps its own
+          const double tn = wv.x * wv.w - wv.y * wv.z;
+          const bool all = o.count >= S;
+          const int start_w = wrap_ray(o.start, S);
+          for (int j = 0; j < sp.y; j++) {
+            const int r = wrap_ray(sp.x + j, S);
+            int x = r - start_w;
+            if (x < 0) x += S;
+            if (all || x < o.count) test_pair(wv, tn, L.rayv[r], &L.dbits[r]);
+          }
         }
       }
+      T += __popcll(kmask);
     }
+    if (T > K2_SEG_CAP) T = K2_SEG_CAP;
     auv_wave_lds_sync();
     SUB_ADD(c_stage)
 
