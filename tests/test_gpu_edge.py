@@ -113,3 +113,20 @@ def test_vessel_on_top_of_obstacle_centres():
     # (vessel.py:266), so most of these overlaps only register after the refresh
     env, _ = _run(_cfg(), [w], 6, steps=30, poses=poses, auto_reset=False)
     assert _np(env.read("EPISODE"))[:, 2].sum() >= 2          # those starts end in collisions
+
+
+@pytest.mark.parametrize("cull", ["reference", "exact"])
+def test_more_front_facing_segments_than_the_stage_holds(cull):
+    """Vessel inside three nested 64-gon rings (hollow: every edge counts from inside) plus polygons
+    around it: one batch of 192 boundary segments of which far more than the 96 the LDS stage holds
+    are kept, so the overflow lanes sweep their own segments; and a vessel just outside the rings,
+    where half of each ring is back-facing."""
+    wp = np.array([[0.0, 400.0], [0.0, 0.0]])
+    circles = np.array([[5.0, 3.0, 70.0], [4.0, -2.0, 90.0], [-3.0, 1.0, 110.0], [160.0, 40.0, 64.0]])
+    rs = np.random.RandomState(4)
+    polys = [sc._star_polygon(rs, np.array([60.0 * np.cos(a), 60.0 * np.sin(a)]), 12.0, 9) for a in (0.3, 2.0, 4.1)]
+    spec = WorldSpec(waypoints=wp, vessel_init=np.array([0.0, 0.0, 0.3]), circles=circles, polygons=polys)
+    poses = [[0.0, 0.0, 0.3], [2.0, 1.0, -2.0], [125.0, 5.0, 3.0], [-118.0, -9.0, 0.1], [5.0, 3.0, 1.0]]
+    env, ora = _run(_cfg(max_timesteps=1000), [spec], len(poses), steps=12, poses=poses, cull=cull, auto_reset=False)
+    d = ora.read("LIDAR_D")
+    assert (d[0] < 150).all()          # inside the rings every beam returns
