@@ -24,6 +24,7 @@ void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world
 void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
 void auv_launch_ring_advance(const AuvDev& d, hipStream_t st);
 void auv_launch_refresh_desc(const AuvDev& d, hipStream_t st);
+void auv_launch_derive(const AuvDev& d, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
 hipError_t auv_k2_prepare(const AuvDev& d);
 bool auv_step_fused_ok(const AuvDev& d);
@@ -171,6 +172,8 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     }
     rc |= dev_upload(ep, &d.beam_cs, bcs.data(), S ? S : 1);
   }
+  rc |= dev_alloc(ep, &d.beam_w, S ? S : 1);
+  rc |= dev_alloc(ep, &d.derived, 4);
   d.ring_slots = 1;
   d.ring_slot_host = -1;
   rc |= dev_alloc(ep, &d.w_obs64, (size_t)W * (6 + S));
@@ -183,6 +186,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   if (rc) return AUV_EHIP;
   }
   d.w_ready = 0;
+  auv_launch_derive(d, nullptr);
   std::vector<int32_t> wi(n);
   if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
   HIP_TRY(auv_k2_prepare(d));

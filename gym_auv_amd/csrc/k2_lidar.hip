@@ -617,13 +617,12 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
   const int S = d.cfg.n_sensors;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   int col = 0;
-  const double logR = log(1 + R);
+  const double logR = d.derived[0];                        // log(1 + R)
   const double px = L.hdr->px, py = L.hdr->py;
   const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
-  const double dangle = 2 * AUV_PI / S;
-  const double raw_free = R * exp(-0.1 * R);
+  const double raw_free = d.derived[1];                    // R exp(-0.1 R)
   const int D = 6 + S * (d.cfg.obs_channels == 3 ? 3 : 1);   // row stride of obs_out (use_lidar is on here)
-  double num = 0.0, den = 0.0;
+  double num = 0.0;
   for (int i = lane; i < S; i += AUV_WAVE) {
     const double t = u2d(L.dbits[i]);
     double di = R;                                          // sensor.py:156
@@ -647,21 +646,15 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
     if (colav) {
       double raw = raw_free;
       if (__any(di != R)) raw = R * exp(-0.1 * di);         // gamma_x
-      const double angle = -AUV_PI + (i + 1) * dangle;      // body-frame beam angle (vessel.py:66-68)
-      const double weight = 1 / (1 + fabs(10.0 * angle));    // gamma_theta
-      num += weight * raw;
-      den += weight;
+      num += d.beam_w[i] * raw;                             // gamma_theta from the per-config table
     }
     col |= (di < W);
   }
   col = __any(col);
-  if (colav) {
-    num = auv_wave_sum(num);
-    den = auv_wave_sum(den);
-  }
+  if (colav) num = auv_wave_sum(num);
   if (lane == 0) {
     d.collision[e] = (uint8_t)(col != 0);
-    if (colav) d.rew_lidar[e] = (S > 0) ? -num / den : 0.0;
+    if (colav) d.rew_lidar[e] = (S > 0) ? -num / d.derived[2] : 0.0;
   }
   return col != 0;
 }

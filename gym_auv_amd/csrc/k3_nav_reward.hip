@@ -90,26 +90,40 @@ __device__ __forceinline__ double reward_path_term(const AuvDev& d, double u, do
 // same arithmetic, lane assignment and summation order as the fused form at the end of K2
 __device__ __forceinline__ double reward_lidar_term_wave(const AuvDev& d, const double* __restrict__ dd, int lane) {
   const int S = d.cfg.n_sensors;
-  const double dangle = 2 * AUV_PI / S;
   const double R = d.cfg.sensor_range;
-  const double raw_free = R * exp(-0.1 * R);
-  double num = 0.0, den = 0.0;
+  const double raw_free = d.derived[1];
+  double num = 0.0;
   for (int i0 = 0; i0 < S; i0 += AUV_WAVE) {
     const int i = i0 + lane;
     const double di = (i < S) ? dd[i] : R;
     double raw = raw_free;
     if (__any(di != R)) raw = R * exp(-0.1 * di);       // gamma_x; velocity channel == 0 (sensor.py:159)
-    if (i < S) {
-      double angle = -AUV_PI + (i + 1) * dangle;        // body-frame beam angle (vessel.py:66-68)
-      double weight = 1 / (1 + fabs(10.0 * angle));      // gamma_theta
-      num += weight * raw;
-      den += weight;
-    }
+    if (i < S) num += d.beam_w[i] * raw;                // gamma_theta
   }
   num = auv_wave_sum(num);
-  den = auv_wave_sum(den);
-  return (S > 0) ? -num / den : 0.0;
+  return (S > 0) ? -num / d.derived[2] : 0.0;
 }
+
+#ifndef AUV_DEVICE_FUNCS_ONLY
+// per-config constants, formed once on the device with the very functions the step would use:
+// gamma_theta of every beam (vessel.py:66-68, rewarder.py:205-222), their sum in the wave-reduction
+// order, log(1 + R) and R exp(-0.1 R)
+__global__ void k_derive(AuvDev d) {
+  const int lane = threadIdx.x;
+  const int S = d.cfg.n_sensors;
+  const double dangle = 2 * AUV_PI / S;
+  const double R = d.cfg.sensor_range;
+  double den = 0.0;
+  for (int i = lane; i < S; i += AUV_WAVE) {
+    const double angle = -AUV_PI + (i + 1) * dangle;
+    const double weight = 1 / (1 + fabs(10.0 * angle));
+    d.beam_w[i] = weight;
+    den += weight;
+  }
+  den = auv_wave_sum(den);
+  if (lane == 0) d.derived[0] = log(1 + R), d.derived[1] = R * exp(-0.1 * R), d.derived[2] = den, d.derived[3] = 0.0;
+}
+#endif
 
 // restore reset-time state of env e bound to world w2 (environment.py:203-245, vessel.py:189-224).
 // The reset observation (navigate + perceive at the initial pose) is a per-world constant that
@@ -510,6 +524,8 @@ __global__ void k_ring_advance(AuvDev d) {
   if (threadIdx.x == 0 && d.ring_slots > 1) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
 }
 }  // namespace
+
+void auv_launch_derive(const AuvDev& d, hipStream_t st) { hipLaunchKernelGGL(k_derive, dim3(1), dim3(AUV_WAVE), 0, st, d); }
 
 void auv_launch_refresh_desc(const AuvDev& d, hipStream_t st) {
   hipLaunchKernelGGL(k_refresh_desc, dim3((d.n + 255) / 256), dim3(256), 0, st, d);
