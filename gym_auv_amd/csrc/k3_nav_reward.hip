@@ -50,28 +50,56 @@ __device__ __forceinline__ MinIdx wave_min_first(MinIdx v) {
   return v;
 }
 
-// SciPy PPoly: interval search (knots are near-uniform: guess then walk) + power-basis eval
-__device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk, double s, double L, double xy[2],
-                                          double dxy[2]) {
+// SciPy PPoly: interval search + power-basis eval.  The knots are near-uniform, so the interval
+// is guessed from s / L and the knots and coefficient rows around the guess are fetched together
+// (one trip to memory); only a guess that is off by more than one interval walks and re-fetches.
+// x0 / xl: the first / last knot, fetched by the caller ahead of time.
+__device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk, double x0, double xl, double s,
+                                          double L, double xy[2], double dxy[2]) {
   const double* x = d.knot_s + k0;
+  const double* cf = d.knot_coef + 8 * k0;
   int i;
-  if (!(s >= x[0])) {
+  double xi;
+  double c[8];
+  bool have = false;
+  if (!(s >= x0)) {
     i = 0;
-  } else if (s >= x[nk - 1]) {
+  } else if (s >= xl) {
     i = nk - 2;
   } else {
     i = (int)(s / L * (nk - 1));
     i = i < 0 ? 0 : (i > nk - 2 ? nk - 2 : i);
-    while (i > 0 && s < x[i]) i--;
-    while (i < nk - 2 && s >= x[i + 1]) i++;
+    if (nk >= 4) {
+      const int g = i < 1 ? 1 : (i > nk - 3 ? nk - 3 : i);       // window [g-1, g+2] inside the table
+      const double xa = x[g - 1], xb = x[g], xc = x[g + 1], xd = x[g + 2];
+      double ca[8], cb8[8], cc[8];
+#pragma unroll
+      for (int a = 0; a < 8; a++) ca[a] = cf[8 * (size_t)(g - 1) + a], cb8[a] = cf[8 * (size_t)g + a], cc[a] = cf[8 * (size_t)(g + 1) + a];
+      if (s >= xa && s < xd) {
+        // the interval [x_i, x_{i+1}) containing s is one of the three fetched
+        const int sel = (s < xb) ? 0 : (s < xc ? 1 : 2);
+        xi = sel == 0 ? xa : (sel == 1 ? xb : xc);
+#pragma unroll
+        for (int a = 0; a < 8; a++) c[a] = sel == 0 ? ca[a] : (sel == 1 ? cb8[a] : cc[a]);
+        have = true;
+      }
+    }
+    if (!have) {
+      while (i > 0 && s < x[i]) i--;
+      while (i < nk - 2 && s >= x[i + 1]) i++;
+    }
   }
-  const double* c = d.knot_coef + 8 * (k0 + i);
-  const double z = s - x[i], z2 = z * z;
+  if (!have) {
+    xi = x[i];
+#pragma unroll
+    for (int a = 0; a < 8; a++) c[a] = cf[8 * (size_t)i + a];
+  }
+  const double z = s - xi, z2 = z * z;
 #pragma unroll
   for (int a = 0; a < 2; a++) {
-    const double* ca = c + 4 * a;
-    xy[a] = ((ca[3] + ca[2] * z) + ca[1] * z2) + ca[0] * (z2 * z);
-    dxy[a] = (ca[2] + (2.0 * ca[1]) * z) + (3.0 * ca[0]) * z2;
+    const double* q = c + 4 * a;
+    xy[a] = ((q[3] + q[2] * z) + q[1] * z2) + q[0] * (z2 * z);
+    dxy[a] = (q[2] + (2.0 * q[1]) * z) + (3.0 * q[0]) * z2;
   }
 }
 
@@ -191,6 +219,13 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   double* ob = d.obs64 + (size_t)e * (6 + S);
   const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
 
+  // operands of the scalar tail, requested now so that their trip to memory overlaps the polyline search
+  const double knot_first = d.knot_s[ed.kn0], knot_last = d.knot_s[ed.kn0 + ed.nk - 1];
+  const double goal_x = ws[1], goal_y = ws[2];
+  const double maxp_in = inf[5];
+  const double u = pre ? pre->s[3] : d.state[3 * n + e], v = pre ? pre->s[4] : d.state[4 * n + e],
+               r = pre ? pre->s[5] : d.state[5 * n + e];
+
   AUV_STAMP_DECL
   // ---- nearest point on the dense polyline (path.py:84-93), exact with chunk pruning ----
   const long long p0 = ed.p0;
@@ -257,29 +292,38 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   MinIdx best;
   best.d = 1.7976931348623157e308;
   best.j = 0x7fffffff;
+  double2 bA = make_double2(0.0, 0.0), bB = bA;        // end points of this lane's best segment
   for (int a = 0; a < n_act; a++) {
     const int j = list[a] * AUV_CHUNK + lane;
     if (j < P - 1) {
       double2 A = xy[j], B = xy[j + 1];
       double dd = auv_pt_seg_dist(px, py, A.x, A.y, B.x, B.y);
-      if (dd < best.d) best.d = dd, best.j = j;
+      if (dd < best.d) best.d = dd, best.j = j, bA = A, bB = B;
     }
   }
+  // cumulative length at this lane's candidate, requested while the reduction runs
+  const int my_j = best.j;
+  const double my_cum = d.poly_cum[p0 + (my_j < P - 1 ? my_j : 0)];
   best = wave_min_first(best);
   AUV_STAMP()
   const int bj = best.j;
+  // the winning lane hands over its segment (no second trip to memory)
+  const unsigned long long wmask = __ballot(my_j == bj);
+  const int src = wmask ? __ffsll((long long)wmask) - 1 : 0;
+  double2 A, B;
+  A.x = __shfl(bA.x, src, AUV_WAVE), A.y = __shfl(bA.y, src, AUV_WAVE);
+  B.x = __shfl(bB.x, src, AUV_WAVE), B.y = __shfl(bB.y, src, AUV_WAVE);
+  const double cum = __shfl(my_cum, src, AUV_WAVE);
   // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure (all lanes, uniform)
-  double2 A = xy[bj], B = xy[bj + 1];
   double dx = B.x - A.x, dy = B.y - A.y, len2 = dx * dx + dy * dy;
   double seglen = sqrt(len2);
   double pf = (len2 == 0.0) ? 0.0 : ((px - A.x) * dx + (py - A.y) * dy) / len2;
-  double cum = d.poly_cum[p0 + bj];
   const double s = pf <= 0.0 ? cum : (pf <= 1.0 ? cum + pf * seglen : cum + seglen);
   double s_t = s + d.cfg.look_ahead_distance;
   if (L < s_t) s_t = L;
   // vessel.py:471-515 -- lane 0 evaluates the spline at s, lane 1 at s_t (same instructions)
   double p[2], dp[2];
-  path_eval(d, ed.kn0, ed.nk, lane == 1 ? s_t : s, L, p, dp);
+  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, lane == 1 ? s_t : s, L, p, dp);
   double dir = atan2(dp[1], dp[0]);                       // lane 0: chi; lane 1: look-ahead direction
   double tgt = atan2(p[1] - py, p[0] - px);               // lane 1: target heading
   const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(tgt, 1, AUV_WAVE);
@@ -292,13 +336,11 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
     double la = auv_princip(la_dir - psi);
     double he = auv_princip(tgt1 - psi);
     double progress = s / L;
-    double maxp = inf[5];
+    double maxp = maxp_in;
     if (progress > maxp) maxp = progress;
-    double gx = ws[1] - px, gy = ws[2] - py;
+    double gx = goal_x - px, gy = goal_y - py;
     double goal = sqrt(gx * gx + gy * gy);
     int reached = (goal <= d.cfg.min_goal_distance) || (progress >= d.cfg.min_path_progress);
-    double u = pre ? pre->s[3] : d.state[3 * n + e], v = pre ? pre->s[4] : d.state[4 * n + e],
-           r = pre ? pre->s[5] : d.state[5 * n + e];
     nv[0] = u, nv[1] = v, nv[2] = r, nv[3] = la, nv[4] = he, nv[5] = cte / 100, nv[6] = chi, nv[7] = s_t;
     inf[1] = reached, inf[2] = goal, inf[3] = progress, inf[5] = maxp, inf[6] = s, inf[7] = 0.0;
     // path-following term of the reward: everything it needs is at hand here, so the
