@@ -73,10 +73,11 @@ def algorithmic_bytes(bank, cfg_S, world_of_env):
     S = float(cfg_S)
     n = len(world_of_env)
     k1 = 144.0 * n
-    lidar = (32.0 * G + 24.0 * K + 16.0 * K + 24.0 + 16.0 * S + K).sum()        # SURVEY 8(d) formula, 32-B segments
+    # SURVEY 8(d) formula, 32-B segments; + the float32 closeness columns, which K2 now emits itself
+    lidar = (32.0 * G + 24.0 * K + 16.0 * K + 24.0 + 16.0 * S + K + 4.0 * S).sum()
     nch = np.ceil((P - 1) / 64.0)
     nav = (32.0 * nch + 3 * 65 * 16.0 + 600.0).sum()                            # chunk circles + ~3 surviving chunks + knots/scalars
-    reward = (8.0 * S + 8.0 * S + 4.0 * (6 + S) + 300.0) * n                    # d in, closeness in, obs f32 out, bookkeeping
+    reward = 300.0 * n                                                          # two reward terms, nav/info rows, counters, outputs
     return dict(k1_dynamics=k1, k23_lidar_nav=float(lidar + nav), k3_reward=float(reward),
                 lidar_part=float(lidar), nav_part=float(nav), nav_bruteforce=float((16.0 * P).sum()))
 

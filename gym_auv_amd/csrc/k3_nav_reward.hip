@@ -188,6 +188,37 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
     for (int k = lane; k < d.k_max; k += AUV_WAVE) d.nearby[(size_t)e * d.k_max + k] = 0;
     return;
   }
+  if (6 + S <= 4 * AUV_WAVE && d.k_max <= AUV_WAVE) {
+    // the usual shapes: every row fits four wave passes.  All loads are issued before the first
+    // store (the rows could alias as far as the compiler knows, so a load-store loop per row would
+    // cost one trip to memory per pass; the auto-reset sits on the reward kernel's critical path)
+    double lv[4], ov[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = q * AUV_WAVE + lane;
+      lv[q] = (i < S) ? d.w_lidar[(size_t)w2 * S + i] : 0.0;
+      ov[q] = (i < 6 + S) ? d.w_obs64[(size_t)w2 * (6 + S) + i] : 0.0;
+    }
+    double row = 0.0;
+    if (lane < 8) row = d.w_info[8 * (size_t)w2 + lane];
+    else if (lane < 16) row = d.w_nav[8 * (size_t)w2 + lane - 8];
+    uint8_t nb = 0;
+    int2 lm = make_int2(0, 0);
+    if (lane < d.k_max) nb = d.w_nearby[(size_t)w2 * d.k_max + lane], lm = d.w_limits[(size_t)w2 * d.k_max + lane];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = q * AUV_WAVE + lane;
+      if (i < S) d.lidar_d[(size_t)e * S + i] = lv[q];
+      if (i < 6 + S) {
+        d.obs64[(size_t)e * (6 + S) + i] = ov[q];
+        if (obs_out && i < DL) obs_out[(size_t)e * D + i] = (float)ov[q];
+      }
+    }
+    if (lane < 8) d.info64[8 * (size_t)e + lane] = row;
+    else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = row;
+    if (lane < d.k_max) d.nearby[(size_t)e * d.k_max + lane] = nb, d.limits[(size_t)e * d.k_max + lane] = lm;
+    return;
+  }
   for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.w_lidar[(size_t)w2 * S + i];
   for (int i = lane; i < 6 + S; i += AUV_WAVE) {
     const double v = d.w_obs64[(size_t)w2 * (6 + S) + i];
