@@ -352,12 +352,14 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   const double s = pf <= 0.0 ? cum : (pf <= 1.0 ? cum + pf * seglen : cum + seglen);
   double s_t = s + d.cfg.look_ahead_distance;
   if (L < s_t) s_t = L;
-  // vessel.py:471-515 -- lane 0 evaluates the spline at s, lane 1 at s_t (same instructions)
+  // vessel.py:471-515 -- lane 0 evaluates the spline at s, lanes 1 and 2 at s_t (same instructions);
+  // one atan2 then serves all three angles: lane 0 chi, lane 1 the look-ahead direction, lane 2
+  // the heading towards the look-ahead point
   double p[2], dp[2];
-  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, lane == 1 ? s_t : s, L, p, dp);
-  double dir = atan2(dp[1], dp[0]);                       // lane 0: chi; lane 1: look-ahead direction
-  double tgt = atan2(p[1] - py, p[0] - px);               // lane 1: target heading
-  const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(tgt, 1, AUV_WAVE);
+  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, lane == 0 ? s : s_t, L, p, dp);
+  const double ang_y = (lane == 2) ? p[1] - py : dp[1], ang_x = (lane == 2) ? p[0] - px : dp[0];
+  const double dir = atan2(ang_y, ang_x);
+  const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(dir, 2, AUV_WAVE);
   if (lane == 0) {
     const double chi = dir;
     double ddx = p[0] - px, ddy = p[1] - py;
