@@ -172,8 +172,8 @@ class BatchedAuvEnv:
         return self.obs, self.reward, self.done, self._lazy_info()
 
     def step_timed(self, actions: torch.Tensor):
-        """One step (default launch shape) with HIP events around each kernel; returns ms for
-        (K1, K2+K3-nav side by side, K3-reward, 0)."""
+        """One step (default launch shape), every dispatch stamped with its own start/stop HIP event;
+        returns ms for (K1, K2+K3-nav side by side, K3-reward, whole step first start..last stop)."""
         a, dt = self._act(actions)
         ms = (C.c_float * 4)()
         _check(_LIB.auv_step_timed(self._h, C.c_void_p(a.data_ptr()), dt, C.c_void_p(self.obs.data_ptr()),

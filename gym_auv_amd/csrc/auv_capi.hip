@@ -13,13 +13,15 @@
 #include "auv_device.h"
 #include "auv_generate.h"
 
-void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st);
+void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st, hipEvent_t ev0 = nullptr,
+                   hipEvent_t ev1 = nullptr);
 void auv_launch_k2(const AuvDev& d, int advance_movers, hipStream_t st);
 void auv_launch_k2_fresh(const AuvDev& d, hipStream_t st);
 void auv_launch_k3(const AuvDev& d, int mode, float* obs, float* reward, uint8_t* done, hipStream_t st);
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st);
 void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st);
-void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st);
+void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st,
+                          hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, float* obs, hipStream_t st);
 void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
 void auv_launch_ring_advance(const AuvDev& d, hipStream_t st);
@@ -29,7 +31,7 @@ size_t auv_k2_lds_bytes(const AuvDev& d);
 hipError_t auv_k2_prepare(const AuvDev& d);
 bool auv_step_fused_ok(const AuvDev& d);
 bool auv_k23_ok(const AuvDev& d);
-void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st);
+void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t auv_step_fused_prepare(const AuvDev& d);
 void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st);
@@ -735,26 +737,20 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
                    uint8_t* done_dev, void* stream, float* out_ms4) {
   REQUIRE_READY(h);
   if (!actions_dev || !out_ms4) return fail(AUV_EINVAL, "auv_step_timed: null argument");
+  if (!auv_k23_ok(h->d)) return fail(AUV_EINVAL, "auv_step_timed: path too long for the side-by-side launch");
   hipStream_t st = (hipStream_t)stream;
   for (auto& e : h->ev)
     if (!e) HIP_TRY(hipEventCreate(&e));
-  // the kernels of the default (side-by-side) step, each bracketed by events on `st`:
-  // K1 | K2 + K3-nav in one launch | K3-reward
-  HIP_TRY(hipEventRecord(h->ev[0], st));
-  auv_launch_k1(h->d, actions_dev, action_dtype, st);
-  HIP_TRY(hipEventRecord(h->ev[1], st));
-  if (auv_k23_ok(h->d)) {
-    auv_launch_k23(h->d, obs_dev, st);
-  } else {
-    auv_launch_k2(h->d, 1, st);
-    auv_launch_k3_nav(h->d, obs_dev, st);
-  }
-  HIP_TRY(hipEventRecord(h->ev[2], st));
-  auv_launch_k3_reward(h->d, obs_dev, reward_dev, done_dev, (auv_k23_ok(h->d) && h->d.cfg.use_lidar) ? 0 : 1, st);
-  HIP_TRY(hipEventRecord(h->ev[3], st));
-  HIP_TRY(hipEventRecord(h->ev[4], st));
-  HIP_TRY(hipEventSynchronize(h->ev[4]));
-  for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[i], h->ev[i + 1]));
+  // the kernels of the default (side-by-side) step, each dispatch stamped with its own start and
+  // stop event (hipExtLaunchKernel): K1 | K2 + K3-nav in one launch | K3-reward.  The elapsed times
+  // are the kernels' own durations, as a kernel trace reports them, without the gaps between them.
+  auv_launch_k1(h->d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
+  auv_launch_k23(h->d, obs_dev, st, h->ev[2], h->ev[3]);
+  auv_launch_k3_reward(h->d, obs_dev, reward_dev, done_dev, h->d.cfg.use_lidar ? 0 : 1, st, h->ev[4], h->ev[5]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventSynchronize(h->ev[5]));
+  for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[2 * i], h->ev[2 * i + 1]));
+  HIP_TRY(hipEventElapsedTime(&out_ms4[3], h->ev[0], h->ev[5]));   // whole step, first start to last stop
   return AUV_OK;
 }
 

@@ -9,6 +9,8 @@
 //            NaN action -> zeros        environment.py:314-315
 // Roofline: HBM.  Algorithmic traffic per env-step: 6 fp64 state in + 6 out + 2 action
 // values (8 or 16 B) + one int4 counter r/w = 136..144 B; ~500 flop and 12 sin/cos.
+#include <hip/hip_ext.h>
+
 #include "auv_device.h"
 
 namespace {
@@ -161,12 +163,14 @@ __global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const AT* __r
 }  // namespace
 
 #ifndef AUV_DEVICE_FUNCS_ONLY
-void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st) {
+// ev0 / ev1 (both or neither): the dispatch itself is stamped (hipExtLaunchKernel), so the elapsed
+// time between them is the kernel's own duration without the gaps around it
+void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const int per_block = AUV_BLOCK / K1_GROUP;
   dim3 grid((d.n + per_block - 1) / per_block), block(AUV_BLOCK);
   if (dtype == AUV_F64)
-    hipLaunchKernelGGL(k1_dynamics<double>, grid, block, 0, st, d, (const double*)actions);
+    hipExtLaunchKernelGGL(k1_dynamics<double>, grid, block, 0, st, ev0, ev1, 0, d, (const double*)actions);
   else
-    hipLaunchKernelGGL(k1_dynamics<float>, grid, block, 0, st, d, (const float*)actions);
+    hipExtLaunchKernelGGL(k1_dynamics<float>, grid, block, 0, st, ev0, ev1, 0, d, (const float*)actions);
 }
 #endif

@@ -24,6 +24,10 @@
 // Roofline: HBM.  Algorithmic bytes per env-step: 32*ceil((P-1)/64) (chunk circles) + ~3 KiB
 // (surviving chunks' vertices) + 8*S (d in) + 8*(6+S) (obs64 r/w) + 4*(6+S) (obs f32 out)
 // + ~600 (knot rows, scalars, info/nav/counters).
+#ifndef AUV_DEVICE_FUNCS_ONLY
+#include <hip/hip_ext.h>
+#endif
+
 #include "auv_device.h"
 
 namespace {
@@ -572,8 +576,9 @@ void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st) {
 }
 
 // lidar_obs = 0: the LiDAR launch before it has written the float32 closeness columns itself
-void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st) {
-  hipLaunchKernelGGL(k3_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, obs, reward, done, lidar_obs);
+void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st,
+                          hipEvent_t ev0, hipEvent_t ev1) {
+  hipExtLaunchKernelGGL(k3_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, ev0, ev1, 0, d, obs, reward, done, lidar_obs);
 }
 
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st) {

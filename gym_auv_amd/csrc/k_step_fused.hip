@@ -10,6 +10,7 @@
 // The new state and counters are handed from phase to phase in registers (EnvPre), so no lane
 // re-reads global memory that another lane of the wave has just written.
 #include <cstdlib>
+#include <hip/hip_ext.h>
 
 #define AUV_DEVICE_FUNCS_ONLY
 #include "k1_dynamics.hip"
@@ -128,11 +129,11 @@ static int k23_wpb() {
   return wpb;
 }
 
-void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st) {
+void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const int wpb = k23_wpb();
   const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * wpb;
   const int nb = (d.n + wpb - 1) / wpb;
-  hipLaunchKernelGGL(k23_lidar_nav, dim3(2 * nb), dim3(AUV_WAVE * wpb), lds, st, d, obs);
+  hipExtLaunchKernelGGL(k23_lidar_nav, dim3(2 * nb), dim3(AUV_WAVE * wpb), (uint32_t)lds, st, ev0, ev1, 0, d, obs);
 }
 
 hipError_t auv_step_fused_prepare(const AuvDev& d) {

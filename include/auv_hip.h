@@ -200,8 +200,9 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2 };
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
 
-/* One step in the default launch shape with HIP events on `stream` around every kernel:
- * out_ms[0..3] = K1, [K2 + K3-nav side by side], K3-reward, 0.                               */
+/* One step in the default launch shape, every dispatch stamped with its own start / stop HIP event
+ * on `stream` (the kernel's own duration, as a kernel trace reports it):
+ * out_ms[0..3] = K1, [K2 + K3-nav side by side], K3-reward, whole step (first start .. last stop). */
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                    float* reward_dev, uint8_t* done_dev, void* stream, float* out_ms4);
 
