@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--graph", type=int, default=0, help="replay a captured hipGraph per step (1) or launch eagerly (0, default: eager launches pipeline deeper than one graph replay per step on this stack)")
     ap.add_argument("--step-mode", default="side_by_side", choices=["side_by_side", "one_kernel", "two_streams"],
                     help="how a step is launched (include/auv_hip.h, AUV_STEP_*)")
+    ap.add_argument("--actions", default="uniform", choices=["uniform", "pilot"],
+                    help="uniform: i.i.d. U(action_space), resident in HBM (headline); pilot: closed loop, "
+                         "a = (1, 0.15 * heading_error) computed on the device from the observation of the "
+                         "previous step, so that episodes progress along the path (SURVEY 8(d), config 1)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
     ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
@@ -148,6 +152,14 @@ def main():
 
         def do_step(i):
             env.step_graph()
+    elif args.actions == "pilot":
+        act = torch.ones((n_local, 2), dtype=torch.float32, device=dev)
+
+        def do_step(i):
+            # look-ahead pilot: full thrust, rudder proportional to the heading error (observation
+            # column 4, already clipped to +-1 rad): two tiny torch kernels per step, all on the device
+            torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
+            env.step(act)
     else:
         def do_step(i):
             env.step(pool[i % n_pool])
@@ -201,7 +213,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
                            parallelism="env-shard x%d (no step-path collective)" % world,
-                           hipgraph=bool(args.graph), step_mode=args.step_mode, world_gen_s=round(t_gen, 1),
+                           hipgraph=bool(args.graph), step_mode=args.step_mode, actions=args.actions, world_gen_s=round(t_gen, 1),
                            episodes_finished=int(stats["episodes"].sum().item())),
                roofline=roofline)
 

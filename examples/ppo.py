@@ -6,7 +6,14 @@ MlpPolicy [256, 128, 64], gamma 0.999, lambda 0.98, 4 epochs, 32 minibatches, en
 lr 2e-4, clip 0.2); the rollout length is shortened because one batched step already yields
 thousands of transitions (the reference collected 8 envs x 1024 steps per update).
 
+Scenarios are generated ON THE DEVICE: every environment gets its own
+MovingObstacles world and the whole bank is regenerated from fresh random draws every `--regen`
+updates (a few milliseconds), so training never waits for host-side world generation; finished
+episodes in between restart on the next world of the bank.  `--worlds host` uses the host
+generator (bit-compatible RNG streams with the reference) instead.
+
     python examples/ppo.py --envs 4096 --updates 20 --rollout 32
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/ppo.py   # data parallel
 """
 import argparse
 import os
@@ -35,39 +42,55 @@ class ActorCritic(nn.Module):
         return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
 
 
-def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print):
+def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=5):
+    from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
+    from gym_auv_amd.devgen import GeneratedWorlds
     from gym_auv_amd.world import build_bank_parallel
-    torch.manual_seed(seed)
+    rank, world = D.rank(), D.world_size()
+    torch.manual_seed(seed + rank)
     cfg = effective_reference_config(use_lidar=True)
-    bank = build_bank_parallel("moving_obstacles_world", range(5000, 5000 + min(envs, 512)), procs=min(8, os.cpu_count() or 1))
+    if worlds == "generated":
+        bank = GeneratedWorlds(n_worlds=envs, seed=1000 * seed + rank)
+    else:
+        bank = build_bank_parallel("moving_obstacles_world", range(5000 + 512 * rank, 5000 + 512 * rank + min(envs, 512)),
+                                   procs=min(8, os.cpu_count() or 1))
     env = BatchedAuvEnv(cfg, bank, envs, device=device, auto_reset=True)
     low = torch.as_tensor(env.action_space.low, device=device)
     high = torch.as_tensor(env.action_space.high, device=device)
     net = ActorCritic(env.obs_dim).to(device)
+    if world > 1:   # data parallel over GPUs: same initial weights, gradients averaged over RCCL
+        for prm in net.parameters():
+            torch.distributed.broadcast(prm.data, 0)
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)
     gamma, lam, clip, ent_coef, epochs, n_mb = 0.999, 0.98, 0.2, 0.01, 4, 32
     obs = env.reset().clone()
     history = []
     for upd in range(updates):
+        if worlds == "generated" and upd and upd % regen == 0:
+            # fresh scenarios for every environment, built on the device; all envs restart
+            env.generate(GeneratedWorlds(n_worlds=envs, seed=1000 * seed + rank + 7919 * upd))
+            obs = env.reset().clone()
         t0 = time.time()
-        O, A, LP, R, D, V = [], [], [], [], [], []
+        O, A, LP, R, Dn, V = [], [], [], [], [], []
         with torch.no_grad():
             for _ in range(rollout):
                 dist = net.dist(obs)
                 a = dist.sample()
                 nobs, rew, done, _ = env.step(torch.max(torch.min(a, high), low))
                 O.append(obs), A.append(a), LP.append(dist.log_prob(a).sum(-1)), V.append(net.v(obs).squeeze(-1))
-                R.append(rew.clone() * 0.01), D.append(done.float())          # reward scale for the value net
+                R.append(rew.clone() * 0.01), Dn.append(done.float())         # reward scale for the value net
                 obs = nobs.clone()
             last_v = net.v(obs).squeeze(-1)
             adv, gae = [None] * rollout, torch.zeros(envs, device=device)
             for t in reversed(range(rollout)):
                 nv = last_v if t == rollout - 1 else V[t + 1]
-                delta = R[t] + gamma * nv * (1 - D[t]) - V[t]
-                gae = delta + gamma * lam * (1 - D[t]) * gae
+                delta = R[t] + gamma * nv * (1 - Dn[t]) - V[t]
+                gae = delta + gamma * lam * (1 - Dn[t]) * gae
                 adv[t] = gae
+        torch.cuda.synchronize()
+        t_roll = time.time() - t0
         O, A, LP, V = torch.cat(O), torch.cat(A), torch.cat(LP), torch.cat(V)
         ADV = torch.cat(adv)
         RET = ADV + V
@@ -83,13 +106,27 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print)
                 loss = pg + 0.5 * vf - ent_coef * dist.entropy().sum(-1).mean()
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
+                if world > 1:
+                    for prm in net.parameters():
+                        torch.distributed.all_reduce(prm.grad)
+                        prm.grad /= world
                 nn.utils.clip_grad_norm_(net.parameters(), 0.5)
                 opt.step()
         torch.cuda.synchronize()
         mean_r = float(torch.stack(R).mean().item()) / 0.01
-        sps = envs * rollout / (time.time() - t0)
+        sps = world * envs * rollout / (time.time() - t0)
         history.append((mean_r, float(loss.item()), sps))
-        log("update %3d  mean step reward %8.3f  loss %8.4f  %.2e env-steps/s incl. learning" % (upd, mean_r, loss.item(), sps))
+        if rank == 0:
+            log("update %3d  mean step reward %8.3f  loss %8.4f  rollout %.2e env-steps/s (policy in the loop), "
+                "%.2e env-steps/s incl. learning" % (upd, mean_r, loss.item(), world * envs * rollout / t_roll, sps))
+    # the one collective of the environment side: finished-episode statistics of all ranks
+    stats = D.gather_episode_stats(env.episode_stats())
+    if rank == 0:
+        fin = stats["episodes"] > 0
+        log("episodes finished %d; last-episode return mean %.1f, collision rate %.2f, goal rate %.2f" % (
+            int(stats["episodes"].sum()), float(stats["episode_return"][fin].mean()) if fin.any() else float("nan"),
+            float(stats["collision"][fin].mean()) if fin.any() else float("nan"),
+            float(stats["reached_goal"][fin].mean()) if fin.any() else float("nan")))
     env.close()
     return history
 
@@ -99,5 +136,9 @@ if __name__ == "__main__":
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--updates", type=int, default=10)
     ap.add_argument("--rollout", type=int, default=32)
+    ap.add_argument("--worlds", default="generated", choices=["generated", "host"])
+    ap.add_argument("--regen", type=int, default=5, help="regenerate the world bank on the device every this many updates")
     a = ap.parse_args()
-    train(a.envs, a.updates, a.rollout)
+    from gym_auv_amd import distributed as D
+    _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
+    train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, worlds=a.worlds, regen=a.regen)

@@ -31,6 +31,14 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block [lo, hi) of global environment indices owned by `rank`; blocks differ
     by at most one env and cover [0, n_total) exactly."""
