@@ -247,14 +247,36 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   // cos / sin of (beam angle + psi) by the addition theorem from the per-config table of beam
   // angles (built at load time): one sincos per environment instead of one per ray
   double sin_psi, cos_psi;
-  sincos(psi, &sin_psi, &cos_psi);
-  for (int i = lane; i < S; i += AUV_WAVE) {
-    const double2 b = d.beam_cs[i];                       // cos, sin of -pi + (i + 1) * dangle
-    const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
-    // end point minus origin, formed exactly as the reference forms the end point
-    double ex = px + c * R, ey = py + s * R;
-    L.rayv[i] = make_double2(ex - px, ey - py);
-    L.dbits[i] = d2u(2.0);   // no hit yet (hits have t in [0, 1])
+  if (S <= 4 * AUV_WAVE) {
+    // the usual shapes: all passes' table entries are requested before the sincos, so the passes
+    // do not each wait for their own trip to memory
+    double2 b[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = q * AUV_WAVE + lane;
+      b[q] = d.beam_cs[i < S ? i : 0];                      // cos, sin of -pi + (i + 1) * dangle
+    }
+    sincos(psi, &sin_psi, &cos_psi);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = q * AUV_WAVE + lane;
+      if (i < S) {
+        const double c = cos_psi * b[q].x - sin_psi * b[q].y, s = sin_psi * b[q].x + cos_psi * b[q].y;
+        // end point minus origin, formed exactly as the reference forms the end point
+        double ex = px + c * R, ey = py + s * R;
+        L.rayv[i] = make_double2(ex - px, ey - py);
+        L.dbits[i] = d2u(2.0);   // no hit yet (hits have t in [0, 1])
+      }
+    }
+  } else {
+    sincos(psi, &sin_psi, &cos_psi);
+    for (int i = lane; i < S; i += AUV_WAVE) {
+      const double2 b = d.beam_cs[i];
+      const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
+      double ex = px + c * R, ey = py + s * R;
+      L.rayv[i] = make_double2(ex - px, ey - py);
+      L.dbits[i] = d2u(2.0);
+    }
   }
   auv_wave_lds_sync();
 
