@@ -328,12 +328,18 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   best.d = 1.7976931348623157e308;
   best.j = 0x7fffffff;
   double2 bA = make_double2(0.0, 0.0), bB = bA;        // end points of this lane's best segment
-  for (int a = 0; a < n_act; a++) {
-    const int j = list[a] * AUV_CHUNK + lane;
-    if (j < P - 1) {
-      double2 A = xy[j], B = xy[j + 1];
-      double dd = auv_pt_seg_dist(px, py, A.x, A.y, B.x, B.y);
-      if (dd < best.d) best.d = dd, best.j = j, bA = A, bB = B;
+  for (int a = 0; a < n_act; a += 2) {                 // two surviving chunks per trip to memory
+    const bool two = a + 1 < n_act;
+    const int ja = list[a] * AUV_CHUNK + lane, jb = two ? list[a + 1] * AUV_CHUNK + lane : ja;
+    const bool va = ja < P - 1, vb = two && jb < P - 1;
+    const double2 A0 = xy[va ? ja : 0], B0 = xy[va ? ja + 1 : 0], A1 = xy[vb ? jb : 0], B1 = xy[vb ? jb + 1 : 0];
+    if (va) {
+      const double dd = auv_pt_seg_dist(px, py, A0.x, A0.y, B0.x, B0.y);
+      if (dd < best.d) best.d = dd, best.j = ja, bA = A0, bB = B0;      // ascending j: strict '<' keeps the first minimum
+    }
+    if (vb) {
+      const double dd = auv_pt_seg_dist(px, py, A1.x, A1.y, B1.x, B1.y);
+      if (dd < best.d) best.d = dd, best.j = jb, bA = A1, bB = B1;
     }
   }
   // cumulative length at this lane's candidate, requested while the reduction runs
