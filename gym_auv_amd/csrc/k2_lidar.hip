@@ -470,18 +470,32 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
     //      face p0 are compacted into the stage ----
     SUB_T0()
     int T = 0;                                             // staged segments
+    // the segment of the NEXT pass is requested before this pass's segment is worked on, so a batch
+    // of several passes (the heavy sweeps that end the launch) pays one trip to memory, not one per pass
+    int a_nx = a0;
+    ObsLds o_nx;
+    double4 s_nx = make_double4(0.0, 0.0, 0.0, 0.0);
+    auto fetch = [&](int tb_f) {
+      const int t = tb_f + lane;
+      a_nx = a0;
+      if (t < T_raw) {
+        while (t + base0 >= L.sbase[a_nx + 1]) a_nx++;
+        o_nx = L.obs[L.act[a_nx]];
+        const int si = t + base0 - L.sbase[a_nx];
+        s_nx = (o_nx.kind == AUV_OBS_MOVER) ? L.mvseg[o_nx.seg_off + si] : d.seg[o_nx.seg_off + si];
+      }
+    };
+    fetch(0);
     for (int tb = 0; tb < T_raw; tb += AUV_WAVE) {
       const int t = tb + lane;
       bool keep = false;
-      int a = a0;
-      ObsLds o;
+      const int a = a_nx;
+      const ObsLds o = o_nx;
+      const double4 s = s_nx;
+      if (tb + AUV_WAVE < T_raw) fetch(tb + AUV_WAVE);
       double4 wv = make_double4(0.0, 0.0, 0.0, 0.0);
       short2 sp = make_short2(0, 0);
       if (t < T_raw) {
-        while (t + base0 >= L.sbase[a + 1]) a++;
-        o = L.obs[L.act[a]];
-        const int si = t + base0 - L.sbase[a];
-        const double4 s = (o.kind == AUV_OBS_MOVER) ? L.mvseg[o.seg_off + si] : d.seg[o.seg_off + si];
         const double wx = s.x - px, wy = s.y - py, sx = s.z - s.x, sy = s.w - s.y;
         wv = make_double4(wx, wy, sx, sy);
         // A ray from outside a simple closed boundary first meets it on an edge that faces p0, and
