@@ -168,6 +168,53 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
   const double* ws2 = d.world_scalar + 8 * (size_t)w2;
   const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
   const int DL = 6 + (d.cfg.use_lidar ? S : 0);                                        // columns this path writes
+  if (d.w_ready && 6 + S <= 4 * AUV_WAVE && d.k_max <= AUV_WAVE) {
+    // The usual shapes: every row fits four wave passes.  The auto-reset sits on the reward kernel's
+    // critical path and the compiler must assume that the rows alias, so the copy is written as:
+    // every load that depends only on the world index (one trip to memory), the mover states (their
+    // offset comes with the first trip), then all stores.
+    const EnvDesc nd = auv_make_desc(d, w2);
+    const double ix = ws2[3], iy = ws2[4], ipsi = ws2[5];
+    const uint8_t wcol = d.w_collision[w2];
+    double lv[4], ov[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = q * AUV_WAVE + lane;
+      lv[q] = (i < S) ? d.w_lidar[(size_t)w2 * S + i] : 0.0;
+      ov[q] = (i < 6 + S) ? d.w_obs64[(size_t)w2 * (6 + S) + i] : 0.0;
+    }
+    double row = 0.0;
+    if (lane < 8) row = d.w_info[8 * (size_t)w2 + lane];
+    else if (lane < 16) row = d.w_nav[8 * (size_t)w2 + lane - 8];
+    uint8_t nb = 0;
+    int2 lm = make_int2(0, 0);
+    if (lane < d.k_max) nb = d.w_nearby[(size_t)w2 * d.k_max + lane], lm = d.w_limits[(size_t)w2 * d.k_max + lane];
+    double4 mv0 = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (lane < nd.M) mv0 = d.mv_init[nd.m0 + lane];
+    if (lane == 0) {
+      d.world_idx[e] = w2;
+      d.env_desc[e] = nd;
+      d.state[0 * n + e] = ix, d.state[1 * n + e] = iy, d.state[2 * n + e] = ipsi;
+      d.state[3 * n + e] = 0.0, d.state[4 * n + e] = 0.0, d.state[5 * n + e] = 0.0;
+      d.counters[e] = make_int4(0, 0, episodes, 0);
+      d.collision[e] = wcol;
+    }
+    if (lane < nd.M) d.mover[(size_t)e * d.m_max + lane] = mv0;
+    for (int m = AUV_WAVE + lane; m < nd.M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = d.mv_init[nd.m0 + m];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = q * AUV_WAVE + lane;
+      if (i < S) d.lidar_d[(size_t)e * S + i] = lv[q];
+      if (i < 6 + S) {
+        d.obs64[(size_t)e * (6 + S) + i] = ov[q];
+        if (obs_out && i < DL) obs_out[(size_t)e * D + i] = (float)ov[q];
+      }
+    }
+    if (lane < 8) d.info64[8 * (size_t)e + lane] = row;
+    else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = row;
+    if (lane < d.k_max) d.nearby[(size_t)e * d.k_max + lane] = nb, d.limits[(size_t)e * d.k_max + lane] = lm;
+    return;
+  }
   if (lane == 0) {
     d.world_idx[e] = w2;
     d.env_desc[e] = auv_make_desc(d, w2);
@@ -190,37 +237,6 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
   if (!d.w_ready) {
     for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
     for (int k = lane; k < d.k_max; k += AUV_WAVE) d.nearby[(size_t)e * d.k_max + k] = 0;
-    return;
-  }
-  if (6 + S <= 4 * AUV_WAVE && d.k_max <= AUV_WAVE) {
-    // the usual shapes: every row fits four wave passes.  All loads are issued before the first
-    // store (the rows could alias as far as the compiler knows, so a load-store loop per row would
-    // cost one trip to memory per pass; the auto-reset sits on the reward kernel's critical path)
-    double lv[4], ov[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int i = q * AUV_WAVE + lane;
-      lv[q] = (i < S) ? d.w_lidar[(size_t)w2 * S + i] : 0.0;
-      ov[q] = (i < 6 + S) ? d.w_obs64[(size_t)w2 * (6 + S) + i] : 0.0;
-    }
-    double row = 0.0;
-    if (lane < 8) row = d.w_info[8 * (size_t)w2 + lane];
-    else if (lane < 16) row = d.w_nav[8 * (size_t)w2 + lane - 8];
-    uint8_t nb = 0;
-    int2 lm = make_int2(0, 0);
-    if (lane < d.k_max) nb = d.w_nearby[(size_t)w2 * d.k_max + lane], lm = d.w_limits[(size_t)w2 * d.k_max + lane];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int i = q * AUV_WAVE + lane;
-      if (i < S) d.lidar_d[(size_t)e * S + i] = lv[q];
-      if (i < 6 + S) {
-        d.obs64[(size_t)e * (6 + S) + i] = ov[q];
-        if (obs_out && i < DL) obs_out[(size_t)e * D + i] = (float)ov[q];
-      }
-    }
-    if (lane < 8) d.info64[8 * (size_t)e + lane] = row;
-    else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = row;
-    if (lane < d.k_max) d.nearby[(size_t)e * d.k_max + lane] = nb, d.limits[(size_t)e * d.k_max + lane] = lm;
     return;
   }
   for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.w_lidar[(size_t)w2 * S + i];
