@@ -446,20 +446,23 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
     int do_reset = 0;
     if (lane == 0) {
       const double lambda = 0.5, eta = 0.0, penalty_yawrate = 10.0, neutral_speed = 0.05, max_speed = 2.0;
+      // everything the block reads is requested up front (one trip to memory, whatever branch follows)
+      const double u = nv[0], v = nv[1], yaw_rate = nv[2];
+      const double rew_path_in = d.rew_path[e], rew_lidar_in = d.rew_lidar[e];
+      const double cum_in = inf[4], reached_in = inf[1], goal_in = inf[2], progress_in = inf[3];
       double reward;
       if (collision) {
         reward = -10000.0 * (1 - lambda);
       } else {
-        const double u = nv[0], v = nv[1], yaw_rate = nv[2];
         const double speed = sqrt(u * u + v * v);
-        const double path_reward = from_buffers ? reward_path_term(d, u, v, nv[4], nv[5], inf[3], inf[5]) : d.rew_path[e];
+        const double path_reward = from_buffers ? reward_path_term(d, u, v, nv[4], nv[5], inf[3], inf[5]) : rew_path_in;
         const double living_penalty = lambda * (2 * neutral_speed + 1) + eta * neutral_speed;
         if (!colav) {
           double slow_penalty = (speed < 0.1) ? -2 : 0;
           reward = path_reward - living_penalty + eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) +
                    slow_penalty;
         } else {
-          const double closeness_reward = (from_buffers || !d.cfg.use_lidar) ? lidar_term : d.rew_lidar[e];
+          const double closeness_reward = (from_buffers || !d.cfg.use_lidar) ? lidar_term : rew_lidar_in;
           double slow_penalty = (speed < 0.04) ? -2 : 0;
           reward = lambda * path_reward + (1 - lambda) * closeness_reward - living_penalty +
                    eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) + slow_penalty;
@@ -468,21 +471,21 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
       }
       // ---- environment.py:333-347, :375-384 ----
       d.reward64[e] = reward;
-      double cum = inf[4] + reward;
+      double cum = cum_in + reward;
       inf[4] = cum;
       const int t_step = cnt.x;
-      const int done = collision || (inf[1] != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
+      const int done = collision || (reached_in != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
                        (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);
       cnt.x = t_step + 1;
       {
         double* si = d.step_info + 4 * (size_t)e;          // environment.py:336-340
-        si[0] = collision, si[1] = inf[1], si[2] = inf[2], si[3] = inf[3];
+        si[0] = collision, si[1] = reached_in, si[2] = goal_in, si[3] = progress_in;
       }
       if (reward_out) reward_out[e] = (float)reward;
       if (done_out) done_out[e] = (uint8_t)done;
       if (done) {
         double* ep = d.episode + 4 * (size_t)e;
-        ep[0] = cum, ep[1] = t_step + 1, ep[2] = collision, ep[3] = inf[1];
+        ep[0] = cum, ep[1] = t_step + 1, ep[2] = collision, ep[3] = reached_in;
         cnt.z += 1;
       }
       do_reset = done && d.cfg.auto_reset;
