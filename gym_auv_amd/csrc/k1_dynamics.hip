@@ -19,6 +19,18 @@ struct Vec6 {
   double v[6];
 };
 
+// x / c for the Runge-Kutta tableau's integer constants, correctly rounded without the ~28-instruction
+// IEEE division sequence: q = RN(x * RN(1/c)), r = x - q c exactly (one FMA), RN(q + r * RN(1/c)).
+// q + r RN(1/c) differs from x / c by at most 2^-51 ulp, while a quotient by an integer c < 2^16 is
+// either representable or at least ulp / (4 c) away from any rounding boundary, so the final
+// rounding lands where the division's would (tests/test_k1_constant_division.py also checks 1e8 cases).
+#define AUV_DIVC(x, c) auv_div_const((x), (c), 1.0 / (c))
+__device__ __forceinline__ double auv_div_const(double x, double c, double rc) {
+  const double q = x * rc;
+  const double r = fma(-q, c, x);
+  return fma(r, rc, q);
+}
+
 __device__ __forceinline__ Vec6 state_dot(const Vec6& y, double tau_u, double tau_r) {
   // constants.py:4-16
   const double m = 23.8, x_g = 0.046, I_z = 1.760, X_udot = -2.0, Y_vdot = -10.0, Y_rdot = 0.0,
@@ -74,23 +86,23 @@ __device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const AT*
   Vec6 s3 = state_dot(t, tu, tr);
 #pragma unroll
   for (int i = 0; i < 6; i++)
-    t.v[i] = y.v[i] + 1932.0 * h * s1.v[i] / 2197.0 - 7200.0 * h * s2.v[i] / 2197.0 +
-             7296.0 * h * s3.v[i] / 2197.0;
+    t.v[i] = y.v[i] + AUV_DIVC(1932.0 * h * s1.v[i], 2197.0) - AUV_DIVC(7200.0 * h * s2.v[i], 2197.0) +
+             AUV_DIVC(7296.0 * h * s3.v[i], 2197.0);
   Vec6 s4 = state_dot(t, tu, tr);
 #pragma unroll
   for (int i = 0; i < 6; i++)
-    t.v[i] = y.v[i] + 439.0 * h * s1.v[i] / 216.0 - 8.0 * h * s2.v[i] + 3680.0 * h * s3.v[i] / 513.0 -
-             845.0 * h * s4.v[i] / 4104.0;
+    t.v[i] = y.v[i] + AUV_DIVC(439.0 * h * s1.v[i], 216.0) - 8.0 * h * s2.v[i] + AUV_DIVC(3680.0 * h * s3.v[i], 513.0) -
+             AUV_DIVC(845.0 * h * s4.v[i], 4104.0);
   Vec6 s5 = state_dot(t, tu, tr);
 #pragma unroll
   for (int i = 0; i < 6; i++)
-    t.v[i] = y.v[i] - 8.0 * h * s1.v[i] / 27.0 + 2 * h * s2.v[i] - 3544.0 * h * s3.v[i] / 2565 +
-             1859.0 * h * s4.v[i] / 4104.0 - 11.0 * h * s5.v[i] / 40.0;
+    t.v[i] = y.v[i] - AUV_DIVC(8.0 * h * s1.v[i], 27.0) + 2 * h * s2.v[i] - AUV_DIVC(3544.0 * h * s3.v[i], 2565.0) +
+             AUV_DIVC(1859.0 * h * s4.v[i], 4104.0) - AUV_DIVC(11.0 * h * s5.v[i], 40.0);
   Vec6 s6 = state_dot(t, tu, tr);
 #pragma unroll
   for (int i = 0; i < 6; i++)
-    t.v[i] = y.v[i] + h * (16.0 * s1.v[i] / 135.0 + 6656.0 * s3.v[i] / 12825.0 +
-                           28561.0 * s4.v[i] / 56430.0 - 9.0 * s5.v[i] / 50.0 + 2.0 * s6.v[i] / 55.0);
+    t.v[i] = y.v[i] + h * (AUV_DIVC(16.0 * s1.v[i], 135.0) + AUV_DIVC(6656.0 * s3.v[i], 12825.0) +
+                           AUV_DIVC(28561.0 * s4.v[i], 56430.0) - AUV_DIVC(9.0 * s5.v[i], 50.0) + AUV_DIVC(2.0 * s6.v[i], 55.0));
   t.v[2] = auv_princip(t.v[2]);
   EnvPre pre;
   pre.cnt = d.counters[e];
@@ -147,13 +159,15 @@ __global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const AT* __r
   const double s2 = sdot(t);
   t = y + 3.0 * h * s1 / 32.0 + 9.0 * h * s2 / 32.0;
   const double s3 = sdot(t);
-  t = y + 1932.0 * h * s1 / 2197.0 - 7200.0 * h * s2 / 2197.0 + 7296.0 * h * s3 / 2197.0;
+  t = y + AUV_DIVC(1932.0 * h * s1, 2197.0) - AUV_DIVC(7200.0 * h * s2, 2197.0) + AUV_DIVC(7296.0 * h * s3, 2197.0);
   const double s4 = sdot(t);
-  t = y + 439.0 * h * s1 / 216.0 - 8.0 * h * s2 + 3680.0 * h * s3 / 513.0 - 845.0 * h * s4 / 4104.0;
+  t = y + AUV_DIVC(439.0 * h * s1, 216.0) - 8.0 * h * s2 + AUV_DIVC(3680.0 * h * s3, 513.0) - AUV_DIVC(845.0 * h * s4, 4104.0);
   const double s5 = sdot(t);
-  t = y - 8.0 * h * s1 / 27.0 + 2 * h * s2 - 3544.0 * h * s3 / 2565 + 1859.0 * h * s4 / 4104.0 - 11.0 * h * s5 / 40.0;
+  t = y - AUV_DIVC(8.0 * h * s1, 27.0) + 2 * h * s2 - AUV_DIVC(3544.0 * h * s3, 2565.0) + AUV_DIVC(1859.0 * h * s4, 4104.0) -
+      AUV_DIVC(11.0 * h * s5, 40.0);
   const double s6 = sdot(t);
-  t = y + h * (16.0 * s1 / 135.0 + 6656.0 * s3 / 12825.0 + 28561.0 * s4 / 56430.0 - 9.0 * s5 / 50.0 + 2.0 * s6 / 55.0);
+  t = y + h * (AUV_DIVC(16.0 * s1, 135.0) + AUV_DIVC(6656.0 * s3, 12825.0) + AUV_DIVC(28561.0 * s4, 56430.0) -
+               AUV_DIVC(9.0 * s5, 50.0) + AUV_DIVC(2.0 * s6, 55.0));
   if (c == 2) t = auv_princip(t);
   if (live && own) d.state[(size_t)c * n + e] = t;
   if (live && c == 0) d.counters[e].y += 1;                // Vessel._step_counter (vessel.py:247)
