@@ -1,5 +1,7 @@
-// K2 — moving-obstacle update + LiDAR sweep: ONE WAVE (64 lanes) PER ENVIRONMENT, four
-// environments per 256-thread workgroup, no workgroup barriers (everything is wave-synchronous).
+// K2 — moving-obstacle update + LiDAR sweep: ONE WAVE (64 lanes) PER ENVIRONMENT, no workgroup
+// barriers (everything is wave-synchronous).  The step path runs it as the first role of the
+// one-wave workgroups of k23_lidar_nav (k_step_fused.hip); k2_lidar below is the stand-alone
+// kernel of the per-kernel API (four environments per 256-thread workgroup).
 //
 // Reference: BaseEnvironment._update              gym_auv/environment.py:386-392
 //            VesselObstacle._update / boundary     objects/obstacles.py:195-233
@@ -7,28 +9,35 @@
 //            find_rays_to_simulate_for_obstacles   objects/vessel/sensor.py:74-97
 //            _find_limit_angle_rays                sensor.py:41-71
 //            simulate_sensor                       sensor.py:140-159
+//            ColavRewarder (LiDAR term)            objects/rewarder.py:205-222
 //
 // Work decomposition inside the wave:
 //   phase A  lanes <-> movers: advance kinematics, rebuild the 5 pentagon segments + cull
 //            circle in the wave's LDS slice.
-//   phase C  lanes <-> rays (S/64 passes): ray vectors (one sincos per ray) into LDS.
-//   phase B  lanes <-> obstacles: (every 25th vessel step) nearby test; cull window
-//            [i_min-1, i_max % S) with the reference's Python-range / negative-index
-//            semantics; obstacles with a non-empty window are compacted (ballot + popcount).
-//   phase S  the boundary segments of the surviving obstacles are staged into LDS in ONE
-//            flattened, coalesced pass (vessel-relative: a - p0, b - a), together with the
-//            point-in-polygon predicates of filled obstacles (LDS xor/or per obstacle) and the
-//            conservative range of ray indices each segment can possibly be hit by (its angular
-//            span seen from p0, fp32 atan2, widened by a ray on both sides).
-//   phase D  lanes <-> staged segments: each lane walks the rays of its segment's span that
-//            also lie in the obstacle's window (the reference's culling decides visibility; the
-//            span only skips pairs that cannot intersect), exact fp64 ray/segment test, a hit
-//            does an LDS atomic-min on the ray's t (non-negative fp64 ordered as uint64).
-//   phase E  lanes <-> rays: distance from the min t, closeness (fused), ballot -> collision.
-// Work per environment is ~2 x (rays subtended by the nearby boundaries), a few hundred pair
-// tests instead of S x G = 99 k, and no longer depends on how wide the reference's windows are.
+//   phase C  lanes <-> rays (S/64 passes): ray vectors into LDS -- one sincos(psi) per environment,
+//            the beam angles' cos/sin come from a per-config table (addition theorem).
+//   phase B0 (every 25th vessel step) lanes <-> obstacles: refresh of the cached nearby mask.
+//   phase B  lanes <-> obstacles: cull window [i_min-1, i_max % S) with the reference's
+//            Python-range / negative-index semantics; obstacles with a non-empty window are
+//            compacted (ballot + popcount).
+//   phase S  the boundary segments of the surviving obstacles are looked at in flattened,
+//            coalesced passes; the FRONT-FACING ones (a ray from outside a simple closed boundary
+//            first meets an edge that faces p0) are compacted into LDS (vessel-relative: a - p0,
+//            b - a), together with the point-in-polygon predicates of filled obstacles (LDS
+//            xor/or per obstacle, all edges) and the conservative range of ray indices each staged
+//            segment can possibly be hit by (its angular span seen from p0, fp32 atan2, widened
+//            by two rays on both sides).
+//   phase D  work items = (staged segment, run of <= 8 rays of its span), lanes <-> items: the rays
+//            that also lie in the obstacle's window (the reference's culling decides visibility;
+//            the span only skips pairs that cannot intersect) get the exact fp64 ray/segment
+//            test, a hit does an LDS atomic-min on the ray's t (non-negative fp64 as uint64).
+//   phase E  lanes <-> rays: distance from the min t, closeness (fp64 + the float32 observation
+//            columns), ballot -> collision, and the LiDAR term of the Colav reward.
+// Work per environment is ~(rays subtended by the nearby front-facing boundaries), ~100 pair
+// tests instead of S x G = 99 k, and does not depend on how wide the reference's windows are.
 // Roofline: HBM.  Algorithmic bytes per env-step (fp64 layout): 32*G (segments, G per env)
-// + 24*K (cull circles) + 16*K (meta) + 24 (pose) + 16*S (d + closeness out) + K (nearby).
+// + 24*K (cull circles) + 16*K (meta) + 24 (pose) + 16*S (d + closeness out) + K (nearby) + 4*S
+// (float32 closeness).
 #include "auv_device.h"
 
 namespace {

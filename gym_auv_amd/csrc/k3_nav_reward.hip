@@ -1,5 +1,7 @@
 // K3 — path navigation + reward + episode termination + observation assembly:
-// ONE WAVE PER ENVIRONMENT, four environments per 256-thread workgroup, wave-synchronous.
+// ONE WAVE PER ENVIRONMENT, wave-synchronous.  The step path runs the navigation as the second role
+// of the one-wave workgroups of k23_lidar_nav (k_step_fused.hip) and the reward as k3_reward; the
+// other kernels here serve the per-kernel API, the reset-row pass and reset().
 //
 // Reference: Vessel.navigate                  gym_auv/objects/vessel/vessel.py:461-541
 //            Path.get_closest_arclength       objects/path.py:84-93  (GEOS LineString.project:
@@ -15,15 +17,17 @@
 //           distance to the path;
 //   pass 2  a chunk can hold the (first) minimum only if |p - c| - rad <= U: the survivors
 //           (typically 1-3 of ~160) are listed in LDS in ascending order (ballot + popcount);
-//   pass 3  lanes <-> the 64 segments of each surviving chunk, GEOS point-segment distance,
-//           (distance, first index) min-reduced with wave shuffles.
+//   pass 3  lanes <-> the 64 segments of each surviving chunk (two chunks per trip to memory),
+//           GEOS point-segment distance, (distance, first index) min-reduced with wave shuffles;
+//           the winning lane hands its segment over by shuffle.
 // Every segment that could win or tie survives, so the result (and the reference's "first
-// minimum wins" tie-break) is identical to the brute-force scan.  Then two lanes evaluate the
-// spline at s and s+look-ahead in parallel, the Colav closeness term is a wave reduction over
-// the S beams, lane 0 does the scalar reward / done logic.
+// minimum wins" tie-break) is identical to the brute-force scan.  Then lane 0 evaluates the spline
+// at s, lanes 1 and 2 at s + look-ahead (knot window + coefficient rows in one trip), one atan2
+// serves the three angles, lane 0 finishes the navigation features and the path term of the reward.
+// The reward kernel combines that term with the LiDAR term K2 left, does cumulative reward / done /
+// episode bookkeeping and copies the reset rows of environments that ended.
 // Roofline: HBM.  Algorithmic bytes per env-step: 32*ceil((P-1)/64) (chunk circles) + ~3 KiB
-// (surviving chunks' vertices) + 8*S (d in) + 8*(6+S) (obs64 r/w) + 4*(6+S) (obs f32 out)
-// + ~600 (knot rows, scalars, info/nav/counters).
+// (surviving chunks' vertices) + ~600 (knot rows, scalars, info/nav/counters); reward ~300.
 #ifndef AUV_DEVICE_FUNCS_ONLY
 #include <hip/hip_ext.h>
 #endif
