@@ -80,9 +80,15 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk,
     if (nk >= 4) {
       const int g = i < 1 ? 1 : (i > nk - 3 ? nk - 3 : i);       // window [g-1, g+2] inside the table
       const double xa = x[g - 1], xb = x[g], xc = x[g + 1], xd = x[g + 2];
+      // coefficient rows are 64-byte records: four 16-byte loads each instead of eight 8-byte ones
+      // (the vector memory pipe takes a wave's load in the same time whatever its width)
       double ca[8], cb8[8], cc[8];
+      const double2* r2 = (const double2*)(cf + 8 * (size_t)(g - 1));
 #pragma unroll
-      for (int a = 0; a < 8; a++) ca[a] = cf[8 * (size_t)(g - 1) + a], cb8[a] = cf[8 * (size_t)g + a], cc[a] = cf[8 * (size_t)(g + 1) + a];
+      for (int a = 0; a < 4; a++) {
+        const double2 va = r2[a], vb = r2[4 + a], vc = r2[8 + a];
+        ca[2 * a] = va.x, ca[2 * a + 1] = va.y, cb8[2 * a] = vb.x, cb8[2 * a + 1] = vb.y, cc[2 * a] = vc.x, cc[2 * a + 1] = vc.y;
+      }
       if (s >= xa && s < xd) {
         // the interval [x_i, x_{i+1}) containing s is one of the three fetched
         const int sel = (s < xb) ? 0 : (s < xc ? 1 : 2);
@@ -99,8 +105,12 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk,
   }
   if (!have) {
     xi = x[i];
+    const double2* r2 = (const double2*)(cf + 8 * (size_t)i);
 #pragma unroll
-    for (int a = 0; a < 8; a++) c[a] = cf[8 * (size_t)i + a];
+    for (int a = 0; a < 4; a++) {
+      const double2 v2 = r2[a];
+      c[2 * a] = v2.x, c[2 * a + 1] = v2.y;
+    }
   }
   const double z = s - xi, z2 = z * z;
 #pragma unroll
@@ -404,17 +414,33 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
     double gx = goal_x - px, gy = goal_y - py;
     double goal = sqrt(gx * gx + gy * gy);
     int reached = (goal <= d.cfg.min_goal_distance) || (progress >= d.cfg.min_path_progress);
-    nv[0] = u, nv[1] = v, nv[2] = r, nv[3] = la, nv[4] = he, nv[5] = cte / 100, nv[6] = chi, nv[7] = s_t;
-    inf[1] = reached, inf[2] = goal, inf[3] = progress, inf[5] = maxp, inf[6] = s, inf[7] = 0.0;
+    // rows are written with 16-byte stores (NAV64 / INFO64 rows are 64-byte records)
+    const double cte100 = cte / 100;
+    double2* nv2 = (double2*)nv;
+    nv2[0] = make_double2(u, v), nv2[1] = make_double2(r, la), nv2[2] = make_double2(he, cte100), nv2[3] = make_double2(chi, s_t);
+    double2* inf2 = (double2*)inf;
+    inf[1] = reached, inf2[1] = make_double2(goal, progress), inf[5] = maxp, inf2[3] = make_double2(s, 0.0);
     // path-following term of the reward: everything it needs is at hand here, so the
     // transcendentals stay out of the reward phase
-    d.rew_path[e] = reward_path_term(d, u, v, he, cte / 100, progress, maxp);
-    // environment.py:276-280; lane 0 also emits the float32 copies of its own six values
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      double c6 = auv_clip(nv[i], -1.0, 1.0);
-      ob[i] = c6;
-      if (obs_out) obs_out[(size_t)e * D + i] = (float)c6;
+    d.rew_path[e] = reward_path_term(d, u, v, he, cte100, progress, maxp);
+    // environment.py:276-280; lane 0 also emits the float32 copies of its own six values.  OBS64 rows
+    // start 16-byte aligned when 6 + S is even, float32 rows 8-byte aligned when their stride is even.
+    const double c0 = auv_clip(u, -1.0, 1.0), c1 = auv_clip(v, -1.0, 1.0), c2 = auv_clip(r, -1.0, 1.0),
+                 c3 = auv_clip(la, -1.0, 1.0), c4 = auv_clip(he, -1.0, 1.0), c5 = auv_clip(cte100, -1.0, 1.0);
+    if (((6 + S) & 1) == 0) {
+      double2* ob2 = (double2*)ob;
+      ob2[0] = make_double2(c0, c1), ob2[1] = make_double2(c2, c3), ob2[2] = make_double2(c4, c5);
+    } else {
+      ob[0] = c0, ob[1] = c1, ob[2] = c2, ob[3] = c3, ob[4] = c4, ob[5] = c5;
+    }
+    if (obs_out) {
+      float* oo = obs_out + (size_t)e * D;
+      if ((D & 1) == 0) {
+        float2* oo2 = (float2*)oo;
+        oo2[0] = make_float2((float)c0, (float)c1), oo2[1] = make_float2((float)c2, (float)c3), oo2[2] = make_float2((float)c4, (float)c5);
+      } else {
+        oo[0] = (float)c0, oo[1] = (float)c1, oo[2] = (float)c2, oo[3] = (float)c3, oo[4] = (float)c4, oo[5] = (float)c5;
+      }
     }
   }
   AUV_STAMP()
