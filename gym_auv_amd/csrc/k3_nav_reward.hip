@@ -477,9 +477,11 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
     if (lane == 0) {
       const double lambda = 0.5, eta = 0.0, penalty_yawrate = 10.0, neutral_speed = 0.05, max_speed = 2.0;
       // everything the block reads is requested up front (one trip to memory, whatever branch follows)
-      const double u = nv[0], v = nv[1], yaw_rate = nv[2];
+      const double2 uv = ((const double2*)nv)[0];           // rows are 64-byte records: 16-byte accesses
+      const double u = uv.x, v = uv.y, yaw_rate = nv[2];
       const double rew_path_in = d.rew_path[e], rew_lidar_in = d.rew_lidar[e];
-      const double cum_in = inf[4], reached_in = inf[1], goal_in = inf[2], progress_in = inf[3];
+      const double2 gp = ((const double2*)inf)[1];
+      const double cum_in = inf[4], reached_in = inf[1], goal_in = gp.x, progress_in = gp.y;
       double reward;
       if (collision) {
         reward = -10000.0 * (1 - lambda);
@@ -508,14 +510,14 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
                        (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);
       cnt.x = t_step + 1;
       {
-        double* si = d.step_info + 4 * (size_t)e;          // environment.py:336-340
-        si[0] = collision, si[1] = reached_in, si[2] = goal_in, si[3] = progress_in;
+        double2* si = (double2*)(d.step_info + 4 * (size_t)e);   // environment.py:336-340
+        si[0] = make_double2(collision, reached_in), si[1] = make_double2(goal_in, progress_in);
       }
       if (reward_out) reward_out[e] = (float)reward;
       if (done_out) done_out[e] = (uint8_t)done;
       if (done) {
-        double* ep = d.episode + 4 * (size_t)e;
-        ep[0] = cum, ep[1] = t_step + 1, ep[2] = collision, ep[3] = reached_in;
+        double2* ep = (double2*)(d.episode + 4 * (size_t)e);
+        ep[0] = make_double2(cum, t_step + 1), ep[1] = make_double2(collision, reached_in);
         cnt.z += 1;
       }
       do_reset = done && d.cfg.auto_reset;
