@@ -75,26 +75,29 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk,
   } else if (s >= xl) {
     i = nk - 2;
   } else {
-    i = (int)(s / L * (nk - 1));
+    const double fi = s / L * (nk - 1);
+    i = (int)fi;
     i = i < 0 ? 0 : (i > nk - 2 ? nk - 2 : i);
     if (nk >= 4) {
-      const int g = i < 1 ? 1 : (i > nk - 3 ? nk - 3 : i);       // window [g-1, g+2] inside the table
-      const double xa = x[g - 1], xb = x[g], xc = x[g + 1], xd = x[g + 2];
+      // two adjacent intervals around the guess: the guessed one and the neighbour on the side the
+      // fractional position leans to -- knots [g, g+2] and coefficient rows g, g+1
+      int g = (fi - (double)i < 0.5) ? i - 1 : i;
+      g = g < 0 ? 0 : (g > nk - 3 ? nk - 3 : g);
+      const double xa = x[g], xb = x[g + 1], xc = x[g + 2];
       // coefficient rows are 64-byte records: four 16-byte loads each instead of eight 8-byte ones
       // (the vector memory pipe takes a wave's load in the same time whatever its width)
-      double ca[8], cb8[8], cc[8];
-      const double2* r2 = (const double2*)(cf + 8 * (size_t)(g - 1));
+      double ca[8], cb8[8];
+      const double2* r2 = (const double2*)(cf + 8 * (size_t)g);
 #pragma unroll
       for (int a = 0; a < 4; a++) {
-        const double2 va = r2[a], vb = r2[4 + a], vc = r2[8 + a];
-        ca[2 * a] = va.x, ca[2 * a + 1] = va.y, cb8[2 * a] = vb.x, cb8[2 * a + 1] = vb.y, cc[2 * a] = vc.x, cc[2 * a + 1] = vc.y;
+        const double2 va = r2[a], vb = r2[4 + a];
+        ca[2 * a] = va.x, ca[2 * a + 1] = va.y, cb8[2 * a] = vb.x, cb8[2 * a + 1] = vb.y;
       }
-      if (s >= xa && s < xd) {
-        // the interval [x_i, x_{i+1}) containing s is one of the three fetched
-        const int sel = (s < xb) ? 0 : (s < xc ? 1 : 2);
-        xi = sel == 0 ? xa : (sel == 1 ? xb : xc);
+      if (s >= xa && s < xc) {
+        const bool second = s >= xb;
+        xi = second ? xb : xa;
 #pragma unroll
-        for (int a = 0; a < 8; a++) c[a] = sel == 0 ? ca[a] : (sel == 1 ? cb8[a] : cc[a]);
+        for (int a = 0; a < 8; a++) c[a] = second ? cb8[a] : ca[a];
         have = true;
       }
     }
