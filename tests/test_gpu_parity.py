@@ -314,3 +314,33 @@ def test_error_paths():
         env.reset(world_idx=torch.tensor([0, 1, 2, 7]))
     with pytest.raises(RuntimeError):
         env.step_graph()
+
+
+def test_long_soak_vs_oracle():
+    """400 steps of 128 environments over 64 mixed worlds with auto-reset (several episodes per
+    environment, nearby-cache refreshes, resets onto other worlds): flags every step, all fields
+    every 10th step."""
+    n = 128
+    bank = _mixed_bank(64)
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.episode.max_timesteps = 90
+    env = _env(cfg, bank, n, auto_reset=True)
+    ora = _oracle(cfg, bank, n, auto_reset=True)
+    env.reset(), ora.reset()
+    rs = np.random.RandomState(123)
+    n_done = 0
+    for t in range(400):
+        a = rs.uniform([-1, -0.15], [1, 0.15], (n, 2))
+        a[:, 0] = np.abs(a[:, 0])                      # keep moving so that obstacles are met
+        obs, rew, done, _ = env.step(torch.as_tensor(a, device="cuda:0"))
+        o_obs, o_rew, o_done = ora.step(a)
+        np.testing.assert_array_equal(_np(done), o_done, err_msg="done step %d" % t)
+        np.testing.assert_array_equal(_np(env.read("COLLISION")), ora.read("COLLISION"), err_msg="collision step %d" % t)
+        n_done += int(o_done.sum())
+        if t % 10 == 9:
+            for f in ("STATE", "LIDAR_D", "OBS64", "REWARD64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE"):
+                np.testing.assert_allclose(_np(env.read(f)), ora.read(f), rtol=0, atol=ATOL, err_msg="%s step %d" % (f, t))
+            for f in ("WORLD_IDX", "NEARBY", "CULL_LIMITS"):
+                np.testing.assert_array_equal(_np(env.read(f)), ora.read(f), err_msg="%s step %d" % (f, t))
+            np.testing.assert_allclose(_np(obs), o_obs, rtol=0, atol=1e-6)
+    assert n_done >= 3 * n
