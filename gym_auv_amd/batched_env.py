@@ -1,4 +1,4 @@
-"""BatchedAuvEnv — N independent gym-auv environments advanced per call by three HIP kernels.
+"""BatchedAuvEnv — N independent gym-auv environments advanced per call by three HIP launches.
 
 VecEnv-shaped surface (what the reference's callers use through stable-baselines' VecEnv,
 /root/reference/scripts/run.py:293-296): `reset() -> obs[N, D]`,
