@@ -102,18 +102,38 @@ __device__ __forceinline__ double point_boundary_distance(double px, double py, 
   return best;
 }
 
+// The five boundary segments of a mover (obstacles.py:217-233) formed on demand from its pose, with
+// the arithmetic phase A used to form them: LDS keeps 40 bytes per mover instead of 160.
+struct MoverSegs {
+  double c, s, x, y, wd;    // snapped cos / sin of the heading, position, width
+  __device__ __forceinline__ void vertex(int k, double& vx, double& vy) const {
+    const double bx = (k <= 1) ? -wd / 2 : (k == 3 ? 3.0 / 2 * wd : wd / 2);
+    const double by = (k == 0 || k == 4) ? -wd / 2 : (k == 3 ? 0.0 : wd / 2);
+    const double x0 = 5.0 * wd / 18.0;
+    const double xo = x0 - x0 * c, yo = 0.0 - x0 * s;
+    vx = (c * bx + -s * by + xo) + x;
+    vy = (s * bx + c * by + yo) + y;
+  }
+  __device__ __forceinline__ double4 operator[](int i) const {
+    double ax, ay, bx, by;
+    vertex(i, ax, ay);
+    vertex(i == 4 ? 0 : i + 1, bx, by);
+    return make_double4(ax, ay, bx, by);
+  }
+};
+
 #define K2_SEG_CAP 96    // staged segments per wave and batch (slice <= 10 KiB -> 16 waves per CU)
 #define K2_RAW_CAP 192   // boundary segments looked at per batch; only the front-facing ones are staged
 #define K2_ITEM_RAYS 8    // rays per work item of the pair sweep
 
 // per-wave LDS slice (decreasing alignment):
-//   EnvHdr | [Mmax*5] double4 mover segs | [Mmax] double4 mover cull | [CAP] double4 staged
-//   (wx,wy,sx,sy) | [S] double2 ray vectors | [S] u64 min-t bits | [Kmax] ObsLds |
-//   [CAP] short2 ray span | [Kmax] int active list | [Kmax+1] int segment prefix |
-//   [Kmax] int inside flags | [CAP] u16 owner | [CAP+1] u16 work-item prefix
+//   EnvHdr | [Mmax] double4 mover pose (cos, sin, x, y) | [CAP] double4 staged (wx,wy,sx,sy) |
+//   [S] double2 ray vectors | [Mmax] double2 mover cull centre | [S] u64 min-t bits | [Mmax] double
+//   mover width | [Kmax] ObsLds | [CAP] short2 ray span | [Kmax] int active list | [Kmax+1] int
+//   segment prefix | [Kmax] int inside flags | [CAP] u16 owner | [CAP+1] u16 work-item prefix
 __host__ __device__ __forceinline__ size_t k2_slice_bytes(int S, int k_max, int m_max) {
-  size_t b = sizeof(EnvHdr) + (size_t)m_max * AUV_MOVER_NSEG * 32 + (size_t)m_max * 32 + (size_t)K2_SEG_CAP * 32 +
-             (size_t)S * 16 + (size_t)S * 8 + (size_t)k_max * sizeof(ObsLds) + (size_t)K2_SEG_CAP * 4 +
+  size_t b = sizeof(EnvHdr) + (size_t)m_max * 32 + (size_t)K2_SEG_CAP * 32 + (size_t)S * 16 + (size_t)m_max * 16 +
+             (size_t)S * 8 + (size_t)m_max * 8 + (size_t)k_max * sizeof(ObsLds) + (size_t)K2_SEG_CAP * 4 +
              (size_t)k_max * 4 + (size_t)(k_max + 1) * 4 + (size_t)k_max * 4 + (size_t)K2_SEG_CAP * 2 +
              (size_t)(K2_SEG_CAP + 2) * 2;
   return (b + 15) & ~(size_t)15;
@@ -121,11 +141,12 @@ __host__ __device__ __forceinline__ size_t k2_slice_bytes(int S, int k_max, int 
 
 struct Slice {
   EnvHdr* hdr;
-  double4* mvseg;
-  double4* mvcull;
+  double4* mvrot;
   double4* stage;
   double2* rayv;
+  double2* mvcull;
   unsigned long long* dbits;
+  double* mvw;
   ObsLds* obs;
   short2* span;
   int* act;
@@ -135,15 +156,22 @@ struct Slice {
   unsigned short* ioff;
 };
 
+__device__ __forceinline__ MoverSegs mover_segs(const double4 rot, const double wd) {
+  MoverSegs ms;
+  ms.c = rot.x, ms.s = rot.y, ms.x = rot.z, ms.y = rot.w, ms.wd = wd;
+  return ms;
+}
+
 __device__ __forceinline__ Slice carve(unsigned char* p, int S, int k_max, int m_max) {
   Slice s;
   s.hdr = (EnvHdr*)p;
-  s.mvseg = (double4*)(s.hdr + 1);
-  s.mvcull = s.mvseg + m_max * AUV_MOVER_NSEG;
-  s.stage = s.mvcull + m_max;
+  s.mvrot = (double4*)(s.hdr + 1);
+  s.stage = s.mvrot + m_max;
   s.rayv = (double2*)(s.stage + K2_SEG_CAP);
-  s.dbits = (unsigned long long*)(s.rayv + S);
-  s.obs = (ObsLds*)(s.dbits + S);
+  s.mvcull = s.rayv + S;
+  s.dbits = (unsigned long long*)(s.mvcull + m_max);
+  s.mvw = (double*)(s.dbits + S);
+  s.obs = (ObsLds*)(s.mvw + m_max);
   s.span = (short2*)(s.obs + k_max);
   s.act = (int*)(s.span + K2_SEG_CAP);
   s.sbase = s.act + k_max;
@@ -232,23 +260,11 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     sincos(st.z, &s, &c);
     // closed form of enclosing_circle for the pentagon (MRR = body box): tests/test_world.py
     const double x0 = 5.0 * wd / 18.0, dxc = wd / 2.0 - x0;
-    L.mvcull[m] = make_double4(st.x + x0 + c * dxc, st.y + s * dxc, wd * sqrt(5.0) / 2.0, 0.0);
+    L.mvcull[m] = make_double2(st.x + x0 + c * dxc, st.y + s * dxc);   // radius: wd * sqrt(5) / 2
     if (fabs(c) < 2.5e-16) c = 0.0;   // shapely.affinity.rotate snaps tiny cos/sin
     if (fabs(s) < 2.5e-16) s = 0.0;
-    const double bx[5] = {-wd / 2, -wd / 2, wd / 2, 3.0 / 2 * wd, wd / 2};
-    const double by[5] = {-wd / 2, wd / 2, wd / 2, 0.0, -wd / 2};
-    const double xo = x0 - x0 * c, yo = 0.0 - x0 * s;
-    double vx[5], vy[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      vx[i] = (c * bx[i] + -s * by[i] + xo) + st.x;
-      vy[i] = (s * bx[i] + c * by[i] + yo) + st.y;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      int j = (i + 1) % 5;
-      L.mvseg[m * AUV_MOVER_NSEG + i] = make_double4(vx[i], vy[i], vx[j], vy[j]);
-    }
+    L.mvrot[m] = make_double4(c, s, st.x, st.y);   // the pentagon's segments are formed on demand (MoverSegs)
+    L.mvw[m] = wd;
   }
   if (!d.cfg.use_lidar) return 0;   // lidar_d stays at sensor_range from reset; collision stays 0
 
@@ -297,7 +313,6 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     for (int k = lane; k < K; k += AUV_WAVE) {
       const int4 meta = d.obs_meta[k0 + k];
       const bool mover = meta.x == AUV_OBS_MOVER;
-      const int seg_off = mover ? meta.w * AUV_MOVER_NSEG : meta.y;
       // Point.distance(boundary) - width < range (filled: 0 inside).  The boundary lies inside the
       // obstacle's enclosing circle (c, rho), so
       //   |p0 - c| - rho <= distance(p0, boundary) <= |p0 - c| + rho ;
@@ -305,8 +320,8 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       // far fewer segment loops).  1e-9 m of slack keeps rounding on the exact side.
       double cx, cy, rho;
       if (mover) {
-        double4 c4 = L.mvcull[meta.w];
-        cx = c4.x, cy = c4.y, rho = c4.z;
+        const double2 c2 = L.mvcull[meta.w];
+        cx = c2.x, cy = c2.y, rho = L.mvw[meta.w] * sqrt(5.0) / 2.0;
       } else {
         cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
       }
@@ -319,10 +334,10 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       } else {
         bool in = false;
         if (meta.x != AUV_OBS_RING)
-          in = mover ? point_in_polygon(px, py, L.mvseg + seg_off, meta.z)
+          in = mover ? point_in_polygon(px, py, mover_segs(L.mvrot[meta.w], L.mvw[meta.w]), meta.z)
                      : point_in_polygon(px, py, d.seg + meta.y, meta.z);
         const double dist = in ? 0.0
-                               : (mover ? point_boundary_distance(px, py, L.mvseg + seg_off, meta.z)
+                               : (mover ? point_boundary_distance(px, py, mover_segs(L.mvrot[meta.w], L.mvw[meta.w]), meta.z)
                                         : point_boundary_distance(px, py, d.seg + meta.y, meta.z));
         near = (dist - W < R) ? 1 : 0;
       }
@@ -363,8 +378,8 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
         } else {
           double cx, cy, rho;
           if (mover) {
-            double4 c4 = L.mvcull[meta.w];
-            cx = c4.x, cy = c4.y, rho = c4.z;
+            const double2 c2 = L.mvcull[meta.w];
+            cx = c2.x, cy = c2.y, rho = L.mvw[meta.w] * sqrt(5.0) / 2.0;
           } else {
             cx = scx, cy = scy, rho = srho;
           }
@@ -491,7 +506,9 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
         while (t + base0 >= L.sbase[a_nx + 1]) a_nx++;
         o_nx = L.obs[L.act[a_nx]];
         const int si = t + base0 - L.sbase[a_nx];
-        s_nx = (o_nx.kind == AUV_OBS_MOVER) ? L.mvseg[o_nx.seg_off + si] : d.seg[o_nx.seg_off + si];
+        // (a mover's seg_off is 5 x its slot)
+        s_nx = (o_nx.kind == AUV_OBS_MOVER) ? mover_segs(L.mvrot[o_nx.seg_off / AUV_MOVER_NSEG], L.mvw[o_nx.seg_off / AUV_MOVER_NSEG])[si]
+                                            : d.seg[o_nx.seg_off + si];
       }
     };
     fetch(0);
