@@ -46,6 +46,11 @@ def parse():
                          "previous step, so that episodes progress along the path (SURVEY 8(d), config 1)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
+    ap.add_argument("--rehearse", type=int, default=0,
+                    help="1: allow more ranks than visible GPUs (ranks share devices, gloo instead of RCCL); the line "
+                         "then reports n_gpus = distinct physical devices, not ranks")
+    ap.add_argument("--dry-run", type=int, default=0,
+                    help="1: every rank prints its shard (rank, env range, seeds, device) and exits without touching the GPU")
     ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
     return ap.parse_args()
 
@@ -98,12 +103,58 @@ def host_cores():
     return max(1, n)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU,
+    the shape of the reference's 8 SubprocVecEnv workers, scripts/run.py:293-296) with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, fail if any rank fails.  The parent never touches
+    HIP (torch.cuda.device_count() does not initialise it on this image) and nothing is re-exec'd."""
+    import socket
+    import subprocess
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if ndev < n and not (args.rehearse or args.dry_run):
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; one rank per GPU is required "
+                         "(--rehearse 1 lets ranks share devices over gloo)" % (n, ndev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if args.rehearse and ndev < n:
+            env.setdefault("AUV_DIST_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE, text=True))
+    outs, failed = [], []
+    for r, p in enumerate(procs):
+        out, _ = p.communicate()
+        outs.append(out)
+        if p.returncode != 0:
+            failed.append((r, p.returncode))
+            for q in procs:                       # a dead rank leaves the others in a collective: end exactly those
+                if q.poll() is None:
+                    q.kill()
+    if failed:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % failed)
+        return 1
+    sys.stdout.write("".join(outs) if args.dry_run else outs[0])
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    ndev = torch.cuda.device_count()              # does not initialise HIP
+    if ndev < world and not (args.rehearse or args.dry_run):
+        raise SystemExit("WORLD_SIZE=%d but only %d GPU(s) visible (one rank per GPU; --rehearse 1 to share)" % (world, ndev))
+    n_devices_used = len({r % max(1, ndev) for r in range(world)})   # ranks map to device LOCAL_RANK % ndev
 
     # ---- reset-time host work first, BEFORE anything initialises the GPU (worker processes
     # are forked here; no process that has touched HIP forks or execs)
@@ -114,7 +165,13 @@ def main():
     cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
     n_local = args.envs
     desc = desc % n_local
-    lo = rank * n_local                                    # weak scaling: fixed envs per GPU
+    from gym_auv_amd.distributed import shard_range
+    lo, hi = shard_range(n_local * world, rank, world)     # weak scaling: fixed envs per GPU, contiguous blocks
+    assert hi - lo == n_local
+    if args.dry_run:
+        print(json.dumps(dict(rank=rank, world=world, env_lo=lo, env_hi=hi, seed_lo=1000 + lo, seed_hi=1000 + hi,
+                              device=int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev), n_devices_used=n_devices_used)), flush=True)
+        return
     procs = args.procs or max(1, min(16, host_cores() // max(1, world)))
     t0 = time.time()
     cache = args.bank_cache and "%s.%s.%d.%d.npz" % (args.bank_cache, args.workload, lo, n_local)
@@ -208,11 +265,11 @@ def main():
     roofline = dict(bound="hbm", kernel=dom, achieved=per_kernel[dom]["achieved_GBs"], peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=per_kernel[dom]["frac"], traffic=traffic, kernels=per_kernel)
 
-    out = dict(metric="env-steps/sec", value=round(value, 1), unit="env-steps/s", n_gpus=world, steps=args.steps,
+    out = dict(metric="env-steps/sec", value=round(value, 1), unit="env-steps/s", n_gpus=n_devices_used, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
-                           parallelism="env-shard x%d (no step-path collective)" % world,
+                           parallelism="env-shard x%d (no step-path collective)" % world, ranks=world,
                            hipgraph=bool(args.graph), step_mode=args.step_mode, actions=args.actions, world_gen_s=round(t_gen, 1),
                            episodes_finished=int(stats["episodes"].sum().item())),
                roofline=roofline)

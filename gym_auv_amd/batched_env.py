@@ -108,12 +108,16 @@ class BatchedAuvEnv:
         m = None
         if mask is not None:
             m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
-            assert m.numel() == self.n_envs
+            if m.numel() != self.n_envs:
+                raise ValueError("mask must have %d entries, got %d" % (self.n_envs, m.numel()))
         wi = None
         if world_idx is not None:
             wi = torch.as_tensor(world_idx).to(device=self.device, dtype=torch.int32).contiguous()
-            assert wi.numel() == self.n_envs
-            assert int(wi.min()) >= 0 and int(wi.max()) < self.n_worlds, "world index out of range"
+            if wi.numel() != self.n_envs:
+                raise ValueError("world_idx must have %d entries, got %d" % (self.n_envs, wi.numel()))
+            if int(wi.min()) < 0 or int(wi.max()) >= self.n_worlds:
+                # (the library itself ignores an out-of-range entry and keeps that env's binding)
+                raise ValueError("world index out of range [0, %d)" % self.n_worlds)
         _check(_LIB.auv_reset(self._h, None if m is None else C.c_void_p(m.data_ptr()),
                               None if wi is None else C.c_void_p(wi.data_ptr()),
                               C.c_void_p(self.obs.data_ptr()), self._stream()), "auv_reset")

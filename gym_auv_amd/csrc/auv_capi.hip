@@ -66,7 +66,6 @@ struct auv_handle {
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
   int step_mode;                 // AUV_STEP_* (include/auv_hip.h)
-  int32_t ring_host_pos;         // action-ring slot of the next eager fused step
   hipEvent_t ev[6];
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
@@ -176,8 +175,6 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   }
   rc |= dev_alloc(ep, &d.beam_w, S ? S : 1);
   rc |= dev_alloc(ep, &d.derived, 4);
-  d.ring_slots = 1;
-  d.ring_slot_host = -1;
   rc |= dev_alloc(ep, &d.w_obs64, (size_t)W * (6 + S));
   rc |= dev_alloc(ep, &d.w_lidar, (size_t)W * S);
   rc |= dev_alloc(ep, &d.w_info, (size_t)W * 8);
@@ -187,6 +184,10 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.w_collision, (size_t)W);
   if (rc) return AUV_EHIP;
   }
+  // a new bank starts with a plain action buffer (a captured graph, and with it the ring, is gone)
+  d.ring_slots = 1;
+  d.ring_slot_host = -1;
+  HIP_TRY(hipMemset(d.ring_pos, 0, sizeof(int32_t)));
   d.w_ready = 0;
   auv_launch_derive(d, nullptr);
   std::vector<int32_t> wi(n);
@@ -247,7 +248,6 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->graph_exec = nullptr;
   h->cap_stream = nullptr;
   h->step_mode = AUV_STEP_SIDE_BY_SIDE;
-  h->ring_host_pos = 0;
   h->gen_worlds = 0;
   h->aux_stream = nullptr;
   h->ev_fork = h->ev_join = nullptr;
@@ -552,34 +552,33 @@ int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx
 // eagerly and under stream capture (the fork/join events become graph edges).
 static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, float* obs, float* reward, uint8_t* done,
                         hipStream_t st, bool capturing) {
-  if (h->step_mode == AUV_STEP_ONE_KERNEL && auv_step_fused_ok(h->d)) {
-    // the whole step in one kernel (csrc/k_step_fused.hip).  Eagerly the host names the action
-    // ring slot; a captured graph cannot change arguments, so it reads the device-side position
-    // and advances it with a tiny follow-up node.
-    AuvDev d = h->d;
-    if (d.ring_slots > 1 && !capturing) {
-      d.ring_slot_host = h->ring_host_pos;
-      h->ring_host_pos = (h->ring_host_pos + 1) % d.ring_slots;
-    }
+  // The action ring belongs to captured graphs only: an eager step reads `actions` as ONE plain
+  // [N][2] buffer and neither reads nor advances the ring position (a caller that launches
+  // eagerly can pass a different pointer every step).
+  AuvDev d = h->d;
+  if (!capturing) d.ring_slots = 1;
+  if (h->step_mode == AUV_STEP_ONE_KERNEL && auv_step_fused_ok(d)) {
+    // the whole step in one kernel (csrc/k_step_fused.hip).  A captured graph cannot change
+    // arguments, so it reads the device-side ring position and advances it with a tiny follow-up node.
     auv_launch_step_fused(d, actions, dtype, obs, reward, done, st);
-    if (d.ring_slots > 1 && capturing) auv_launch_ring_advance(h->d, st);
+    if (d.ring_slots > 1) auv_launch_ring_advance(d, st);
     return AUV_OK;
   }
-  if (h->step_mode != AUV_STEP_TWO_STREAMS && auv_k23_ok(h->d)) {
+  if (h->step_mode != AUV_STEP_TWO_STREAMS && auv_k23_ok(d)) {
     // default: K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward, one stream
-    auv_launch_k1(h->d, actions, dtype, st);
-    auv_launch_k23(h->d, obs, st);
-    auv_launch_k3_reward(h->d, obs, reward, done, h->d.cfg.use_lidar ? 0 : 1, st);
+    auv_launch_k1(d, actions, dtype, st);
+    auv_launch_k23(d, obs, st);
+    auv_launch_k3_reward(d, obs, reward, done, d.cfg.use_lidar ? 0 : 1, st);
     return AUV_OK;
   }
-  auv_launch_k1(h->d, actions, dtype, st);
+  auv_launch_k1(d, actions, dtype, st);
   HIP_TRY(hipEventRecord(h->ev_fork, st));
   HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-  auv_launch_k3_nav(h->d, obs, h->aux_stream);
+  auv_launch_k3_nav(d, obs, h->aux_stream);
   HIP_TRY(hipEventRecord(h->ev_join, h->aux_stream));
-  auv_launch_k2(h->d, 1, st);
+  auv_launch_k2(d, 1, st);
   HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-  auv_launch_k3_reward(h->d, obs, reward, done, 1, st);   // a done env with auto-reset copies its next world's reset rows
+  auv_launch_k3_reward(d, obs, reward, done, 1, st);   // a done env with auto-reset copies its next world's reset rows
   return AUV_OK;
 }
 
@@ -600,7 +599,6 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(h->d.ring_pos, 0, sizeof(int32_t)));
   h->d.ring_slots = n_slots;
-  h->ring_host_pos = 0;
   if (h->graph_exec) {   // a captured graph has the old value baked into its kernel arguments
     HIP_TRY(hipGraphExecDestroy(h->graph_exec));
     h->graph_exec = nullptr;
@@ -744,9 +742,11 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   // the kernels of the default (side-by-side) step, each dispatch stamped with its own start and
   // stop event (hipExtLaunchKernel): K1 | K2 + K3-nav in one launch | K3-reward.  The elapsed times
   // are the kernels' own durations, as a kernel trace reports them, without the gaps between them.
-  auv_launch_k1(h->d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
-  auv_launch_k23(h->d, obs_dev, st, h->ev[2], h->ev[3]);
-  auv_launch_k3_reward(h->d, obs_dev, reward_dev, done_dev, h->d.cfg.use_lidar ? 0 : 1, st, h->ev[4], h->ev[5]);
+  AuvDev d = h->d;
+  d.ring_slots = 1;   // eager: `actions_dev` is one plain [N][2] buffer (see enqueue_step)
+  auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
+  auv_launch_k23(d, obs_dev, st, h->ev[2], h->ev[3]);
+  auv_launch_k3_reward(d, obs_dev, reward_dev, done_dev, d.cfg.use_lidar ? 0 : 1, st, h->ev[4], h->ev[5]);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventSynchronize(h->ev[5]));
   for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[2 * i], h->ev[2 * i + 1]));

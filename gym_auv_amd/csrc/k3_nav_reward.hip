@@ -596,7 +596,8 @@ __global__ void __launch_bounds__(AUV_BLOCK) k_reset(AuvDev d, const uint8_t* __
   const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   if (mask && !mask[e]) return;
-  const int w = world_idx ? world_idx[e] : d.world_idx[e];
+  int w = world_idx ? world_idx[e] : d.world_idx[e];
+  if (w < 0 || w >= d.n_worlds) w = d.world_idx[e];        // an out-of-range request keeps the current binding
   restore_env(d, e, w, lane, d.counters[e].z, obs_out);
 }
 

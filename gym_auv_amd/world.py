@@ -185,12 +185,11 @@ def build_bank_parallel(kind: str, seeds: Sequence[int], procs: int = 1, **kwarg
     if procs <= 1 or len(seeds) < 2 * procs:
         return _build_chunk((kind, seeds, kwargs))
     import multiprocessing as mp
+    # CONTIGUOUS chunks merged in order: world i of the bank is always seeds[i], whatever `procs` is
+    # (so env e -> world e does not depend on the core or rank count)
     n_chunks = min(len(seeds), procs * 4)
-    chunks = [(kind, seeds[i::n_chunks], kwargs) for i in range(n_chunks)]
+    bounds = [len(seeds) * c // n_chunks for c in range(n_chunks + 1)]
+    chunks = [(kind, seeds[bounds[c]:bounds[c + 1]], kwargs) for c in range(n_chunks)]
     with mp.get_context("fork").Pool(procs) as pool:
         banks = pool.map(_build_chunk, chunks)
-    # restore seed order: chunk c holds seeds c, c+n_chunks, ... -> world index permutation
-    merged = merge_banks(banks)
-    order = np.concatenate([np.arange(len(seeds))[i::n_chunks] for i in range(n_chunks)])
-    merged["seed_order"] = np.asarray(seeds)[order]
-    return merged
+    return merge_banks(banks)

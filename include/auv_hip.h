@@ -184,11 +184,14 @@ int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_d
                       float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 int auv_graph_launch(auv_handle_t* h, void* stream);
 
-/* Action ring: after this call `actions_dev` of auv_step / auv_graph_capture is a ring of
- * n_slots consecutive [N][2] buffers; step k reads slot k % n_slots (the position lives on the
- * device and is advanced by the step itself), so a policy can fill slot k+1 while step k runs
- * and a replayed hipGraph needs no per-step argument update.  n_slots = 1 restores the plain
- * buffer.  Invalidates a captured graph.                                                    */
+/* Action ring (captured graphs only): after this call `actions_dev` of auv_graph_capture is a ring
+ * of n_slots consecutive [N][2] buffers; replayed step k reads slot k % n_slots (the position lives
+ * on the device and is advanced by the step itself), so a policy can fill slot k+1 while step k
+ * runs and a replayed hipGraph needs no per-step argument update.  n_slots = 1 restores the plain
+ * buffer.  Invalidates a captured graph.  EAGER auv_step / auv_step_timed never use the ring: they
+ * read `actions_dev` as one plain [N][2] buffer and leave the ring position alone (a caller that
+ * launches eagerly passes whatever pointer it likes per step).  Loading or generating a bank
+ * resets the ring to one slot.                                                                */
 int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 
 /* How auv_step / auv_graph_capture run a step (same results, bit for bit):

@@ -64,3 +64,30 @@ def test_gloo_world2_gather_episode_stats():
         assert full["collision"] == (exp % 3 == 0).float().tolist()
         assert t == 2.0
     assert sorted((r[1], r[2]) for r in res) == [(0, 6), (6, 11)]
+
+
+@pytest.mark.timeout(300)
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts two ranks by itself; --dry-run
+    shows their shards without touching a GPU.  Without enough GPUs (none here) and without --rehearse it
+    must fail loudly instead of running one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--envs", "100", "--dry-run", "1"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr
+    rows = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda r: r["rank"])
+    assert [r["rank"] for r in rows] == [0, 1] and all(r["world"] == 2 for r in rows)
+    assert [(r["env_lo"], r["env_hi"]) for r in rows] == [shard_range(200, 0, 2), shard_range(200, 1, 2)] == [(0, 100), (100, 200)]
+    assert [(r["seed_lo"], r["seed_hi"]) for r in rows] == [(1000, 1100), (1100, 1200)]
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                             env=env, capture_output=True, text=True, timeout=280)
+        assert bad.returncode != 0 and "GPU(s) visible" in (bad.stderr + bad.stdout)
+        # a launcher-provided WORLD_SIZE larger than the device count is refused too
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                             env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=280)
+        assert bad.returncode != 0 and "GPU(s) visible" in (bad.stderr + bad.stdout)

@@ -267,30 +267,40 @@ def test_step_modes_agree_bitwise(dtype):
                 assert torch.equal(envs[0].read(f), envs[other].read(f)), f
 
 
-def test_action_ring_eager_and_graph():
-    """The action ring consumes slot k % n at step k, eagerly (host-named slot) and in a replayed graph."""
-    n, slots = 16, 5
+def test_action_ring_graph_and_eager_after_capture():
+    """The action ring belongs to captured graphs: replay k consumes slot k % n.  An eager step() on
+    an env whose ring is on (after capture_graph(slots > 1)) reads its [N, 2] tensor as a plain
+    buffer and does not move the ring -- bit for bit what a plain env does (the eager
+    path used to apply the ring offset and read past the tensor)."""
+    n, slots = 16, 4
     bank = _mixed_bank(8)
     cfg = effective_reference_config(use_lidar=True)
-    ref, ring_e, ring_g = _env(cfg, bank, n), _env(cfg, bank, n), _env(cfg, bank, n)
-    for e in (ref, ring_e, ring_g):
-        e.reset()
+    ref, ring_g = _env(cfg, bank, n), _env(cfg, bank, n)
+    ref.reset(), ring_g.reset()
     rs = np.random.RandomState(2)
     acts = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (slots, n, 2)), dtype=torch.float32, device="cuda:0")
+    extra = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (3, n, 2)), dtype=torch.float32, device="cuda:0")
     buf_g = ring_g.capture_graph(torch.float32, slots=slots)
     buf_g.copy_(acts)
-    from gym_auv_amd.batched_env import _LIB, _check
-    _check(_LIB.auv_set_action_ring(ring_e._h, slots), "ring")
-    for k in range(12):
-        o0, r0, d0, _ = ref.step(acts[k % slots])
-        # eager ring: pass the ring base, the library picks the slot
-        import ctypes as C
-        _check(_LIB.auv_step(ring_e._h, C.c_void_p(acts.data_ptr()), 0, C.c_void_p(ring_e.obs.data_ptr()),
-                             C.c_void_p(ring_e.reward.data_ptr()), C.c_void_p(ring_e.done.data_ptr()), ring_e._stream()), "auv_step")
-        o2, r2, d2, _ = ring_g.step_graph()
+    k = 0
+    for rep in range(3):
+        for _ in range(5):                                   # replays walk the ring
+            o0, r0, d0, _ = ref.step(acts[k % slots])
+            o2, r2, d2, _ = ring_g.step_graph()
+            torch.cuda.synchronize()
+            assert torch.equal(o0, o2) and torch.equal(r0, r2) and torch.equal(d0, d2), k
+            k += 1
+        # eager steps in between: plain buffer, ring position untouched
+        o0, r0, d0, _ = ref.step(extra[rep])
+        o2, r2, d2, _ = ring_g.step(extra[rep])
         torch.cuda.synchronize()
-        assert torch.equal(o0, ring_e.obs) and torch.equal(r0, ring_e.reward), k
-        assert torch.equal(o0, o2) and torch.equal(r0, r2) and torch.equal(d0, d2), k
+        assert torch.equal(o0, o2) and torch.equal(r0, r2) and torch.equal(d0, d2), "eager %d" % rep
+        ms = ring_g.step_timed(extra[rep])                   # the stamped eager step too
+        ref.step(extra[rep])
+        torch.cuda.synchronize()
+        assert len(ms) == 4 and torch.equal(ref.obs, ring_g.obs)
+    for f in ("STATE", "OBS64", "INFO64", "COUNTERS", "EPISODE"):
+        assert torch.equal(ref.read(f), ring_g.read(f)), f
 
 
 def test_cull_exact_mode_vs_oracle():
@@ -310,8 +320,17 @@ def test_error_paths():
     env = _env(cfg, bank, 4)
     with pytest.raises(ValueError):
         env.step(torch.zeros((3, 2), device="cuda:0"))
-    with pytest.raises(AssertionError):
+    with pytest.raises(ValueError):
         env.reset(world_idx=torch.tensor([0, 1, 2, 7]))
+    # straight through the C ABI an out-of-range world index keeps the env's current binding
+    import ctypes as C
+    from gym_auv_amd.batched_env import _LIB, _check
+    env.reset()
+    before = _np(env.read("WORLD_IDX")).copy()
+    wi = torch.tensor([2, 99, -5, 1], dtype=torch.int32, device="cuda:0")
+    _check(_LIB.auv_reset(env._h, None, C.c_void_p(wi.data_ptr()), C.c_void_p(env.obs.data_ptr()), env._stream()), "auv_reset")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(env.read("WORLD_IDX")), [2, before[1], before[2], 1])
     with pytest.raises(RuntimeError):
         env.step_graph()
 

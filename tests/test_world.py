@@ -135,3 +135,16 @@ def test_fixed_test_scenarios_match_reference_worlds():
     assert len(sc.test_scenario4().circles) == 15      # the boolean-compare quirk (testscenario.py:125)
     assert len(sc.test_crossing().movers) == len(sc.test_crossing1().movers) == 1
     assert len(sc.empty_scenario().circles) == 0
+
+
+def test_bank_order_independent_of_worker_count():
+    """World i of a bank built in parallel is seeds[i] whatever the number of worker processes
+    (chunks used to be strided and the permutation was never undone)."""
+    from gym_auv_amd.world import build_bank_parallel
+    seeds = range(1000, 1013)
+    one = build_bank_parallel("static_circles_world", seeds, procs=1, n_circles=3)
+    for procs in (2, 3):
+        par = build_bank_parallel("static_circles_world", seeds, procs=procs, n_circles=3)
+        assert set(par) == set(one)
+        for k in one:
+            np.testing.assert_array_equal(np.asarray(par[k]), np.asarray(one[k]), err_msg="%s procs=%d" % (k, procs))
