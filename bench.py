@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="polygons50", choices=["polygons50", "circles20", "moving28", "mixed47"])
     ap.add_argument("--graph", type=int, default=0, help="replay a captured hipGraph per step (1) or launch eagerly (0, default: eager launches pipeline deeper than one graph replay per step on this stack)")
-    ap.add_argument("--step-mode", default="side_by_side", choices=["side_by_side", "one_kernel", "two_streams"],
+    ap.add_argument("--step-mode", default="side_by_side", choices=["side_by_side", "two_kernels", "one_kernel", "two_streams"],
                     help="how a step is launched (include/auv_hip.h, AUV_STEP_*)")
     ap.add_argument("--actions", default="uniform", choices=["uniform", "pilot"],
                     help="uniform: i.i.d. U(action_space), resident in HBM (headline); pilot: closed loop, "
@@ -246,14 +246,17 @@ def main():
     kms /= n_prof
     world_of_env = env.read("WORLD_IDX").cpu().numpy()
     alg = algorithmic_bytes(bank, S, world_of_env)
-    names = ["k1_dynamics", "k23_lidar_nav", "k3_reward"]
+    names = env.timed_kernel_names()
+    if names[0] == "k1n_dyn_nav":
+        alg = dict(alg, k1n_dyn_nav=alg["k1_dynamics"] + alg["nav_part"], k2r_lidar_reward=alg["lidar_part"] + alg["k3_reward"])
     per_kernel = {}
     for j, nm in enumerate(names):
         gbs = alg[nm] / (kms[j] * 1e-3) / 1e9 if kms[j] > 0 else 0.0
         per_kernel[nm] = dict(avg_ms=round(float(kms[j]), 5), algorithmic_bytes=int(alg[nm]),
                               achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
-    per_kernel["k23_lidar_nav"].update(lidar_bytes=int(alg["lidar_part"]), nav_bytes=int(alg["nav_part"]),
-                                       nav_bruteforce_bytes=int(alg["nav_bruteforce"]))
+    if "k23_lidar_nav" in per_kernel:
+        per_kernel["k23_lidar_nav"].update(lidar_bytes=int(alg["lidar_part"]), nav_bytes=int(alg["nav_part"]),
+                                           nav_bruteforce_bytes=int(alg["nav_bruteforce"]))
     dom = max(names, key=lambda nm: per_kernel[nm]["avg_ms"])
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -77,6 +77,7 @@ class BatchedAuvEnv:
             self.reward = torch.zeros((self.n_envs,), dtype=torch.float32, device=self.device)
             self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
         self._graph_actions = None
+        self.step_mode = "side_by_side"
 
     # ------------------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -133,11 +134,14 @@ class BatchedAuvEnv:
     def _lazy_info(self):
         return _LazyInfo(self)
 
+    STEP_MODES = {"side_by_side": 0, "one_kernel": 1, "two_streams": 2, "two_kernels": 3}
+
     def set_step_mode(self, mode: str):
-        """"side_by_side" (default): K1 -> [K2 + K3-nav in one launch] -> K3-reward;
-        "one_kernel": the whole step in one kernel; "two_streams": K3-nav forked beside K2."""
-        _check(_LIB.auv_set_step_mode(self._h, {"side_by_side": 0, "one_kernel": 1, "two_streams": 2}[mode]),
-               "auv_set_step_mode")
+        """"side_by_side" (default): K1 -> [K2 + K3-nav in one launch] -> K3-reward; "two_kernels": [K1 -> K3-nav]
+        -> [K2 -> K3-reward]; "one_kernel": the whole step in one kernel; "two_streams": K3-nav forked
+        beside K2.  All four give the same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise)."""
+        _check(_LIB.auv_set_step_mode(self._h, self.STEP_MODES[mode]), "auv_set_step_mode")
+        self.step_mode = mode
 
     # per-kernel entry points (parity tests)
     def step_dynamics(self, actions: torch.Tensor):
@@ -176,14 +180,18 @@ class BatchedAuvEnv:
         return self.obs, self.reward, self.done, self._lazy_info()
 
     def step_timed(self, actions: torch.Tensor):
-        """One step (default launch shape), every dispatch stamped with its own start/stop HIP event;
-        returns ms for (K1, K2+K3-nav side by side, K3-reward, whole step first start..last stop)."""
+        """One step, every dispatch stamped with its own start/stop HIP event; returns ms: in the
+        two-kernel mode ([K1 + K3-nav], [K2 + K3-reward], 0, whole step first start..last stop), otherwise
+        the side-by-side shape (K1, K2+K3-nav, K3-reward, whole step).  `timed_kernel_names()` names them."""
         a, dt = self._act(actions)
         ms = (C.c_float * 4)()
         _check(_LIB.auv_step_timed(self._h, C.c_void_p(a.data_ptr()), dt, C.c_void_p(self.obs.data_ptr()),
                                    C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
                                    self._stream(), ms), "auv_step_timed")
         return [float(x) for x in ms]
+
+    def timed_kernel_names(self):
+        return ["k1n_dyn_nav", "k2r_lidar_reward"] if self.step_mode == "two_kernels" else ["k1_dynamics", "k23_lidar_nav", "k3_reward"]
 
     # ------------------------------------------------------------------------------ optional post-kernel
     def feasibility_pooling(self, width: Optional[float] = None):

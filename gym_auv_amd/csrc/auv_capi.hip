@@ -35,6 +35,11 @@ void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0 
 hipError_t auv_step_fused_prepare(const AuvDev& d);
 void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st);
+bool auv_two_kernel_ok(const AuvDev& d);
+void auv_launch_k1n(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr,
+                    hipEvent_t ev1 = nullptr);
+void auv_launch_k2r(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
+                    hipEvent_t ev1 = nullptr);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
                    float* out_closeness, hipStream_t st);
 
@@ -158,6 +163,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.limits, n * k_max);
   rc |= dev_alloc(ep, &d.collision, n);
   rc |= dev_alloc(ep, &d.step_info, n * 4);
+  rc |= dev_alloc(ep, &d.pose_cs, n);
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
   rc |= dev_alloc(ep, &d.stamps, n * 16);
@@ -564,6 +570,12 @@ static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, flo
     if (d.ring_slots > 1) auv_launch_ring_advance(d, st);
     return AUV_OK;
   }
+  if (h->step_mode == AUV_STEP_TWO_KERNELS && auv_two_kernel_ok(d)) {
+    // [K1 -> K3-nav] -> [K2 -> K3-reward], two launches on one stream (csrc/k_step_fused.hip)
+    auv_launch_k1n(d, actions, dtype, obs, st);
+    auv_launch_k2r(d, obs, reward, done, st);
+    return AUV_OK;
+  }
   if (h->step_mode != AUV_STEP_TWO_STREAMS && auv_k23_ok(d)) {
     // default: K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward, one stream
     auv_launch_k1(d, actions, dtype, st);
@@ -608,7 +620,7 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
 
 int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   if (!h) return fail(AUV_EINVAL, "null handle");
-  if (mode < 0 || mode > 2) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
+  if (mode < 0 || mode > 3) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
   h->step_mode = mode;
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);
@@ -735,22 +747,30 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
                    uint8_t* done_dev, void* stream, float* out_ms4) {
   REQUIRE_READY(h);
   if (!actions_dev || !out_ms4) return fail(AUV_EINVAL, "auv_step_timed: null argument");
-  if (!auv_k23_ok(h->d)) return fail(AUV_EINVAL, "auv_step_timed: path too long for the side-by-side launch");
   hipStream_t st = (hipStream_t)stream;
   for (auto& e : h->ev)
     if (!e) HIP_TRY(hipEventCreate(&e));
-  // the kernels of the default (side-by-side) step, each dispatch stamped with its own start and
-  // stop event (hipExtLaunchKernel): K1 | K2 + K3-nav in one launch | K3-reward.  The elapsed times
-  // are the kernels' own durations, as a kernel trace reports them, without the gaps between them.
   AuvDev d = h->d;
   d.ring_slots = 1;   // eager: `actions_dev` is one plain [N][2] buffer (see enqueue_step)
-  auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
-  auv_launch_k23(d, obs_dev, st, h->ev[2], h->ev[3]);
-  auv_launch_k3_reward(d, obs_dev, reward_dev, done_dev, d.cfg.use_lidar ? 0 : 1, st, h->ev[4], h->ev[5]);
+  // every dispatch of the step is stamped with its own start and stop event (hipExtLaunchKernel): the
+  // elapsed times are the kernels' own durations, as a kernel trace reports them, without the gaps
+  int nk;
+  if (h->step_mode == AUV_STEP_TWO_KERNELS && auv_two_kernel_ok(d)) {
+    auv_launch_k1n(d, actions_dev, action_dtype, obs_dev, st, h->ev[0], h->ev[1]);
+    auv_launch_k2r(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
+    nk = 2;
+  } else {
+    if (!auv_k23_ok(d)) return fail(AUV_EINVAL, "auv_step_timed: path too long for the side-by-side launch");
+    auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
+    auv_launch_k23(d, obs_dev, st, h->ev[2], h->ev[3]);
+    auv_launch_k3_reward(d, obs_dev, reward_dev, done_dev, d.cfg.use_lidar ? 0 : 1, st, h->ev[4], h->ev[5]);
+    nk = 3;
+  }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventSynchronize(h->ev[5]));
-  for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[2 * i], h->ev[2 * i + 1]));
-  HIP_TRY(hipEventElapsedTime(&out_ms4[3], h->ev[0], h->ev[5]));   // whole step, first start to last stop
+  HIP_TRY(hipEventSynchronize(h->ev[2 * nk - 1]));
+  out_ms4[2] = 0.0f;
+  for (int i = 0; i < nk; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[2 * i], h->ev[2 * i + 1]));
+  HIP_TRY(hipEventElapsedTime(&out_ms4[3], h->ev[0], h->ev[2 * nk - 1]));   // whole step, first start to last stop
   return AUV_OK;
 }
 

@@ -75,6 +75,7 @@ struct AuvDev {
   int2* limits;        // [N][Kmax]
   uint8_t* collision;  // [N]
   double* step_info;   // [N][4] info of the last step (terminal values survive an auto-reset)
+  double2* pose_cs;    // [N] cos, sin of the heading K1 has just produced (K1 -> LiDAR within one step only)
   int32_t* fresh_count; // [1]  } work list of the load-time pass that computes the reset rows
   int32_t* fresh_list;  // [N]  }
   // ---- per-world reset rows (derived once at load time by running the reset observation of

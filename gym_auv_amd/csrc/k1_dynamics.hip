@@ -31,7 +31,43 @@ __device__ __forceinline__ double auv_div_const(double x, double c, double rc) {
   return fma(r, rc, q);
 }
 
-__device__ __forceinline__ Vec6 state_dot(const Vec6& y, double tau_u, double tau_r) {
+// Heading of a Runge-Kutta stage = heading at the start of the step + a small increment (dt times a
+// combination of yaw rates): its sine / cosine follow from those of the start heading by the addition
+// theorem with a short Taylor series in the increment (|delta| <= 1/8: truncation < 1e-19, rounding
+// ~2 ulp) -- one full-range sincos per step instead of six on the kernel's dependent chain.  The
+// reference evaluates np.sin / np.cos of every stage heading (vessel.py:566-568); the difference is
+// a few 1e-16, the K1 parity bound is 1e-12.
+struct Heading0 {
+  double psi, s, c;      // start heading of the step, its sine and cosine
+};
+
+__device__ __forceinline__ Heading0 heading0(double psi) {
+  Heading0 h;
+  h.psi = psi;
+  sincos(auv_princip(psi), &h.s, &h.c);
+  return h;
+}
+
+__device__ __forceinline__ void stage_sincos(const Heading0& h0, const double psi, double* s, double* c) {
+  const double dl = psi - h0.psi;
+  if (fabs(dl) <= 0.125) {
+    const double z = dl * dl;
+    double ps = fma(z, 1.0 / 6227020800.0, -1.0 / 39916800.0);
+    ps = fma(z, ps, 1.0 / 362880.0), ps = fma(z, ps, -1.0 / 5040.0), ps = fma(z, ps, 1.0 / 120.0);
+    ps = fma(z, ps, -1.0 / 6.0);
+    const double sd = fma(dl * z, ps, dl);                       // sin(delta)
+    double pc = fma(z, -1.0 / 87178291200.0, 1.0 / 479001600.0);
+    pc = fma(z, pc, -1.0 / 3628800.0), pc = fma(z, pc, 1.0 / 40320.0), pc = fma(z, pc, -1.0 / 720.0);
+    pc = fma(z, pc, 1.0 / 24.0), pc = fma(z, pc, -0.5);
+    const double cd = fma(z, pc, 1.0);                           // cos(delta)
+    *s = fma(h0.s, cd, h0.c * sd);
+    *c = fma(h0.c, cd, -(h0.s * sd));
+  } else {
+    sincos(auv_princip(psi), s, c);                              // (a yaw rate beyond anything the model reaches)
+  }
+}
+
+__device__ __forceinline__ Vec6 state_dot(const Vec6& y, double tau_u, double tau_r, const Heading0& h0) {
   // constants.py:4-16
   const double m = 23.8, x_g = 0.046, I_z = 1.760, X_udot = -2.0, Y_vdot = -10.0, Y_rdot = 0.0,
                N_rdot = -1.0, N_vdot = 0.0, X_u = -2.0, Y_v = -7.0, Y_r = -0.1, N_v = -0.1, N_r = -0.5;
@@ -39,9 +75,8 @@ __device__ __forceinline__ Vec6 state_dot(const Vec6& y, double tau_u, double ta
                m33 = I_z - N_rdot;
   const double det = m22 * m33 - m23 * m32;
   const double i11 = 1.0 / m11, i22 = m33 / det, i23 = -m23 / det, i32 = -m32 / det, i33 = m22 / det;
-  double psi = auv_princip(y.v[2]);
   double s, c;
-  sincos(psi, &s, &c);
+  stage_sincos(h0, y.v[2], &s, &c);
   double u = y.v[3], v = y.v[4], r = y.v[5];
   Vec6 o;
   o.v[0] = c * u + -s * v;   // Rz(psi).dot(nu), geomutils.py:37-43
@@ -77,28 +112,29 @@ __device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const AT*
 #pragma unroll
   for (int i = 0; i < 6; i++) y.v[i] = d.state[i * n + e];
 
-  Vec6 s1 = state_dot(y, tu, tr);
+  const Heading0 h0 = heading0(y.v[2]);
+  Vec6 s1 = state_dot(y, tu, tr, h0);
 #pragma unroll
   for (int i = 0; i < 6; i++) t.v[i] = y.v[i] + h * s1.v[i] / 4.0;
-  Vec6 s2 = state_dot(t, tu, tr);
+  Vec6 s2 = state_dot(t, tu, tr, h0);
 #pragma unroll
   for (int i = 0; i < 6; i++) t.v[i] = y.v[i] + 3.0 * h * s1.v[i] / 32.0 + 9.0 * h * s2.v[i] / 32.0;
-  Vec6 s3 = state_dot(t, tu, tr);
+  Vec6 s3 = state_dot(t, tu, tr, h0);
 #pragma unroll
   for (int i = 0; i < 6; i++)
     t.v[i] = y.v[i] + AUV_DIVC(1932.0 * h * s1.v[i], 2197.0) - AUV_DIVC(7200.0 * h * s2.v[i], 2197.0) +
              AUV_DIVC(7296.0 * h * s3.v[i], 2197.0);
-  Vec6 s4 = state_dot(t, tu, tr);
+  Vec6 s4 = state_dot(t, tu, tr, h0);
 #pragma unroll
   for (int i = 0; i < 6; i++)
     t.v[i] = y.v[i] + AUV_DIVC(439.0 * h * s1.v[i], 216.0) - 8.0 * h * s2.v[i] + AUV_DIVC(3680.0 * h * s3.v[i], 513.0) -
              AUV_DIVC(845.0 * h * s4.v[i], 4104.0);
-  Vec6 s5 = state_dot(t, tu, tr);
+  Vec6 s5 = state_dot(t, tu, tr, h0);
 #pragma unroll
   for (int i = 0; i < 6; i++)
     t.v[i] = y.v[i] - AUV_DIVC(8.0 * h * s1.v[i], 27.0) + 2 * h * s2.v[i] - AUV_DIVC(3544.0 * h * s3.v[i], 2565.0) +
              AUV_DIVC(1859.0 * h * s4.v[i], 4104.0) - AUV_DIVC(11.0 * h * s5.v[i], 40.0);
-  Vec6 s6 = state_dot(t, tu, tr);
+  Vec6 s6 = state_dot(t, tu, tr, h0);
 #pragma unroll
   for (int i = 0; i < 6; i++)
     t.v[i] = y.v[i] + h * (AUV_DIVC(16.0 * s1.v[i], 135.0) + AUV_DIVC(6656.0 * s3.v[i], 12825.0) +
@@ -117,22 +153,18 @@ __device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const AT*
   return pre;
 }
 
-#ifndef AUV_DEVICE_FUNCS_ONLY
-// The stand-alone kernel spreads one environment over eight lanes: lane c < 6 owns state
-// component c and forms its Runge-Kutta combinations (15 of the 90 fp64 divisions by tableau
-// constants), every lane evaluates _state_dot of the stage vector it gathers from its group with
-// shuffles and keeps component c.  The same operations in the same order per component as
-// k1_env, so the results are bit-identical; the wave retires ~2x fewer instructions per
-// environment step than with one lane doing all six components.
+// Eight lanes advance one environment: lane c < 6 owns state component c and forms its
+// Runge-Kutta combinations (15 of the 90 fp64 divisions by tableau constants), every lane evaluates
+// _state_dot of the stage vector it gathers from its group with shuffles and keeps component c.  The
+// same operations in the same order per component as k1_env, so the results are bit-identical; the
+// wave retires ~2x fewer instructions per environment step than with one lane doing all six
+// components.  Returns component c of the new state (lanes c >= 6: unspecified).  Lanes whose group
+// is idle (`e` clamped by the caller) compute along.
 #define K1_GROUP 8
 template <typename AT>
-__global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const AT* __restrict__ actions) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x % AUV_WAVE;
+__device__ __forceinline__ double k1_group(const AuvDev& d, const AT* __restrict__ actions, const int e, const int lane) {
   const int c = lane % K1_GROUP, gbase = lane - c;
   const size_t n = (size_t)d.n;
-  const bool live = tid / K1_GROUP < d.n;
-  const int e = live ? tid / K1_GROUP : d.n - 1;          // idle groups compute along, store nothing
   const bool own = c < 6;
   if (d.ring_slots > 1)   // action ring: slot of this step
     actions += (size_t)(d.ring_slot_host >= 0 ? d.ring_slot_host : *d.ring_pos) * 2 * n;
@@ -142,13 +174,14 @@ __global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const AT* __r
   const double tr = auv_clip(a1, -1.0, 1.0) * d.cfg.moment_max;
   const double h = d.cfg.dt;
   const double y = d.state[(size_t)(own ? c : 0) * n + e];
+  const Heading0 h0 = heading0(__shfl(y, gbase + 2, AUV_WAVE));
   // _state_dot of the stage vector whose component c this lane holds in `t`; returns component c
   auto sdot = [&](double t) {
     Vec6 v;
     v.v[0] = 0.0, v.v[1] = 0.0;                              // x, y do not enter _state_dot
     v.v[2] = __shfl(t, gbase + 2, AUV_WAVE), v.v[3] = __shfl(t, gbase + 3, AUV_WAVE);
     v.v[4] = __shfl(t, gbase + 4, AUV_WAVE), v.v[5] = __shfl(t, gbase + 5, AUV_WAVE);
-    const Vec6 o = state_dot(v, tu, tr);
+    const Vec6 o = state_dot(v, tu, tr, h0);
     double r = o.v[0];
 #pragma unroll
     for (int i = 1; i < 6; i++) r = (c == i) ? o.v[i] : r;
@@ -169,7 +202,20 @@ __global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const AT* __r
   t = y + h * (AUV_DIVC(16.0 * s1, 135.0) + AUV_DIVC(6656.0 * s3, 12825.0) + AUV_DIVC(28561.0 * s4, 56430.0) -
                AUV_DIVC(9.0 * s5, 50.0) + AUV_DIVC(2.0 * s6, 55.0));
   if (c == 2) t = auv_princip(t);
-  if (live && own) d.state[(size_t)c * n + e] = t;
+  return t;
+}
+
+#ifndef AUV_DEVICE_FUNCS_ONLY
+template <typename AT>
+__global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const AT* __restrict__ actions) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x % AUV_WAVE;
+  const int c = lane % K1_GROUP;
+  const size_t n = (size_t)d.n;
+  const bool live = tid / K1_GROUP < d.n;
+  const int e = live ? tid / K1_GROUP : d.n - 1;          // idle groups compute along, store nothing
+  const double t = k1_group<AT>(d, actions, e, lane);
+  if (live && c < 6) d.state[(size_t)c * n + e] = t;
   if (live && c == 0) d.counters[e].y += 1;                // Vessel._step_counter (vessel.py:247)
 }
 #endif

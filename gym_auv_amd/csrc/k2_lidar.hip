@@ -67,41 +67,6 @@ __device__ __forceinline__ int wrap_ray(int i, int S) {   // Python list index f
   return i;
 }
 
-// point in closed polygon; "on the boundary" (GEOS distance == 0) decided with the same
-// predicates as Distance::pointToSegment == 0, without its divisions / square roots
-template <typename SegPtr>
-__device__ __forceinline__ bool point_in_polygon(double px, double py, SegPtr seg, int nseg) {
-  bool inside = false;
-  for (int i = 0; i < nseg; i++) {
-    double4 s = seg[i];
-    double ex = s.z - s.x, ey = s.w - s.y;
-    double dxa = px - s.x, dya = py - s.y;
-    double len2 = ex * ex + ey * ey;
-    double dot = dxa * ex + dya * ey;
-    bool on;
-    if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
-    else if (dot >= len2) on = (px == s.z && py == s.w);
-    else on = ((s.y - py) * ex - (s.x - px) * ey) == 0.0;
-    if (on) return true;
-    if ((s.y > py) != (s.w > py)) {
-      double xint = s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
-      if (px < xint) inside = !inside;
-    }
-  }
-  return inside;
-}
-
-template <typename SegPtr>
-__device__ __forceinline__ double point_boundary_distance(double px, double py, SegPtr seg, int nseg) {
-  double best = 1.0e300;
-  for (int i = 0; i < nseg; i++) {
-    double4 s = seg[i];
-    double t = auv_pt_seg_dist(px, py, s.x, s.y, s.z, s.w);
-    if (t < best) best = t;
-  }
-  return best;
-}
-
 // The five boundary segments of a mover (obstacles.py:217-233) formed on demand from its pose, with
 // the arithmetic phase A used to form them: LDS keeps 40 bytes per mover instead of 160.
 struct MoverSegs {
@@ -211,15 +176,43 @@ __device__ __forceinline__ void sweep_unstaged(const ObsLds& o, int tid, int nth
   }
 }
 
+// inside flag of one filled obstacle straight from its boundary in HBM/LDS, lanes <-> segments
+// (ballot: any on-boundary, parity of crossings).  "On the boundary" (GEOS distance == 0) is decided with
+// the same predicates as Distance::pointToSegment == 0, without its divisions / square roots
+template <typename SegPtr>
+__device__ __forceinline__ int inside_flag_wave(double px, double py, SegPtr g, int nseg, int lane) {
+  int on_any = 0, cross = 0;
+  for (int sb = 0; sb < nseg; sb += AUV_WAVE) {
+    const int si = sb + lane;
+    bool on = false, cr = false;
+    if (si < nseg) {
+      const double4 s = g[si];
+      const double sx = s.z - s.x, sy = s.w - s.y, dxa = px - s.x, dya = py - s.y;
+      const double len2 = sx * sx + sy * sy, dot = dxa * sx + dya * sy;
+      if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
+      else if (dot >= len2) on = (px == s.z && py == s.w);
+      else on = ((s.y - py) * sx - (s.x - px) * sy) == 0.0;
+      if ((s.y > py) != (s.w > py)) cr = px < s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
+    }
+    on_any |= __any(on);
+    cross += __popcll(__ballot(cr));
+  }
+  return (on_any ? 2 : 0) | (cross & 1);
+}
+
 // phases A, C, B, S for one environment, by one wave
+// cs_pre: cos / sin of the heading when the dynamics kernel of this step has left them (pose_cs);
+// nullptr = form them here (same function, same argument: the same bits)
 __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
-                        const EnvPre* pre = nullptr) {
+                        const EnvPre* pre = nullptr, const double2* cs_pre = nullptr) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const int4 cnt = pre ? pre->cnt : d.counters[e];
   const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
                psi = pre ? pre->s[2] : d.state[2 * n + e];
   const EnvDesc ed = d.env_desc[e];
+  double2 cs_in = make_double2(0.0, 0.0);
+  if (cs_pre) cs_in = cs_pre[e];
   const long long k0 = ed.k0;
   const int K = ed.K;
   const long long m0 = ed.m0;
@@ -281,7 +274,8 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       const int i = q * AUV_WAVE + lane;
       b[q] = d.beam_cs[i < S ? i : 0];                      // cos, sin of -pi + (i + 1) * dangle
     }
-    sincos(psi, &sin_psi, &cos_psi);
+    if (cs_pre) cos_psi = cs_in.x, sin_psi = cs_in.y;
+    else sincos(psi, &sin_psi, &cos_psi);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int i = q * AUV_WAVE + lane;
@@ -294,7 +288,8 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       }
     }
   } else {
-    sincos(psi, &sin_psi, &cos_psi);
+    if (cs_pre) cos_psi = cs_in.x, sin_psi = cs_in.y;
+    else sincos(psi, &sin_psi, &cos_psi);
     for (int i = lane; i < S; i += AUV_WAVE) {
       const double2 b = d.beam_cs[i];
       const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
@@ -310,38 +305,85 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   //      distance loops do not sit inside its register budget ----
   const bool refresh = (cnt.y % d.cfg.sensor_interval_load_obstacles) == 0;
   if (refresh) {
-    for (int k = lane; k < K; k += AUV_WAVE) {
-      const int4 meta = d.obs_meta[k0 + k];
-      const bool mover = meta.x == AUV_OBS_MOVER;
+    for (int kb = 0; kb < K; kb += AUV_WAVE) {
+      const int k = kb + lane;
       // Point.distance(boundary) - width < range (filled: 0 inside).  The boundary lies inside the
       // obstacle's enclosing circle (c, rho), so
       //   |p0 - c| - rho <= distance(p0, boundary) <= |p0 - c| + rho ;
       // only obstacles the two bounds cannot classify need the exact distance (same answer,
       // far fewer segment loops).  1e-9 m of slack keeps rounding on the exact side.
-      double cx, cy, rho;
-      if (mover) {
-        const double2 c2 = L.mvcull[meta.w];
-        cx = c2.x, cy = c2.y, rho = L.mvw[meta.w] * sqrt(5.0) / 2.0;
-      } else {
-        cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
+      int4 meta = make_int4(0, 0, 0, 0);
+      double dc = 0.0, rho = 0.0;
+      int state = 0;                                          // 0 far, 1 near, 2 undecided
+      if (k < K) {
+        meta = d.obs_meta[k0 + k];
+        double cx, cy;
+        if (meta.x == AUV_OBS_MOVER) {
+          const double2 c2 = L.mvcull[meta.w];
+          cx = c2.x, cy = c2.y, rho = L.mvw[meta.w] * sqrt(5.0) / 2.0;
+        } else {
+          cx = d.obs_cull[3 * (k0 + k)], cy = d.obs_cull[3 * (k0 + k) + 1], rho = d.obs_cull[3 * (k0 + k) + 2];
+        }
+        dc = sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy));
+        state = (dc - rho - W >= R + 1e-9) ? 0 : ((dc + rho - W < R - 1e-9) ? 1 : 2);
       }
-      const double dc = sqrt((px - cx) * (px - cx) + (py - cy) * (py - cy));
-      uint8_t near;
-      if (dc - rho - W >= R + 1e-9) {
-        near = 0;
-      } else if (dc + rho - W < R - 1e-9) {
-        near = 1;
-      } else {
-        bool in = false;
-        if (meta.x != AUV_OBS_RING)
-          in = mover ? point_in_polygon(px, py, mover_segs(L.mvrot[meta.w], L.mvw[meta.w]), meta.z)
-                     : point_in_polygon(px, py, d.seg + meta.y, meta.z);
-        const double dist = in ? 0.0
-                               : (mover ? point_boundary_distance(px, py, mover_segs(L.mvrot[meta.w], L.mvw[meta.w]), meta.z)
-                                        : point_boundary_distance(px, py, d.seg + meta.y, meta.z));
-        near = (dist - W < R) ? 1 : 0;
+      // The undecided few.  An environment that refreshes is otherwise the launch's straggler (the
+      // slowest wave ends the kernel), so their boundaries are walked by the whole wave, flattened:
+      // lanes <-> (obstacle, segment) pairs, every pass one trip to memory.  The decision
+      // fl(min_t - W) < R equals OR over segments of fl(t - W) < R (rounding is monotone), so an LDS
+      // flag per obstacle replaces the min.  act / sbase / par / obs are free scratch here (phase B
+      // rewrites them).
+      // (rare) a filled obstacle whose enclosing circle contains p0: exact inside test first
+      unsigned long long pin = __ballot(state == 2 && meta.x != AUV_OBS_RING && dc <= rho * (1.0 + 1e-9) + 1e-9);
+      while (pin) {
+        const int src = __ffsll((long long)pin) - 1;
+        pin &= pin - 1;
+        const int kind = __shfl(meta.x, src, AUV_WAVE), soff = __shfl(meta.y, src, AUV_WAVE),
+                  nseg = __shfl(meta.z, src, AUV_WAVE), mi = __shfl(meta.w, src, AUV_WAVE);
+        const int in = (kind == AUV_OBS_MOVER) ? inside_flag_wave(px, py, mover_segs(L.mvrot[mi], L.mvw[mi]), nseg, lane)
+                                               : inside_flag_wave(px, py, d.seg + soff, nseg, lane);
+        if (in && lane == src) state = 1;                       // distance 0
       }
-      d.nearby[(size_t)e * d.k_max + k] = near;              // read back below by the same lane
+      const unsigned long long und = __ballot(state == 2);
+      if (und) {
+        const int nu = __popcll(und), pos = __popcll(und & ((1ull << lane) - 1ull));
+        int incl = (state == 2) ? meta.z : 0;
+#pragma unroll
+        for (int o = 1; o < AUV_WAVE; o <<= 1) {
+          const int t = __shfl_up(incl, o, AUV_WAVE);
+          if (lane >= o) incl += t;
+        }
+        const int total = __shfl(incl, AUV_WAVE - 1, AUV_WAVE);
+        if (state == 2) {
+          ObsLds o;
+          o.kind = meta.x, o.seg_off = (meta.x == AUV_OBS_MOVER) ? meta.w : meta.y, o.nseg = meta.z;
+          o.start = 0, o.count = 0, o.wind = 0;
+          L.obs[pos] = o;
+          L.sbase[pos + 1] = incl;
+          L.par[pos] = 0;
+        }
+        if (lane == 0) L.sbase[0] = 0;
+        auv_wave_lds_sync();
+        for (int tb = 0; tb < total; tb += AUV_WAVE) {
+          const int t = tb + lane;
+          if (t < total) {
+            int lo = 0, hi = nu;                                 // largest a with sbase[a] <= t
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if (L.sbase[mid] <= t) lo = mid; else hi = mid;
+            }
+            const ObsLds o = L.obs[lo];
+            const int si = t - L.sbase[lo];
+            const double4 sg = (o.kind == AUV_OBS_MOVER) ? mover_segs(L.mvrot[o.seg_off], L.mvw[o.seg_off])[si] : d.seg[o.seg_off + si];
+            const double dist = auv_pt_seg_dist(px, py, sg.x, sg.y, sg.z, sg.w);
+            if (dist - W < R) atomicOr(&L.par[lo], 1);
+          }
+        }
+        auv_wave_lds_sync();
+        if (state == 2) state = L.par[pos] ? 1 : 0;
+        auv_wave_lds_sync();                                     // (the scratch is reused by the next block of obstacles)
+      }
+      if (k < K) d.nearby[(size_t)e * d.k_max + k] = (uint8_t)state;   // read back below by the same lane
     }
   }
 
@@ -434,29 +476,6 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   }
   auv_wave_lds_sync();
   return n_act;
-}
-
-// inside flag of one filled obstacle straight from its boundary in HBM/LDS, lanes <-> segments
-// (ballot: any on-boundary, parity of crossings): same predicates as point_in_polygon
-template <typename SegPtr>
-__device__ __forceinline__ int inside_flag_wave(double px, double py, SegPtr g, int nseg, int lane) {
-  int on_any = 0, cross = 0;
-  for (int sb = 0; sb < nseg; sb += AUV_WAVE) {
-    const int si = sb + lane;
-    bool on = false, cr = false;
-    if (si < nseg) {
-      const double4 s = g[si];
-      const double sx = s.z - s.x, sy = s.w - s.y, dxa = px - s.x, dya = py - s.y;
-      const double len2 = sx * sx + sy * sy, dot = dxa * sx + dya * sy;
-      if (len2 == 0.0 || dot <= 0.0) on = (dxa == 0.0 && dya == 0.0);
-      else if (dot >= len2) on = (px == s.z && py == s.w);
-      else on = ((s.y - py) * sx - (s.x - px) * sy) == 0.0;
-      if ((s.y > py) != (s.w > py)) cr = px < s.x + (py - s.y) * (s.z - s.x) / (s.w - s.y);
-    }
-    on_any |= __any(on);
-    cross += __popcll(__ballot(cr));
-  }
-  return (on_any ? 2 : 0) | (cross & 1);
 }
 
 // phases S + D for one environment, by one wave, in batches of <= K2_SEG_CAP boundary segments
@@ -552,7 +571,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
           }
         }
         if (o.kind != AUV_OBS_RING) {
-          // point-in-polygon predicates of this boundary segment (same tests as point_in_polygon)
+          // point-in-polygon predicates of this boundary segment (same tests as inside_flag_wave)
           const double dxa = px - s.x, dya = py - s.y;
           const double len2 = sx * sx + sy * sy;
           const double dot = dxa * sx + dya * sy;
@@ -675,7 +694,8 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 // term of the Colav reward (rewarder.py:205-222: sum of gamma_theta-weighted R exp(-0.1 d) over
 // the beams; the velocity channel is identically zero, sensor.py:159) and the float32 closeness
 // columns of the observation row.
-__device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, float* __restrict__ obs_out = nullptr) {
+__device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, float* __restrict__ obs_out = nullptr,
+                       double* rew_lidar_out = nullptr) {
   const int S = d.cfg.n_sensors;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   int col = 0;
@@ -714,10 +734,12 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
   }
   col = __any(col);
   if (colav) num = auv_wave_sum(num);
+  const double term = (colav && S > 0) ? -num / d.derived[2] : 0.0;   // the same in every lane
   if (lane == 0) {
     d.collision[e] = (uint8_t)(col != 0);
-    if (colav) d.rew_lidar[e] = (S > 0) ? -num / d.derived[2] : 0.0;
+    if (colav) d.rew_lidar[e] = term;
   }
+  if (rew_lidar_out) *rew_lidar_out = term;
   return col != 0;
 }
 

@@ -61,9 +61,65 @@ __device__ __forceinline__ MinIdx wave_min_first(MinIdx v) {
 // SciPy PPoly: interval search + power-basis eval.  The knots are near-uniform, so the interval
 // is guessed from s / L and the knots and coefficient rows around the guess are fetched together
 // (one trip to memory); only a guess that is off by more than one interval walks and re-fetches.
-// x0 / xl: the first / last knot, fetched by the caller ahead of time.
+// KnotWin = such a two-interval window: knots [g, g+2] and the coefficient rows g, g+1.  The step's
+// navigation requests it for LAST step's arclength before the vessel has even moved (the vessel
+// advances a fraction of an interval per step), so the evaluation usually needs no trip at all.
+struct KnotWin {
+  double xa, xb, xc;       // knots g, g+1, g+2
+  double ca[8], cb[8];     // coefficient rows g, g+1
+  bool have;
+};
+
+__device__ __forceinline__ KnotWin knot_window(const AuvDev& d, long long k0, int nk, double x0, double xl, double s,
+                                               double L) {
+  KnotWin w;
+  w.have = false;
+  w.xa = w.xb = w.xc = 0.0;
+#pragma unroll
+  for (int a = 0; a < 8; a++) w.ca[a] = w.cb[a] = 0.0;
+  if (!(s >= x0) || s >= xl || nk < 4) return w;
+  const double* x = d.knot_s + k0;
+  const double* cf = d.knot_coef + 8 * k0;
+  const double fi = s / L * (nk - 1);
+  int i = (int)fi;
+  i = i < 0 ? 0 : (i > nk - 2 ? nk - 2 : i);
+  // two adjacent intervals around the guess: the guessed one and the neighbour on the side the
+  // fractional position leans to
+  int g = (fi - (double)i < 0.5) ? i - 1 : i;
+  g = g < 0 ? 0 : (g > nk - 3 ? nk - 3 : g);
+  w.xa = x[g], w.xb = x[g + 1], w.xc = x[g + 2];
+  // coefficient rows are 64-byte records: four 16-byte loads each instead of eight 8-byte ones
+  // (the vector memory pipe takes a wave's load in the same time whatever its width)
+  const double2* r2 = (const double2*)(cf + 8 * (size_t)g);
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const double2 va = r2[a], vb = r2[4 + a];
+    w.ca[2 * a] = va.x, w.ca[2 * a + 1] = va.y, w.cb[2 * a] = vb.x, w.cb[2 * a + 1] = vb.y;
+  }
+  w.have = true;
+  return w;
+}
+
+// a lane's spline window parked in LDS (20 doubles) while something register-hungry runs
+__device__ __forceinline__ void knot_win_store(const KnotWin& w, double* slot) {
+  slot[0] = w.have ? 1.0 : 0.0, slot[1] = w.xa, slot[2] = w.xb, slot[3] = w.xc;
+#pragma unroll
+  for (int a = 0; a < 8; a++) slot[4 + a] = w.ca[a], slot[12 + a] = w.cb[a];
+}
+__device__ __forceinline__ KnotWin knot_win_load(const double* slot) {
+  KnotWin w;
+  w.have = slot[0] != 0.0, w.xa = slot[1], w.xb = slot[2], w.xc = slot[3];
+#pragma unroll
+  for (int a = 0; a < 8; a++) w.ca[a] = slot[4 + a], w.cb[a] = slot[12 + a];
+  return w;
+}
+
+// x0 / xl: the first / last knot, fetched by the caller ahead of time.  `slot`: a window requested
+// earlier for a nearby arclength and parked in LDS (knot_win_store; used if it contains s, and read
+// row by row so that it never occupies registers as a whole); the coefficient row is the same row
+// whichever way it is reached, so the result does not depend on the window.
 __device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk, double x0, double xl, double s,
-                                          double L, double xy[2], double dxy[2]) {
+                                          double L, double xy[2], double dxy[2], const double* slot = nullptr) {
   const double* x = d.knot_s + k0;
   const double* cf = d.knot_coef + 8 * k0;
   int i;
@@ -75,33 +131,31 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk,
   } else if (s >= xl) {
     i = nk - 2;
   } else {
-    const double fi = s / L * (nk - 1);
-    i = (int)fi;
-    i = i < 0 ? 0 : (i > nk - 2 ? nk - 2 : i);
-    if (nk >= 4) {
-      // two adjacent intervals around the guess: the guessed one and the neighbour on the side the
-      // fractional position leans to -- knots [g, g+2] and coefficient rows g, g+1
-      int g = (fi - (double)i < 0.5) ? i - 1 : i;
-      g = g < 0 ? 0 : (g > nk - 3 ? nk - 3 : g);
-      const double xa = x[g], xb = x[g + 1], xc = x[g + 2];
-      // coefficient rows are 64-byte records: four 16-byte loads each instead of eight 8-byte ones
-      // (the vector memory pipe takes a wave's load in the same time whatever its width)
-      double ca[8], cb8[8];
-      const double2* r2 = (const double2*)(cf + 8 * (size_t)g);
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        const double2 va = r2[a], vb = r2[4 + a];
-        ca[2 * a] = va.x, ca[2 * a + 1] = va.y, cb8[2 * a] = vb.x, cb8[2 * a + 1] = vb.y;
-      }
+    if (slot && slot[0] != 0.0) {
+      const double xa = slot[1], xb = slot[2], xc = slot[3];
       if (s >= xa && s < xc) {
         const bool second = s >= xb;
         xi = second ? xb : xa;
+        const double* row = slot + (second ? 12 : 4);
 #pragma unroll
-        for (int a = 0; a < 8; a++) c[a] = second ? cb8[a] : ca[a];
+        for (int a = 0; a < 8; a++) c[a] = row[a];
         have = true;
       }
     }
     if (!have) {
+      const KnotWin w = knot_window(d, k0, nk, x0, xl, s, L);
+      if (w.have && s >= w.xa && s < w.xc) {
+        const bool second = s >= w.xb;
+        xi = second ? w.xb : w.xa;
+#pragma unroll
+        for (int a = 0; a < 8; a++) c[a] = second ? w.cb[a] : w.ca[a];
+        have = true;
+      }
+    }
+    if (!have) {
+      const double fi = s / L * (nk - 1);
+      i = (int)fi;
+      i = i < 0 ? 0 : (i > nk - 2 ? nk - 2 : i);
       while (i > 0 && s < x[i]) i--;
       while (i < nk - 2 && s >= x[i + 1]) i++;
     }
@@ -131,6 +185,17 @@ __device__ __forceinline__ double reward_path_term(const AuvDev& d, double u, do
   const double speed = sqrt(u * u + v * v);
   const double ctp = exp(-gamma_y_e * fabs(cross_track_error));
   double path_reward = (1 + cos(heading_error) * speed / max_speed) * (1 + ctp) - 1;
+  if (d.cfg.rewarder == AUV_REWARD_COLAV && progress < max_progress) path_reward = fmin(path_reward, 0.0);
+  return path_reward;
+}
+
+// the same with cos(heading_error) handed in (the navigation forms it without the angle)
+__device__ __forceinline__ double reward_path_term_cos(const AuvDev& d, double u, double v, double cos_heading_error,
+                                                       double cross_track_error, double progress, double max_progress) {
+  const double gamma_y_e = 5.0, max_speed = 2.0;
+  const double speed = sqrt(u * u + v * v);
+  const double ctp = exp(-gamma_y_e * fabs(cross_track_error));
+  double path_reward = (1 + cos_heading_error * speed / max_speed) * (1 + ctp) - 1;
   if (d.cfg.rewarder == AUV_REWARD_COLAV && progress < max_progress) path_reward = fmin(path_reward, 0.0);
   return path_reward;
 }
@@ -271,83 +336,111 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
 }
 
 // ---- navigation part (Vessel.navigate + the six navigation observations) ----------------------
-// Independent of the LiDAR sweep, so the step path runs it concurrently with K2.
-__device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* list, float* __restrict__ obs_out,
-                           const EnvPre* pre = nullptr) {
-  const int S = d.cfg.n_sensors;
-  const size_t n = (size_t)d.n;
-  const EnvDesc ed = d.env_desc[e];
-  const int w = ed.w;
-  const double* ws = d.world_scalar + 8 * (size_t)w;
-  const double L = ws[0];
-  const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
-               psi = pre ? pre->s[2] : d.state[2 * n + e];
-  double* inf = d.info64 + 8 * (size_t)e;
-  double* nv = d.nav64 + 8 * (size_t)e;
-  double* ob = d.obs64 + (size_t)e * (6 + S);
-  const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
+// Independent of the LiDAR sweep, so the step path runs it concurrently with K2 or right behind K1.
+//
+// The nearest-point search is split in two so that everything that touches memory can be requested
+// BEFORE the vessel's new pose exists (the dynamics + navigation kernel does this while the dynamics
+// are being integrated):
+//   nav_speculate(q, slack)  chunk circles against a pose guess q (the pose before the step), U =
+//                            min (|q - c| + rad), survivors |q - c| - rad <= U + slack listed in
+//                            LDS, and -- if at most NAV_SPEC survive -- their 64 segments each
+//                            fetched into registers; plus the spline windows around last step's
+//                            arclength.
+//   nav_finish(p)            if |p - q| <= NAV_DELTA the survivor list is a superset of the
+//                            survivors of p (every circle distance moves by at most |p - q|, so a
+//                            survivor of p has |q - c| - rad <= U_p + |p - q| <= U_q + 2 |p - q|; the
+//                            slack is 2 NAV_DELTA): the exact distances to the listed segments are
+//                            formed with p, the (distance, first index) minimum over them is the
+//                            brute-force result.  Otherwise (or without a guess) the speculation is
+//                            simply redone for p with zero slack.
+// The winner is the same segment whichever superset it was picked from, so all launch shapes
+// produce the same bits.
+constexpr int NAV_CPL = 4;           // chunk circles per lane kept in registers (paths up to 16 k vertices)
+constexpr int NAV_SPEC = 2;          // speculative chunks whose segments are held in registers
+#define NAV_DELTA 1.0                // metres the pose may differ from the guess (a step moves ~0.25 m)
 
-  // operands of the scalar tail, requested now so that their trip to memory overlaps the polyline search
-  const double knot_first = d.knot_s[ed.kn0], knot_last = d.knot_s[ed.kn0 + ed.nk - 1];
-  const double goal_x = ws[1], goal_y = ws[2];
-  const double maxp_in = inf[5];
-  const double u = pre ? pre->s[3] : d.state[3 * n + e], v = pre ? pre->s[4] : d.state[4 * n + e],
-               r = pre ? pre->s[5] : d.state[5 * n + e];
+struct NavSpec {
+  EnvDesc ed;
+  double L, goal_x, goal_y, knot_first, knot_last, maxp_in;
+  double qx, qy;                     // the pose guess the list was made for
+  int n_list;                        // surviving chunks listed in LDS (ascending)
+  bool in_regs;                      // n_list <= NAV_SPEC: their segments are in A / B / cum below
+  double2 A[NAV_SPEC], B[NAV_SPEC];  // this lane's segment of speculative chunk q
+  double cum[NAV_SPEC];              // cumulative arclength at its first vertex
+};
 
-  AUV_STAMP_DECL
-  // ---- nearest point on the dense polyline (path.py:84-93), exact with chunk pruning ----
-  const long long p0 = ed.p0;
-  const int P = ed.P;
-  const double2* xy = d.poly_xy + p0;
-  const long long c0 = ed.c0;
-  const int nch = ed.nch;
-  const double4* cb = d.chunk_bound + c0;
-  // up to 4 chunks per lane stay in registers (paths up to 16 k vertices); their loads are
-  // issued together.  Longer paths take the generic two-pass route below.
-  constexpr int CPL = 4;
-  double cdist[CPL], crad[CPL];
+// win_slots: LDS, [3][20] doubles of this wave, or nullptr: the spline windows around last step's arclength
+// (lane 0 will evaluate at s, lanes 1 and 2 at min(L, s + look-ahead)) are parked there
+__device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, const int lane, int* list, const double qx,
+                                                 const double qy, const double slack, double* win_slots) {
+  NavSpec sp;
+  sp.ed = d.env_desc[e];
+  const EnvDesc& ed = sp.ed;
+  const double* ws = d.world_scalar + 8 * (size_t)ed.w;
+  sp.L = ws[0], sp.goal_x = ws[1], sp.goal_y = ws[2];
+  sp.knot_first = d.knot_s[ed.kn0], sp.knot_last = d.knot_s[ed.kn0 + ed.nk - 1];
+  const double2 prog = ((const double2*)(d.info64 + 8 * (size_t)e))[3 - 0];   // [6] arclength of last step, [7] spare
+  sp.maxp_in = d.info64[8 * (size_t)e + 5];
+  sp.qx = qx, sp.qy = qy;
+  const int nch = ed.nch, P = ed.P;
+  const double4* cb = d.chunk_bound + ed.c0;
+  const double2* xy = d.poly_xy + ed.p0;
   double U = 1.7976931348623157e308;
-  const bool in_regs = nch <= CPL * AUV_WAVE;
-  if (in_regs) {
-    double4 b[CPL];
+  int n_act = 0;
+  if (nch <= NAV_CPL * AUV_WAVE) {
+    double4 b[NAV_CPL];
+    double cdist[NAV_CPL];
 #pragma unroll
-    for (int i = 0; i < CPL; i++) {
+    for (int i = 0; i < NAV_CPL; i++) {
       const int c = i * AUV_WAVE + lane;
       b[i] = cb[c < nch ? c : nch - 1];
     }
 #pragma unroll
-    for (int i = 0; i < CPL; i++) {
-      const double dx = px - b[i].x, dy = py - b[i].y;
+    for (int i = 0; i < NAV_CPL; i++) {
+      const double dx = qx - b[i].x, dy = qy - b[i].y;
       cdist[i] = sqrt(dx * dx + dy * dy);
-      crad[i] = b[i].z;
-      if (i * AUV_WAVE + lane < nch) U = fmin(U, cdist[i] + crad[i]);
     }
-  } else {
-    for (int c = lane; c < nch; c += AUV_WAVE) {
-      double4 b = cb[c];
-      double dx = px - b.x, dy = py - b.y;
-      U = fmin(U, sqrt(dx * dx + dy * dy) + b.z);
-    }
-  }
-  U = auv_wave_min(U);
-  AUV_STAMP()
-  int n_act = 0;
-  if (in_regs) {
+    // upper bound on the distance to the path: first from the circles (min of |q - c| + rad), then the
+    // EXACT distance to the 64 segments of the chunk that gave it -- within a few centimetres of the
+    // truth instead of a chunk diameter, so that typically one or two chunks survive
+    MinIdx ub;
+    ub.d = 1.7976931348623157e308, ub.j = 0;
 #pragma unroll
-    for (int i = 0; i < CPL; i++) {
+    for (int i = 0; i < NAV_CPL; i++) {
       const int c = i * AUV_WAVE + lane;
-      const bool act = (c < nch) && (cdist[i] - crad[i] <= U);
+      if (c < nch && cdist[i] + b[i].z < ub.d) ub.d = cdist[i] + b[i].z, ub.j = c;
+    }
+    ub = wave_min_first(ub);
+    {
+      const int j = ub.j * AUV_CHUNK + lane;
+      double dd = 1.7976931348623157e308;
+      if (j < P - 1) {
+        const double2 A = xy[j], B = xy[j + 1];
+        dd = auv_pt_seg_dist(qx, qy, A.x, A.y, B.x, B.y);
+      }
+      U = fmin(ub.d, auv_wave_min(dd)) + slack;
+    }
+#pragma unroll
+    for (int i = 0; i < NAV_CPL; i++) {
+      const int c = i * AUV_WAVE + lane;
+      const bool act = (c < nch) && (cdist[i] - b[i].z <= U);
       const unsigned long long mask = __ballot(act);
       if (act) list[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = c;
       n_act += __popcll(mask);
     }
   } else {
+    for (int c = lane; c < nch; c += AUV_WAVE) {
+      const double4 b = cb[c];
+      const double dx = qx - b.x, dy = qy - b.y;
+      U = fmin(U, sqrt(dx * dx + dy * dy) + b.z);
+    }
+    U = auv_wave_min(U) + slack;
     for (int cbase = 0; cbase < nch; cbase += AUV_WAVE) {
       const int c = cbase + lane;
       bool act = false;
       if (c < nch) {
-        double4 b = cb[c];
-        double dx = px - b.x, dy = py - b.y;
+        const double4 b = cb[c];
+        const double dx = qx - b.x, dy = qy - b.y;
         act = (sqrt(dx * dx + dy * dy) - b.z) <= U;
       }
       const unsigned long long mask = __ballot(act);
@@ -356,28 +449,102 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
     }
   }
   auv_wave_lds_sync();
+  sp.n_list = n_act;
+  sp.in_regs = n_act <= NAV_SPEC;
+#pragma unroll
+  for (int q = 0; q < NAV_SPEC; q++) {
+    sp.A[q] = sp.B[q] = make_double2(0.0, 0.0);
+    sp.cum[q] = 0.0;
+    if (sp.in_regs && q < n_act) {
+      const int j = list[q] * AUV_CHUNK + lane;
+      const int jj = j < P - 1 ? j : 0;
+      sp.A[q] = xy[jj], sp.B[q] = xy[jj + 1], sp.cum[q] = d.poly_cum[ed.p0 + jj];
+    }
+  }
+  if (win_slots && lane < 3) {
+    double s_guess = prog.x;
+    if (lane != 0) {
+      s_guess += d.cfg.look_ahead_distance;
+      if (sp.L < s_guess) s_guess = sp.L;
+    }
+    knot_win_store(knot_window(d, ed.kn0, ed.nk, sp.knot_first, sp.knot_last, s_guess, sp.L), win_slots + lane * 20);
+  }
+  return sp;
+}
+
+__device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const int lane, int* list,
+                                           float* __restrict__ obs_out, const EnvPre* pre, NavSpec sp, const bool have_spec,
+                                           const double* win_slots, const double2* pose_cs_in) {
+  const int S = d.cfg.n_sensors;
+  const size_t n = (size_t)d.n;
+  const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
+               psi = pre ? pre->s[2] : d.state[2 * n + e];
+  const double u = pre ? pre->s[3] : d.state[3 * n + e], v = pre ? pre->s[4] : d.state[4 * n + e],
+               r = pre ? pre->s[5] : d.state[5 * n + e];
+  AUV_STAMP_DECL
+  // is the guess close enough for its list to cover the survivors of the real pose?
+  bool usable = have_spec;
+  if (usable) {
+    const double mx = px - sp.qx, my = py - sp.qy;
+    usable = (mx * mx + my * my) <= NAV_DELTA * NAV_DELTA;   // (NaN compares false)
+  }
+  if (!usable) sp = nav_speculate(d, e, lane, list, px, py, 0.0, nullptr);   // (parked spline windows stay valid: they do not depend on the pose)
+  const EnvDesc ed = sp.ed;
+  const double L = sp.L;
+  double* inf = d.info64 + 8 * (size_t)e;
+  double* nv = d.nav64 + 8 * (size_t)e;
+  double* ob = d.obs64 + (size_t)e * (6 + S);
+  const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
+  const double knot_first = sp.knot_first, knot_last = sp.knot_last;
+  const double goal_x = sp.goal_x, goal_y = sp.goal_y;
+  const double maxp_in = sp.maxp_in;
+  const long long p0 = ed.p0;
+  const int P = ed.P;
+  const double2* xy = d.poly_xy + p0;
   AUV_STAMP()
+  AUV_STAMP()
+  // ---- exact distances to the listed segments (path.py:84-93): (distance, first index) minimum ----
   MinIdx best;
   best.d = 1.7976931348623157e308;
   best.j = 0x7fffffff;
   double2 bA = make_double2(0.0, 0.0), bB = bA;        // end points of this lane's best segment
-  for (int a = 0; a < n_act; a += 2) {                 // two surviving chunks per trip to memory
-    const bool two = a + 1 < n_act;
-    const int ja = list[a] * AUV_CHUNK + lane, jb = two ? list[a + 1] * AUV_CHUNK + lane : ja;
-    const bool va = ja < P - 1, vb = two && jb < P - 1;
-    const double2 A0 = xy[va ? ja : 0], B0 = xy[va ? ja + 1 : 0], A1 = xy[vb ? jb : 0], B1 = xy[vb ? jb + 1 : 0];
-    if (va) {
-      const double dd = auv_pt_seg_dist(px, py, A0.x, A0.y, B0.x, B0.y);
-      if (dd < best.d) best.d = dd, best.j = ja, bA = A0, bB = B0;      // ascending j: strict '<' keeps the first minimum
+  double my_cum = 0.0;
+  const int n_act = sp.n_list;
+  // cos / sin of the new heading for the reward's cos(heading error) below
+  // (handed in by the dynamics wave of the two-kernel step, which forms them for eight environments at once)
+  double sin_psi, cos_psi;
+  if (pose_cs_in) cos_psi = pose_cs_in->x, sin_psi = pose_cs_in->y;
+  else sincos(psi, &sin_psi, &cos_psi);
+  if (sp.in_regs) {
+#pragma unroll
+    for (int q = 0; q < NAV_SPEC; q++) {
+      if (q < n_act) {
+        const int j = list[q] * AUV_CHUNK + lane;
+        if (j < P - 1) {
+          const double dd = auv_pt_seg_dist(px, py, sp.A[q].x, sp.A[q].y, sp.B[q].x, sp.B[q].y);
+          if (dd < best.d) best.d = dd, best.j = j, bA = sp.A[q], bB = sp.B[q], my_cum = sp.cum[q];   // ascending j: strict '<' keeps the first minimum
+        }
+      }
     }
-    if (vb) {
-      const double dd = auv_pt_seg_dist(px, py, A1.x, A1.y, B1.x, B1.y);
-      if (dd < best.d) best.d = dd, best.j = jb, bA = A1, bB = B1;
+  } else {
+    for (int a = 0; a < n_act; a += 2) {                 // two surviving chunks per trip to memory
+      const bool two = a + 1 < n_act;
+      const int ja = list[a] * AUV_CHUNK + lane, jb = two ? list[a + 1] * AUV_CHUNK + lane : ja;
+      const bool va = ja < P - 1, vb = two && jb < P - 1;
+      const double2 A0 = xy[va ? ja : 0], B0 = xy[va ? ja + 1 : 0], A1 = xy[vb ? jb : 0], B1 = xy[vb ? jb + 1 : 0];
+      if (va) {
+        const double dd = auv_pt_seg_dist(px, py, A0.x, A0.y, B0.x, B0.y);
+        if (dd < best.d) best.d = dd, best.j = ja, bA = A0, bB = B0;
+      }
+      if (vb) {
+        const double dd = auv_pt_seg_dist(px, py, A1.x, A1.y, B1.x, B1.y);
+        if (dd < best.d) best.d = dd, best.j = jb, bA = A1, bB = B1;
+      }
     }
+    // cumulative length at this lane's candidate, requested while the reduction runs
+    my_cum = d.poly_cum[p0 + (best.j < P - 1 ? best.j : 0)];
   }
-  // cumulative length at this lane's candidate, requested while the reduction runs
   const int my_j = best.j;
-  const double my_cum = d.poly_cum[p0 + (my_j < P - 1 ? my_j : 0)];
   best = wave_min_first(best);
   AUV_STAMP()
   const int bj = best.j;
@@ -399,18 +566,24 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   // one atan2 then serves all three angles: lane 0 chi, lane 1 the look-ahead direction, lane 2
   // the heading towards the look-ahead point
   double p[2], dp[2];
-  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, lane == 0 ? s : s_t, L, p, dp);
+  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, lane == 0 ? s : s_t, L, p, dp,
+            (win_slots && lane < 3) ? win_slots + lane * 20 : nullptr);
   const double ang_y = (lane == 2) ? p[1] - py : dp[1], ang_x = (lane == 2) ? p[0] - px : dp[0];
   const double dir = atan2(ang_y, ang_x);
+  // unit vector of (ang_x, ang_y): lane 0 cos / sin of chi, lane 2 of the direction to the look-ahead
+  // point -- formed beside the atan2, not from it, so that the cross-track error and the reward's
+  // cos(heading error) do not wait for the angle (sin(atan2(y, x)) = y / |(x, y)| to rounding)
+  const double hyp = sqrt(ang_x * ang_x + ang_y * ang_y);
+  const double ux = hyp > 0.0 ? ang_x / hyp : 1.0, uy = hyp > 0.0 ? ang_y / hyp : 0.0;   // atan2(0, 0) = 0
   const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(dir, 2, AUV_WAVE);
+  const double tx = __shfl(ux, 2, AUV_WAVE), ty = __shfl(uy, 2, AUV_WAVE);
   if (lane == 0) {
     const double chi = dir;
     double ddx = p[0] - px, ddy = p[1] - py;
-    double sn, cs;
-    sincos(-chi, &sn, &cs);
-    double cte = sn * ddx + cs * ddy;
+    double cte = -uy * ddx + ux * ddy;                         // vessel.py:481-483: -sin(chi) dx + cos(chi) dy
     double la = auv_princip(la_dir - psi);
     double he = auv_princip(tgt1 - psi);
+    const double cos_he = tx * cos_psi + ty * sin_psi;        // cos(target direction - psi)
     double progress = s / L;
     double maxp = maxp_in;
     if (progress > maxp) maxp = progress;
@@ -425,7 +598,7 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
     inf[1] = reached, inf2[1] = make_double2(goal, progress), inf[5] = maxp, inf2[3] = make_double2(s, 0.0);
     // path-following term of the reward: everything it needs is at hand here, so the
     // transcendentals stay out of the reward phase
-    d.rew_path[e] = reward_path_term(d, u, v, he, cte100, progress, maxp);
+    d.rew_path[e] = reward_path_term_cos(d, u, v, cos_he, cte100, progress, maxp);
     // environment.py:276-280; lane 0 also emits the float32 copies of its own six values.  OBS64 rows
     // start 16-byte aligned when 6 + S is even, float32 rows 8-byte aligned when their stride is even.
     const double c0 = auv_clip(u, -1.0, 1.0), c1 = auv_clip(v, -1.0, 1.0), c2 = auv_clip(r, -1.0, 1.0),
@@ -450,6 +623,14 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
   AUV_STAMP_FLUSH(e, 8)   // 8:bounds 9:list 10:scan 11:nav
 }
 
+// the navigation of one environment in one go (no pose guess): the per-kernel API, the reset pass and the
+// launch shapes that run it behind a finished dynamics kernel
+__device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* list,
+                                           float* __restrict__ obs_out, const EnvPre* pre = nullptr) {
+  NavSpec none;
+  nav_finish(d, e, lane, list, obs_out, pre, none, false, nullptr, nullptr);
+}
+
 // ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----
 // full = false: only publish the collision flag and the float32 LiDAR observations (reset path)
 // from_buffers: form the two reward terms here from NAV64 / INFO64 / LIDAR_D as they stand (the
@@ -458,7 +639,8 @@ __device__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* li
 __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, const bool full,
                               float* __restrict__ obs_out, float* __restrict__ reward_out,
                               uint8_t* __restrict__ done_out, const EnvPre* pre = nullptr, const int collision_pre = -1,
-                              const bool from_buffers = false, const bool lidar_obs = true) {
+                              const bool from_buffers = false, const bool lidar_obs = true,
+                              const double* rew_lidar_pre = nullptr) {
   const int S = d.cfg.n_sensors;
   int4 cnt = pre ? pre->cnt : d.counters[e];
   const int w = d.world_idx[e];
@@ -482,7 +664,8 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
       // everything the block reads is requested up front (one trip to memory, whatever branch follows)
       const double2 uv = ((const double2*)nv)[0];           // rows are 64-byte records: 16-byte accesses
       const double u = uv.x, v = uv.y, yaw_rate = nv[2];
-      const double rew_path_in = d.rew_path[e], rew_lidar_in = d.rew_lidar[e];
+      // (the LiDAR term arrives in a register when the sweep ran in this very wave)
+      const double rew_path_in = d.rew_path[e], rew_lidar_in = rew_lidar_pre ? *rew_lidar_pre : d.rew_lidar[e];
       const double2 gp = ((const double2*)inf)[1];
       const double cum_in = inf[4], reached_in = inf[1], goal_in = gp.x, progress_in = gp.y;
       double reward;

@@ -98,6 +98,109 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* _
   }
 }
 
+// ---- the default step: TWO launches --------------------------------------------------------------
+// k1n_dyn_nav      Vessel.step for eight environments by ONE wave (eight lanes per environment), then
+//                  Vessel.navigate of those eight by the workgroup's eight waves.  While the
+//                  dynamics are being integrated every wave runs its navigation's nearest-point
+//                  search against the pose BEFORE the step and fetches what it finds (nav_speculate);
+//                  behind the barrier only arithmetic on registers is left (nav_finish).
+// k2r_lidar_reward _update + Vessel.perceive of one environment per one-wave workgroup and, in the
+//                  same wave, reward / done / bookkeeping / auto-reset: the navigation's results
+//                  are a kernel boundary old by then, the sweep's are in registers.
+// Same device functions, hence the same bits, as the other launch shapes.
+#ifndef K1N_ENVS
+#define K1N_ENVS 8
+#endif
+#define K1N_THREADS ((K1N_ENVS + 1) * AUV_WAVE)   // eight navigation waves + the dynamics wave
+template <typename AT>
+__global__ void __launch_bounds__(K1N_THREADS, 5) k1n_dyn_nav(AuvDev d, const AT* __restrict__ actions,
+                                                            float* __restrict__ obs_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* sh = (double*)smem;                                       // [K1N_ENVS][8]: the new state
+  double* wins = sh + K1N_ENVS * 8;                                 // [K1N_ENVS][3][20]: parked spline windows
+  int* lists = (int*)(wins + K1N_ENVS * 3 * 20);                    // [K1N_ENVS][nch_max] surviving chunks
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const size_t n = (size_t)d.n;
+  const int e0 = (int)blockIdx.x * K1N_ENVS;
+  if (wave == K1N_ENVS) {
+    // ---- the dynamics wave: Vessel.step of the workgroup's eight environments, eight lanes each.  (Its own
+    // branch, so that the navigation's prefetched registers are not live across the integrator.)
+    const int g = lane / K1_GROUP, c = lane % K1_GROUP;
+    const bool live = g < K1N_ENVS && e0 + g < d.n;
+    const int eg = live ? e0 + g : d.n - 1;                         // idle groups compute along, store nothing
+    const double t = k1_group<AT>(d, actions, eg, lane);
+    if (live && c < 6) d.state[(size_t)c * n + eg] = t, sh[g * 8 + c] = t;
+    if (live && c == 0) d.counters[eg].y += 1;                      // Vessel._step_counter (vessel.py:247)
+    // cos / sin of the new heading, for the reward's cos(heading error) and for the LiDAR sweep of this
+    // step (k2_front): here they cost one sincos per eight environments instead of one per environment
+    double sn, co;
+    sincos(__shfl(t, lane - c + 2, AUV_WAVE), &sn, &co);
+    if (live && c == 6) sh[g * 8 + 6] = co, sh[g * 8 + 7] = sn, d.pose_cs[eg] = make_double2(co, sn);
+    __syncthreads();
+    return;
+  }
+  const int e = auv_uniform(e0 + wave);
+  const bool valid = e < d.n;
+#ifdef AUV_STAMPS
+  const unsigned long long t_wg0 = wall_clock64();
+#endif
+  // the navigation's search against the pose BEFORE the step, with every load it needs (chunk circles,
+  // the surviving chunks' segments, spline windows): all of it overlaps the dynamics.  (A wave that
+  // reads the state after the dynamics wave has already stored the new one merely gets a better guess.)
+  NavSpec sp;
+  if (valid) sp = nav_speculate(d, e, lane, lists + (size_t)wave * d.nch_max, d.state[0 * n + e], d.state[1 * n + e],
+                                2.0 * NAV_DELTA, wins + wave * 3 * 20);
+  __syncthreads();
+  if (!valid) return;
+  EnvPre pre;
+#pragma unroll
+  for (int i = 0; i < 6; i++) pre.s[i] = sh[wave * 8 + i];
+  pre.cnt = make_int4(0, 0, 0, 0);                                  // (the navigation does not look at the counters)
+#ifdef AUV_STAMPS
+  const unsigned long long t_nav0 = wall_clock64();
+#endif
+  const double2 cs = make_double2(sh[wave * 8 + 6], sh[wave * 8 + 7]);
+  nav_finish(d, e, lane, lists + (size_t)wave * d.nch_max, obs_out, &pre, sp, true, wins + wave * 3 * 20, &cs);
+#ifdef AUV_STAMPS
+  if (lane == 0) d.stamps[(size_t)e * 16 + 12] = t_nav0, d.stamps[(size_t)e * 16 + 13] = wall_clock64(), d.stamps[(size_t)e * 16 + 14] = t_wg0;
+#endif
+}
+
+__global__ void __launch_bounds__(AUV_BLOCK, 4) k2r_lidar_reward(AuvDev d, float* __restrict__ obs_out,
+                                                                 float* __restrict__ reward_out,
+                                                                 uint8_t* __restrict__ done_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x % AUV_WAVE;
+  const int S = d.cfg.n_sensors;
+  const int e = auv_uniform((int)blockIdx.x);
+  if (e >= d.n) return;
+  const Slice L = carve(smem, S, d.k_max, d.m_max);
+  AUV_STAMP_DECL
+#ifdef AUV_STAMPS
+  const unsigned long long t_real0 = wall_clock64();
+#endif
+  int collision = -1;
+  double term = 0.0;
+  const int n_act = k2_front(d, e, lane, L, 1, nullptr, d.pose_cs);
+  if (d.cfg.use_lidar) {
+    AUV_STAMP()
+    k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
+    AUV_STAMP()
+    collision = k2_back(d, e, lane, L, obs_out, &term);
+    AUV_STAMP()
+    AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 3] = t_real0, d.stamps[(size_t)e * 16 + 4] = wall_clock64();
+    if (lane == 0) d.stamps[(size_t)e * 16 + 5] = (unsigned long long)L.sbase[n_act];
+#endif
+  }
+  k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, nullptr, collision, false, !d.cfg.use_lidar,
+                d.cfg.use_lidar ? &term : nullptr);
+#ifdef AUV_STAMPS
+  if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();   // end of the reward phase
+#endif
+}
+
 }  // namespace
 
 // the nav chunk list must fit the segment stage it borrows
@@ -136,7 +239,36 @@ void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0,
   hipExtLaunchKernelGGL(k23_lidar_nav, dim3(2 * nb), dim3(AUV_WAVE * wpb), (uint32_t)lds, st, ev0, ev1, 0, d, obs);
 }
 
+// ---- launches of the two-kernel step ----
+static size_t k1n_lds_bytes(const AuvDev& d) {
+  return K1N_ENVS * 8 * sizeof(double) + K1N_ENVS * 3 * 20 * sizeof(double) + (size_t)K1N_ENVS * d.nch_max * sizeof(int);
+}
+bool auv_two_kernel_ok(const AuvDev& d) { return k1n_lds_bytes(d) <= 64 * 1024; }
+
+void auv_launch_k1n(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0,
+                    hipEvent_t ev1) {
+  const dim3 grid((d.n + K1N_ENVS - 1) / K1N_ENVS), block(K1N_THREADS);
+  const uint32_t lds = (uint32_t)k1n_lds_bytes(d);
+  if (dtype == AUV_F64)
+    hipExtLaunchKernelGGL(k1n_dyn_nav<double>, grid, block, lds, st, ev0, ev1, 0, d, (const double*)actions, obs);
+  else
+    hipExtLaunchKernelGGL(k1n_dyn_nav<float>, grid, block, lds, st, ev0, ev1, 0, d, (const float*)actions, obs);
+}
+
+void auv_launch_k2r(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0,
+                    hipEvent_t ev1) {
+  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  hipExtLaunchKernelGGL(k2r_lidar_reward, dim3(d.n), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs, reward, done);
+}
+
 hipError_t auv_step_fused_prepare(const AuvDev& d) {
+  {
+    const size_t b1 = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+    if (b1 > 64 * 1024) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)k2r_lidar_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b1);
+      if (e1 != hipSuccess) return e1;
+    }
+  }
   const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
   if (b <= 64 * 1024) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);

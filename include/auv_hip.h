@@ -197,15 +197,21 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 /* How auv_step / auv_graph_capture run a step (same results, bit for bit):
  *   AUV_STEP_SIDE_BY_SIDE (default)  K1 -> one launch whose workgroups do K2 for all envs and
  *                                    K3-nav for all envs side by side -> K3-reward; one stream.
+ *   AUV_STEP_TWO_KERNELS             [K1 -> K3-nav] -> [K2 -> K3-reward]: Vessel.step of eight
+ *                                    environments by one wave while the workgroup's other eight run
+ *                                    their navigation's search against the pose before the step;
+ *                                    then one wave per environment sweeps the LiDAR and finishes
+ *                                    the step (reward, done, auto-reset).  Two launches.
  *   AUV_STEP_ONE_KERNEL              the whole step in one kernel, one wave per env running
  *                                    K1 -> K3-nav -> K2 -> K3-reward back to back.
  *   AUV_STEP_TWO_STREAMS             K1 -> { K2 || K3-nav on an auxiliary stream } -> K3-reward. */
-enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2 };
+enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2, AUV_STEP_TWO_KERNELS = 3 };
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
 
-/* One step in the default launch shape, every dispatch stamped with its own start / stop HIP event
- * on `stream` (the kernel's own duration, as a kernel trace reports it):
- * out_ms[0..3] = K1, [K2 + K3-nav side by side], K3-reward, whole step (first start .. last stop). */
+/* One step with every dispatch stamped with its own start / stop HIP event on `stream` (the kernel's
+ * own duration, as a kernel trace reports it).  In AUV_STEP_TWO_KERNELS mode
+ * out_ms[0..3] = [K1 + K3-nav], [K2 + K3-reward], 0, whole step (first start .. last stop); in any
+ * other mode the side-by-side shape is timed: K1, [K2 + K3-nav], K3-reward, whole step.          */
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                    float* reward_dev, uint8_t* done_dev, void* stream, float* out_ms4);
 

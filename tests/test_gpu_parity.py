@@ -244,13 +244,13 @@ def test_graph_replay_matches_eager():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_step_modes_agree_bitwise(dtype):
-    """side-by-side launch (default) vs whole step in one kernel vs two streams: bitwise the same."""
+    """two kernels (default) vs side-by-side launch vs whole step in one kernel vs two streams: bitwise the same."""
     n = 64
     bank = _mixed_bank(32)
     cfg = effective_reference_config(use_lidar=True)
     cfg.episode.max_timesteps = 9
     envs = []
-    for mode in ("side_by_side", "one_kernel", "two_streams"):
+    for mode in ("two_kernels", "side_by_side", "one_kernel", "two_streams"):
         e = _env(cfg, bank, n)
         e.set_step_mode(mode)
         e.reset()
@@ -260,7 +260,7 @@ def test_step_modes_agree_bitwise(dtype):
         a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=dtype, device="cuda:0")
         outs = [e.step(a)[:3] for e in envs]
         torch.cuda.synchronize()
-        for other in (1, 2):
+        for other in (1, 2, 3):
             for x, y in zip(outs[0], outs[other]):
                 assert torch.equal(x, y)
             for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO"):

@@ -1,0 +1,15 @@
+#!/bin/bash
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+O=gpurun_out/${TAG:-r02_g}; mkdir -p $O
+python bench.py --bank-cache /tmp/bank --steps 20 --cpu-baseline 0 > /dev/null 2>&1
+for rep in 1 2; do
+for v in csrc csrc_e4 csrc_e2; do
+AUV_HIP_LIB=gym_auv_amd/$v/libauv_hip.so python bench.py --bank-cache /tmp/bank --cpu-baseline 0 > $O/bench_$v.json 2>$O/bench_$v.err; python - <<PY
+import json; b=json.load(open("$O/bench_$v.json")); print("$v", b["value"], b["ms_per_step"], {k:v["avg_ms"] for k,v in b["roofline"]["kernels"].items()})
+PY
+done; done
+for v in stamps stamps4; do
+echo "== $v"; STEPS=2000 AUV_HIP_LIB=gym_auv_amd/csrc_$v/libauv_hip.so python tools/phase_stamps2.py 2>&1 | grep -E "k1n|nav\."
+done
