@@ -42,8 +42,10 @@
 
 namespace {
 
+#define K2_KIND_MASK 0xff
+#define K2_PIP_FLAG 0x100   // p0 lies within the enclosing circle: the point-in-polygon predicates are needed
 struct ObsLds {        // per-obstacle scratch in LDS (24 B)
-  int kind;
+  int kind;            // AUV_OBS_* | K2_PIP_FLAG
   int seg_off;         // absolute index into seg[] (static) or mover slot*5 (mover)
   int nseg;
   int start;           // first ray index of the window (may be negative, > -2S)
@@ -162,6 +164,18 @@ __device__ __forceinline__ void test_pair(const double4 w, const double tn, cons
   if (hit) atomicMin(slot, d2u(tn / den));
 }
 
+// The same for the rays of one work item, whose segment (hence tn) is fixed: a hit needs t = tn / den
+// >= 0, i.e. den of the sign of tn, so the flip is decided once per item (sg = -1 for tn < 0: exact) and
+// a ray whose den has the other sign fails `dn > 0`.  tn == 0 (p0 on the segment's line: t = 0 for any
+// non-parallel ray) has no preferred sign and takes the general form above.
+__device__ __forceinline__ void test_pair_signed(const double4 w, const double tn, const double ta, const double sg,
+                                                 const double2 r, unsigned long long* slot) {
+  const double dn = sg * (r.x * w.w - r.y * w.z);
+  const double u1 = sg * (w.x * r.y - w.y * r.x);
+  const bool hit = (dn > 0.0) & (ta <= dn) & (u1 >= 0.0) & (u1 <= dn);
+  if (hit) atomicMin(slot, d2u(ta / dn));                  // = tn / den: both signs flipped, exact
+}
+
 // (window x boundary) pairs of an obstacle that did not fit the LDS stage, straight from HBM
 template <typename SegPtr>
 __device__ __forceinline__ void sweep_unstaged(const ObsLds& o, int tid, int nthr, int S, double px, double py,
@@ -260,45 +274,6 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     L.mvw[m] = wd;
   }
   if (!d.cfg.use_lidar) return 0;   // lidar_d stays at sensor_range from reset; collision stays 0
-
-  // ---- phase C: ray vectors, vessel.py:66-68, :317 ------------------------------------
-  // cos / sin of (beam angle + psi) by the addition theorem from the per-config table of beam
-  // angles (built at load time): one sincos per environment instead of one per ray
-  double sin_psi, cos_psi;
-  if (S <= 4 * AUV_WAVE) {
-    // the usual shapes: all passes' table entries are requested before the sincos, so the passes
-    // do not each wait for their own trip to memory
-    double2 b[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int i = q * AUV_WAVE + lane;
-      b[q] = d.beam_cs[i < S ? i : 0];                      // cos, sin of -pi + (i + 1) * dangle
-    }
-    if (cs_pre) cos_psi = cs_in.x, sin_psi = cs_in.y;
-    else sincos(psi, &sin_psi, &cos_psi);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int i = q * AUV_WAVE + lane;
-      if (i < S) {
-        const double c = cos_psi * b[q].x - sin_psi * b[q].y, s = sin_psi * b[q].x + cos_psi * b[q].y;
-        // end point minus origin, formed exactly as the reference forms the end point
-        double ex = px + c * R, ey = py + s * R;
-        L.rayv[i] = make_double2(ex - px, ey - py);
-        L.dbits[i] = d2u(2.0);   // no hit yet (hits have t in [0, 1])
-      }
-    }
-  } else {
-    if (cs_pre) cos_psi = cs_in.x, sin_psi = cs_in.y;
-    else sincos(psi, &sin_psi, &cos_psi);
-    for (int i = lane; i < S; i += AUV_WAVE) {
-      const double2 b = d.beam_cs[i];
-      const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
-      double ex = px + c * R, ey = py + s * R;
-      L.rayv[i] = make_double2(ex - px, ey - py);
-      L.dbits[i] = d2u(2.0);
-    }
-  }
-  auv_wave_lds_sync();
 
   // ---- phase B0 (every sensor_interval_load_obstacles-th vessel step, vessel.py:266-273): refresh
   //      the cached nearby mask.  Kept apart from the cull-window pass below so that the exact
@@ -406,9 +381,22 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       o.wind = mover ? -1 : (meta.w == -2 ? 1 : (meta.w == -3 ? -1 : 0));   // mover pentagon: clockwise
       // a ring is hollow: from inside, every edge is seen from behind and all of them count.  Its
       // cull circle is its circumcircle, so strictly outside that circle is strictly outside the ring.
-      if (meta.x == AUV_OBS_RING) {
-        const double rx = scx - px, ry = scy - py;
-        if (!(rx * rx + ry * ry > srho * srho * (1.0 + 1e-9))) o.wind = 0;
+      {
+        // p0 on or inside a filled obstacle needs p0 within its enclosing circle (centre of the minimum
+        // rotated rectangle, half its diagonal): only then do the staging passes evaluate the
+        // point-in-polygon predicates of its edges
+        double ccx = scx, ccy = scy, crho = srho;
+        if (mover) {
+          const double2 c2 = L.mvcull[meta.w];
+          ccx = c2.x, ccy = c2.y, crho = L.mvw[meta.w] * sqrt(5.0) / 2.0;
+        }
+        const double rx = ccx - px, ry = ccy - py;
+        const bool outside = rx * rx + ry * ry > crho * crho * (1.0 + 1e-9) + 1e-9;
+        if (meta.x == AUV_OBS_RING) {
+          if (!outside) o.wind = 0;
+        } else if (!outside) {
+          o.kind |= K2_PIP_FLAG;
+        }
       }
       const uint8_t near = d.nearby[(size_t)e * d.k_max + k];
       int2 lim = make_int2(INT32_MIN, INT32_MIN);
@@ -474,6 +462,45 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     }
     if (lane == 0) L.sbase[0] = 0;
   }
+  if (n_act == 0) return 0;                                  // nothing in sight: no rays, no sweep (k2_back writes the free row)
+  // ---- phase C: ray vectors, vessel.py:66-68, :317 (only if some obstacle has rays to test) ----
+  // cos / sin of (beam angle + psi) by the addition theorem from the per-config table of beam
+  // angles (built at load time): one sincos per environment instead of one per ray
+  double sin_psi, cos_psi;
+  if (S <= 4 * AUV_WAVE) {
+    // the usual shapes: all passes' table entries are requested before the sincos, so the passes
+    // do not each wait for their own trip to memory
+    double2 b[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = q * AUV_WAVE + lane;
+      b[q] = d.beam_cs[i < S ? i : 0];                      // cos, sin of -pi + (i + 1) * dangle
+    }
+    if (cs_pre) cos_psi = cs_in.x, sin_psi = cs_in.y;
+    else sincos(psi, &sin_psi, &cos_psi);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (q * AUV_WAVE >= S) break;                         // (uniform: 180 beams are three passes)
+      const int i = q * AUV_WAVE + lane;
+      if (i < S) {
+        const double c = cos_psi * b[q].x - sin_psi * b[q].y, s = sin_psi * b[q].x + cos_psi * b[q].y;
+        // end point minus origin, formed exactly as the reference forms the end point
+        double ex = px + c * R, ey = py + s * R;
+        L.rayv[i] = make_double2(ex - px, ey - py);
+        L.dbits[i] = d2u(2.0);   // no hit yet (hits have t in [0, 1])
+      }
+    }
+  } else {
+    if (cs_pre) cos_psi = cs_in.x, sin_psi = cs_in.y;
+    else sincos(psi, &sin_psi, &cos_psi);
+    for (int i = lane; i < S; i += AUV_WAVE) {
+      const double2 b = d.beam_cs[i];
+      const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
+      double ex = px + c * R, ey = py + s * R;
+      L.rayv[i] = make_double2(ex - px, ey - py);
+      L.dbits[i] = d2u(2.0);
+    }
+  }
   auv_wave_lds_sync();
   return n_act;
 }
@@ -497,7 +524,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
       // a single boundary larger than a batch (never a circle or a mover): sweep it from HBM
       const ObsLds o = L.obs[L.act[a0]];
       const double4* g = d.seg + o.seg_off;
-      if (o.kind != AUV_OBS_RING && inside_flag_wave(px, py, g, o.nseg, lane) != 0) {
+      if ((o.kind & K2_PIP_FLAG) && inside_flag_wave(px, py, g, o.nseg, lane) != 0) {
         for (int q = lane; q < o.count; q += AUV_WAVE) atomicMin(&L.dbits[wrap_ray(o.start + q, S)], 0ull);
       } else {
         sweep_unstaged(o, lane, AUV_WAVE, S, px, py, L.rayv, L.dbits, g);
@@ -526,7 +553,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
         o_nx = L.obs[L.act[a_nx]];
         const int si = t + base0 - L.sbase[a_nx];
         // (a mover's seg_off is 5 x its slot)
-        s_nx = (o_nx.kind == AUV_OBS_MOVER) ? mover_segs(L.mvrot[o_nx.seg_off / AUV_MOVER_NSEG], L.mvw[o_nx.seg_off / AUV_MOVER_NSEG])[si]
+        s_nx = ((o_nx.kind & K2_KIND_MASK) == AUV_OBS_MOVER) ? mover_segs(L.mvrot[o_nx.seg_off / AUV_MOVER_NSEG], L.mvw[o_nx.seg_off / AUV_MOVER_NSEG])[si]
                                             : d.seg[o_nx.seg_off + si];
       }
     };
@@ -570,7 +597,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
             sp = make_short2((short)klo, (short)(n > S ? S : n));
           }
         }
-        if (o.kind != AUV_OBS_RING) {
+        if (o.kind & K2_PIP_FLAG) {
           // point-in-polygon predicates of this boundary segment (same tests as inside_flag_wave)
           const double dxa = px - s.x, dya = py - s.y;
           const double len2 = sx * sx + sy * sy;
@@ -615,7 +642,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
     // ---- phase D (i): obstacles containing p0 -> distance 0 on every ray of their window ----
     for (int ab = a0; ab < a1; ab += AUV_WAVE) {            // lanes <-> obstacles of the batch
       const int al = ab + lane;
-      unsigned long long in_mask = __ballot(al < a1 && L.par[al] != 0 && L.obs[L.act[al]].kind != AUV_OBS_RING);
+      unsigned long long in_mask = __ballot(al < a1 && L.par[al] != 0 && (L.obs[L.act[al]].kind & K2_PIP_FLAG));
       while (in_mask) {                                      // (rare) whole wave per containing obstacle
         const int a = ab + __ffsll((long long)in_mask) - 1;
         in_mask &= in_mask - 1;
@@ -632,7 +659,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
       if (t < T) {
         const int a = L.owner[t];
         const ObsLds o = L.obs[L.act[a]];
-        if (!(o.kind != AUV_OBS_RING && L.par[a] != 0)) v = (L.span[t].y + K2_ITEM_RAYS - 1) / K2_ITEM_RAYS;
+        if (!((o.kind & K2_PIP_FLAG) && L.par[a] != 0)) v = (L.span[t].y + K2_ITEM_RAYS - 1) / K2_ITEM_RAYS;
       }
       int incl = v;
 #pragma unroll
@@ -677,9 +704,16 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
         rr[jj] = r;
         rv[jj] = L.rayv[r < 0 ? 0 : r];
       }
+      if (tn != 0.0) {
+        const double sg = tn < 0.0 ? -1.0 : 1.0, ta = fabs(tn);
 #pragma unroll
-      for (int jj = 0; jj < K2_ITEM_RAYS; jj++)
-        if (rr[jj] >= 0) test_pair(w, tn, rv[jj], &L.dbits[rr[jj]]);
+        for (int jj = 0; jj < K2_ITEM_RAYS; jj++)
+          if (rr[jj] >= 0) test_pair_signed(w, tn, ta, sg, rv[jj], &L.dbits[rr[jj]]);
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < K2_ITEM_RAYS; jj++)
+          if (rr[jj] >= 0) test_pair(w, tn, rv[jj], &L.dbits[rr[jj]]);
+      }
     }
     auv_wave_lds_sync();
     SUB_ADD(c_items)
@@ -690,47 +724,99 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 #endif
 }
 
-// phase E: outputs (vessel.py:88-95, :356-359) and, while the ranges are in registers, the LiDAR
-// term of the Colav reward (rewarder.py:205-222: sum of gamma_theta-weighted R exp(-0.1 d) over
-// the beams; the velocity channel is identically zero, sensor.py:159) and the float32 closeness
-// columns of the observation row.
-__device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, float* __restrict__ obs_out = nullptr,
-                       double* rew_lidar_out = nullptr) {
+// phase E: outputs (vessel.py:88-95, :356-359) and the LiDAR term of the Colav reward
+// (rewarder.py:205-222: sum of gamma_theta-weighted R exp(-0.1 d) over the beams; the velocity channel
+// is identically zero, sensor.py:159) and the float32 closeness columns of the observation row.
+// A beam without a return sits exactly at R: closeness 1 - x/x = 0 and its exp() is one per-config
+// constant.  So the beams are split: one cheap pass stores the free beams' constants and compacts the
+// indices of the beams WITH a return into LDS (ballot + popcount); the square root / log / exp are then
+// evaluated over that dense list only (typically one pass of 64 instead of S / 64).
+// n_act == 0 (no obstacle had a ray to test): the whole row is free, nothing was swept.
+#define K2_HIT_CAP (K2_SEG_CAP * 8)    // ints that fit the (by now idle) segment stage
+__device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, const int n_act,
+                       float* __restrict__ obs_out = nullptr, double* rew_lidar_out = nullptr) {
   const int S = d.cfg.n_sensors;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
-  int col = 0;
-  const double logR = d.derived[0];                        // log(1 + R)
-  const double px = L.hdr->px, py = L.hdr->py;
   const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
-  const double raw_free = d.derived[1];                    // R exp(-0.1 R)
   const int D = 6 + S * (d.cfg.obs_channels == 3 ? 3 : 1);   // row stride of obs_out (use_lidar is on here)
+  double* dd = d.lidar_d + (size_t)e * S;
+  double* ob = d.obs64 + (size_t)e * (6 + S) + 6;
+  float* oo = obs_out ? obs_out + (size_t)e * D + 6 : nullptr;
+  if (n_act == 0) {
+    for (int i = lane; i < S; i += AUV_WAVE) {
+      dd[i] = R, ob[i] = 0.0;
+      if (oo) oo[i] = 0.0f;
+    }
+    const double term = colav ? d.derived[3] : 0.0;
+    if (lane == 0) {
+      d.collision[e] = 0;
+      if (colav) d.rew_lidar[e] = term;
+    }
+    if (rew_lidar_out) *rew_lidar_out = term;
+    return 0;
+  }
+  const double logR = d.derived[0];                        // log(1 + R)
+  const double raw_free = d.derived[1];                    // R exp(-0.1 R)
+  const double px = L.hdr->px, py = L.hdr->py;
+  int* hits = (int*)L.stage;
+  int col = 0;
   double num = 0.0;
-  for (int i = lane; i < S; i += AUV_WAVE) {
-    const double t = u2d(L.dbits[i]);
-    double di = R;                                          // sensor.py:156
-    if (t <= 1.0) {
-      // intersection point, then Point.distance: exactly the reference's arithmetic
-      const double2 r = L.rayv[i];
-      const double X = px + t * r.x, Y = py + t * r.y;
-      const double dx = X - px, dy = Y - py;
-      di = sqrt(dx * dx + dy * dy);
+  if (S <= K2_HIT_CAP) {
+    // ---- free beams + compaction of the returns ----
+    int n_hit = 0;
+    for (int i0 = 0; i0 < S; i0 += AUV_WAVE) {
+      const int i = i0 + lane;
+      const bool hit = (i < S) && (u2d(L.dbits[i]) <= 1.0);
+      if (i < S && !hit) {
+        dd[i] = R, ob[i] = 0.0;                            // sensor.py:156; closeness 1 - clip(x / x) = 0
+        if (oo) oo[i] = 0.0f;
+        if (colav) num += d.beam_w[i] * raw_free;          // gamma_theta from the per-config table
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) hits[n_hit + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      n_hit += __popcll(m);
     }
-    d.lidar_d[(size_t)e * S + i] = di;
-    // a beam without a return sits exactly at R: closeness 1 - x/x = 0 and its exp() is one
-    // constant, so the transcendentals are only evaluated in passes where some lane has a return
-    const bool any_return = __any(t <= 1.0);
-    double cl = 0.0;
-    if (any_return)
-      cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0) : 1 - auv_clip(di / R, 0.0, 1.0);
-    cl = auv_clip(cl, -1.0, 1.0);
-    d.obs64[(size_t)e * (6 + S) + 6 + i] = cl;
-    if (obs_out) obs_out[(size_t)e * D + 6 + i] = (float)cl;
-    if (colav) {
-      double raw = raw_free;
-      if (__any(di != R)) raw = R * exp(-0.1 * di);         // gamma_x
-      num += d.beam_w[i] * raw;                             // gamma_theta from the per-config table
+    auv_wave_lds_sync();
+    // ---- the returns ----
+    for (int h0 = 0; h0 < n_hit; h0 += AUV_WAVE) {
+      const int h = h0 + lane;
+      if (h < n_hit) {
+        const int i = hits[h];
+        const double t = u2d(L.dbits[i]);
+        // intersection point, then Point.distance: exactly the reference's arithmetic
+        const double2 r = L.rayv[i];
+        const double X = px + t * r.x, Y = py + t * r.y;
+        const double dx = X - px, dy = Y - py;
+        const double di = sqrt(dx * dx + dy * dy);
+        dd[i] = di;
+        double cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0) : 1 - auv_clip(di / R, 0.0, 1.0);
+        cl = auv_clip(cl, -1.0, 1.0);
+        ob[i] = cl;
+        if (oo) oo[i] = (float)cl;
+        if (colav) num += d.beam_w[i] * ((di != R) ? R * exp(-0.1 * di) : raw_free);   // gamma_x
+        col |= (di < W);
+      }
     }
-    col |= (di < W);
+  } else {
+    // (more beams than the hit list holds: every pass does everything)
+    for (int i = lane; i < S; i += AUV_WAVE) {
+      const double t = u2d(L.dbits[i]);
+      double di = R;
+      if (t <= 1.0) {
+        const double2 r = L.rayv[i];
+        const double X = px + t * r.x, Y = py + t * r.y;
+        const double dx = X - px, dy = Y - py;
+        di = sqrt(dx * dx + dy * dy);
+      }
+      dd[i] = di;
+      double cl = 0.0;
+      if (t <= 1.0) cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0) : 1 - auv_clip(di / R, 0.0, 1.0);
+      cl = auv_clip(cl, -1.0, 1.0);
+      ob[i] = cl;
+      if (oo) oo[i] = (float)cl;
+      if (colav) num += d.beam_w[i] * ((di != R) ? R * exp(-0.1 * di) : raw_free);
+      col |= (di < W);
+    }
   }
   col = __any(col);
   if (colav) num = auv_wave_sum(num);
@@ -761,7 +847,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k2_lidar(AuvDev d, int advance_m
   AUV_STAMP()
   k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
   AUV_STAMP()
-  k2_back(d, e, lane, L);
+  k2_back(d, e, lane, L, n_act);
   AUV_STAMP()
   AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
 #ifdef AUV_STAMPS
@@ -782,7 +868,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
     const int n_act = k2_front(d, e, lane, L, 0);
     if (d.cfg.use_lidar) {
       k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
-      k2_back(d, e, lane, L);
+      k2_back(d, e, lane, L, n_act);
     }
     auv_wave_lds_sync();
   }

@@ -211,7 +211,7 @@ __device__ __forceinline__ double reward_lidar_term_wave(const AuvDev& d, const 
     const int i = i0 + lane;
     const double di = (i < S) ? dd[i] : R;
     double raw = raw_free;
-    if (__any(di != R)) raw = R * exp(-0.1 * di);       // gamma_x; velocity channel == 0 (sensor.py:159)
+    if (__any(di != R)) raw = (di != R) ? R * exp(-0.1 * di) : raw_free;   // gamma_x; velocity channel == 0 (sensor.py:159)
     if (i < S) num += d.beam_w[i] * raw;                // gamma_theta
   }
   num = auv_wave_sum(num);
@@ -221,21 +221,25 @@ __device__ __forceinline__ double reward_lidar_term_wave(const AuvDev& d, const 
 #ifndef AUV_DEVICE_FUNCS_ONLY
 // per-config constants, formed once on the device with the very functions the step would use:
 // gamma_theta of every beam (vessel.py:66-68, rewarder.py:205-222), their sum in the wave-reduction
-// order, log(1 + R) and R exp(-0.1 R)
+// order, log(1 + R), R exp(-0.1 R) and the all-free LiDAR term of the reward
 __global__ void k_derive(AuvDev d) {
   const int lane = threadIdx.x;
   const int S = d.cfg.n_sensors;
   const double dangle = 2 * AUV_PI / S;
   const double R = d.cfg.sensor_range;
-  double den = 0.0;
+  const double raw_free = R * exp(-0.1 * R);
+  double den = 0.0, num_free = 0.0;
   for (int i = lane; i < S; i += AUV_WAVE) {
     const double angle = -AUV_PI + (i + 1) * dangle;
     const double weight = 1 / (1 + fabs(10.0 * angle));
     d.beam_w[i] = weight;
     den += weight;
+    num_free += weight * raw_free;                        // the sweep's own summation order (k2_back)
   }
   den = auv_wave_sum(den);
-  if (lane == 0) d.derived[0] = log(1 + R), d.derived[1] = R * exp(-0.1 * R), d.derived[2] = den, d.derived[3] = 0.0;
+  num_free = auv_wave_sum(num_free);
+  // [3]: the LiDAR term of the Colav reward when no beam has a return
+  if (lane == 0) d.derived[0] = log(1 + R), d.derived[1] = raw_free, d.derived[2] = den, d.derived[3] = (S > 0) ? -num_free / den : 0.0;
 }
 #endif
 

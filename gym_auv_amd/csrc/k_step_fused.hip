@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
   const int n_act = k2_front(d, e, lane, L, 1, &pre);
   if (d.cfg.use_lidar) {
     k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
-    collision = k2_back(d, e, lane, L, obs_out);
+    collision = k2_back(d, e, lane, L, n_act, obs_out);
   }
   // K3-reward (lidar_d / closeness rows are re-read by the lanes that wrote them)
   k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, &pre, collision, false, !d.cfg.use_lidar);
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* _
       k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
 #endif
       AUV_STAMP()
-      k2_back(d, e, lane, L, obs_out);
+      k2_back(d, e, lane, L, n_act, obs_out);
       AUV_STAMP()
       AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
 #ifdef AUV_STAMPS
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k2r_lidar_reward(AuvDev d, float
     AUV_STAMP()
     k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
     AUV_STAMP()
-    collision = k2_back(d, e, lane, L, obs_out, &term);
+    collision = k2_back(d, e, lane, L, n_act, obs_out, &term);
     AUV_STAMP()
     AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
 #ifdef AUV_STAMPS

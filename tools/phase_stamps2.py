@@ -8,6 +8,7 @@ cfg = effective_reference_config(use_lidar=True)
 n = 4096
 z = np.load("/tmp/bank.polygons50.0.4096.npz"); bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
 env = BatchedAuvEnv(cfg, bank, n, auto_reset=True)
+env.set_step_mode(os.environ.get("MODE", "two_kernels"))
 env.reset()
 a = torch.rand((n, 2), device="cuda:0") * 2 - 1
 for i in range(int(os.environ.get("STEPS", "30"))): env.step(torch.rand((n, 2), device="cuda:0") * torch.tensor([2.0, 0.3], device="cuda:0") - torch.tensor([1.0, 0.15], device="cuda:0"))
