@@ -4,16 +4,27 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], the configuration the >=1 M env-steps/s target is quoted
-on): 4096 envs x 180 sensors per GPU, 50 static filled polygon obstacles per env, one distinct
-world per env (seed 1000 + global env index), effective reference dt = 0.5 s, LiDAR on,
-ColavRewarder, VecEnv auto-reset, i.i.d. U(action_space) actions (torch seed 0) resident in
-HBM before the timed region.  One "step" = one batched env.step() = K1 -> K2 -> K3 (+ the
-reset pass) over all envs of the rank.  Weak scaling: per-GPU work is fixed as N grows.
+`python bench.py --gpus N` without a launcher starts its N ranks itself (one process per GPU).
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel,
-HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle = a C port of the
-reference algorithm, timed on this box's host cores on a bounded sample of the same workload).
+Workload (BASELINE.json configs[2], the configuration the >=1 M env-steps/s target is quoted
+on): 4096 envs x 180 sensors per GPU, 50 static filled polygon obstacles per env, effective
+reference dt = 0.5 s, LiDAR on, ColavRewarder, VecEnv auto-reset, i.i.d. U(action_space) actions
+(torch seed 0) resident in HBM before the timed region.  The world bank holds --worlds-per-env
+(default 2) worlds per environment: env g starts in the world of seed 1000 + g and an episode
+that ends rebinds it to a world it has not seen (seed 1000 + k * total_envs + g for its k-th
+episode, cyclically), as the reference regenerates the scenario on every reset
+(envs/movingobstacles.py:28-95).  One "step" = one batched env.step() over all envs of the rank.
+Weak scaling: per-GPU work is fixed as N grows.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline      dominant kernel (HIP-event timed on the launch stream in this process): the HBM leg
+                (`achieved` = algorithmic bytes per launch / duration; algorithmic = what the
+                implemented algorithm must touch, LiDAR segments counted for NEARBY obstacles only)
+                and the VALU leg (`valu`: wave-instructions and issue cycles per launch from the
+                committed rocprofv3 SQ-counter pass, profiles/pmc_sq.json); `bound` names the larger;
+  cpu_baseline  the CPU oracle (a C port of the reference algorithm) timed on this box's host cores
+                on a bounded sample of the same workload, plus the reference's own Python step()
+                as measured in the build container (a stated constant, never run here).
 """
 import argparse
 import json
@@ -28,6 +39,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -37,7 +49,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="polygons50", choices=["polygons50", "circles20", "moving28", "mixed47"])
-    ap.add_argument("--graph", type=int, default=0, help="replay a captured hipGraph per step (1) or launch eagerly (0, default: eager launches pipeline deeper than one graph replay per step on this stack)")
+    ap.add_argument("--worlds-per-env", type=int, default=2,
+                    help="bank size / envs: 2 (default) lets every auto-reset land on a world the env has not seen; "
+                         "1 = the round-1 bench (an env is reborn in its own world)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="0 (default): eager launches; K > 0: K consecutive steps captured in ONE hipGraph over the action "
+                         "ring, one replay per K steps (steps not a multiple of K are finished eagerly)")
     ap.add_argument("--step-mode", default="side_by_side", choices=["side_by_side", "two_kernels", "one_kernel", "two_streams"],
                     help="how a step is launched (include/auv_hip.h, AUV_STEP_*)")
     ap.add_argument("--actions", default="uniform", choices=["uniform", "pilot"],
@@ -46,12 +63,12 @@ def parse():
                          "previous step, so that episodes progress along the path (SURVEY 8(d), config 1)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
+    ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
     ap.add_argument("--rehearse", type=int, default=0,
                     help="1: allow more ranks than visible GPUs (ranks share devices, gloo instead of RCCL); the line "
                          "then reports n_gpus = distinct physical devices, not ranks")
     ap.add_argument("--dry-run", type=int, default=0,
                     help="1: every rank prints its shard (rank, env range, seeds, device) and exits without touching the GPU")
-    ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
     return ap.parse_args()
 
 
@@ -68,27 +85,47 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(bank, cfg_S, world_of_env):
-    """Per-launch algorithmic HBM bytes of each kernel of the step: what the
-    implemented algorithm has to move, summed over the envs of one rank, fp64 layout."""
-    P = np.diff(bank["poly_off"])[world_of_env].astype(np.float64)
-    K = np.diff(bank["obs_off"])[world_of_env].astype(np.float64)
-    meta = bank["obs_meta"]
-    nseg_world = np.zeros(int(bank["n_worlds"]))
-    w_of_obs = np.repeat(np.arange(int(bank["n_worlds"])), np.diff(bank["obs_off"]))
-    static = meta[:, 0] != 2
-    np.add.at(nseg_world, w_of_obs[static], meta[static, 2])
-    G = nseg_world[world_of_env]
-    S = float(cfg_S)
+def algorithmic_bytes(bank, S, world_of_env, nearby):
+    """Per-launch algorithmic HBM bytes of each phase of the step: what the
+    implemented algorithm has to touch, summed over the envs of one rank, fp64 layout.  The LiDAR
+    sweep only reads the boundary segments of obstacles whose cached NEARBY flag is set
+    (vessel.py:266-273), so only those are charged (`nearby` = the mask at the end of the timed
+    run, [n, k_max])."""
     n = len(world_of_env)
-    k1 = 144.0 * n
-    # SURVEY 8(d) formula, 32-B segments; + the float32 closeness columns, which K2 now emits itself
-    lidar = (32.0 * G + 24.0 * K + 16.0 * K + 24.0 + 16.0 * S + K + 4.0 * S).sum()
+    P = np.diff(bank["poly_off"])[world_of_env].astype(np.float64)
+    obs_off = bank["obs_off"]
+    K = np.diff(obs_off)[world_of_env].astype(np.float64)
+    M = np.diff(bank["mv_off"])[world_of_env].astype(np.float64)
+    meta = bank["obs_meta"]
+    seg_near = np.zeros(n)
+    k_max = nearby.shape[1]
+    for j in range(k_max):                                 # obstacle slot j of every env
+        has = j < np.diff(obs_off)[world_of_env]
+        idx = np.minimum(obs_off[world_of_env] + j, len(meta) - 1)
+        static = has & (meta[idx, 0] != 2) & (nearby[:, j] != 0)
+        seg_near += np.where(static, meta[idx, 2], 0)
+    S = float(S)
+    k1 = 144.0 * n                                                          # state r/w, action, counter
+    # reads: pose + counters + table descriptor, per obstacle meta / cull circle / nearby flag, the nearby
+    # obstacles' segments (32 B each), per mover state r/w + parameters; writes: ranges, closeness (fp64 + f32),
+    # cull limits, collision, reward term
+    lidar = (104.0 + 41.0 * K + 32.0 * seg_near + 96.0 * M + 20.0 * S + 8.0 * K + 9.0).sum()
     nch = np.ceil((P - 1) / 64.0)
-    nav = (32.0 * nch + 3 * 65 * 16.0 + 600.0).sum()                            # chunk circles + ~3 surviving chunks + knots/scalars
-    reward = 300.0 * n                                                          # two reward terms, nav/info rows, counters, outputs
-    return dict(k1_dynamics=k1, k23_lidar_nav=float(lidar + nav), k3_reward=float(reward),
-                lidar_part=float(lidar), nav_part=float(nav), nav_bruteforce=float((16.0 * P).sum()))
+    nav = (32.0 * nch + 3 * 65 * 16.0 + 600.0).sum()                        # chunk circles + ~3 surviving chunks + knots/scalars
+    reward = 300.0 * n                                                      # two reward terms, nav/info rows, counters, outputs
+    all_seg = np.zeros(int(bank["n_worlds"]))
+    w_of_obs = np.repeat(np.arange(int(bank["n_worlds"])), np.diff(obs_off))
+    st = meta[:, 0] != 2
+    np.add.at(all_seg, w_of_obs[st], meta[st, 2])
+    return dict(k1=k1, lidar=float(lidar), nav=float(nav), reward=float(reward),
+                nearby_segments_per_env=float(seg_near.mean()), all_segments_per_env=float(all_seg[world_of_env].mean()),
+                nav_bruteforce=float((16.0 * P).sum()))
+
+
+KERNEL_PHASES = {   # which phases of the step a launch performs (for its algorithmic byte count)
+    "k1_dynamics": ("k1",), "k23_lidar_nav": ("lidar", "nav"), "k3_reward": ("reward",),
+    "k1n_dyn_nav": ("k1", "nav"), "k2r_lidar_reward": ("lidar", "reward"),
+}
 
 
 def host_cores():
@@ -143,6 +180,12 @@ def spawn_ranks(args):
     return 0
 
 
+def world_seeds(lo, n_local, total_envs, worlds_per_env):
+    """Seed of world w of this rank's bank: env g = lo + (w % n_local) meets it in its (w // n_local)-th episode."""
+    w = np.arange(n_local * worlds_per_env)
+    return 1000 + (w // n_local) * total_envs + lo + (w % n_local)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -168,18 +211,21 @@ def main():
     from gym_auv_amd.distributed import shard_range
     lo, hi = shard_range(n_local * world, rank, world)     # weak scaling: fixed envs per GPU, contiguous blocks
     assert hi - lo == n_local
+    wpe = max(1, args.worlds_per_env)
+    seeds = world_seeds(lo, n_local, n_local * world, wpe)
     if args.dry_run:
-        print(json.dumps(dict(rank=rank, world=world, env_lo=lo, env_hi=hi, seed_lo=1000 + lo, seed_hi=1000 + hi,
-                              device=int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev), n_devices_used=n_devices_used)), flush=True)
+        print(json.dumps(dict(rank=rank, world=world, env_lo=lo, env_hi=hi, seed_lo=int(seeds[0]), seed_hi=int(seeds[n_local - 1]) + 1,
+                              n_worlds=len(seeds), device=int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev),
+                              n_devices_used=n_devices_used)), flush=True)
         return
     procs = args.procs or max(1, min(16, host_cores() // max(1, world)))
     t0 = time.time()
-    cache = args.bank_cache and "%s.%s.%d.%d.npz" % (args.bank_cache, args.workload, lo, n_local)
+    cache = args.bank_cache and "%s.%s.%d.%d.%d.%d.npz" % (args.bank_cache, args.workload, lo, n_local, n_local * world, wpe)
     if cache and os.path.exists(cache):
         z = np.load(cache)
         bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
     else:
-        bank = build_bank_parallel(gen, range(1000 + lo, 1000 + lo + n_local), procs=procs, **kwargs)
+        bank = build_bank_parallel(gen, seeds, procs=procs, **kwargs)
         if cache:
             np.savez(cache, **bank)
     t_gen = time.time() - t0
@@ -201,34 +247,41 @@ def main():
     pool = low + (high - low) * torch.rand((n_pool, n_local, 2), generator=g, device=dev)   # resident in HBM
 
     env.reset()
-    if args.graph:
-        # the 64 pre-generated action batches become the action ring of the captured step: each
-        # replay consumes the next slot, nothing is copied or re-bound in the timed loop
-        ring = env.capture_graph(torch.float32, slots=n_pool)
+    K = max(0, args.graph)
+    if K:
+        # the 64 pre-generated action batches become the action ring of the captured steps: a replay consumes
+        # the next K slots, nothing is copied or re-bound in the timed loop.  Steps beyond a multiple of K are
+        # launched eagerly from the pool (eager launches never touch the ring).
+        if n_pool % K and K % n_pool:
+            raise SystemExit("--graph K: K must divide %d (the action pool) or be a multiple of it" % n_pool)
+        ring = env.capture_graph(torch.float32, slots=n_pool, steps=K)
         ring.copy_(pool)
 
-        def do_step(i):
-            env.step_graph()
+        def run(i0, n):
+            for _ in range(n // K):
+                env.step_graph()
+            for i in range(n % K):
+                env.step(pool[(i0 + i) % n_pool])
     elif args.actions == "pilot":
         act = torch.ones((n_local, 2), dtype=torch.float32, device=dev)
 
-        def do_step(i):
+        def run(i0, n):
             # look-ahead pilot: full thrust, rudder proportional to the heading error (observation
             # column 4, already clipped to +-1 rad): two tiny torch kernels per step, all on the device
-            torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
-            env.step(act)
+            for _ in range(n):
+                torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
+                env.step(act)
     else:
-        def do_step(i):
-            env.step(pool[i % n_pool])
+        def run(i0, n):
+            for i in range(n):
+                env.step(pool[(i0 + i) % n_pool])
 
-    for i in range(args.warmup):
-        do_step(i)
+    run(0, args.warmup)
     torch.cuda.synchronize(dev)
     D.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        do_step(args.warmup + i)
+    run(args.warmup, args.steps)
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = time.perf_counter() - t0
@@ -237,43 +290,61 @@ def main():
     stats = D.gather_episode_stats(env.episode_stats())
     total_envs = n_local * world
     value = total_envs * args.steps / elapsed
+    world_of_env = env.read("WORLD_IDX").cpu().numpy()
+    nearby = env.read("NEARBY").cpu().numpy()
 
     # ---- per-kernel timing with HIP events on the launch stream (same workload, same process)
     kms = np.zeros(4)
-    n_prof = min(args.steps, 100)
+    n_prof = min(max(args.steps, 20), 100)
     for i in range(n_prof):
         kms += np.array(env.step_timed(pool[i % n_pool]))
     kms /= n_prof
-    world_of_env = env.read("WORLD_IDX").cpu().numpy()
-    alg = algorithmic_bytes(bank, S, world_of_env)
+    alg = algorithmic_bytes(bank, S, world_of_env, nearby)
     names = env.timed_kernel_names()
-    if names[0] == "k1n_dyn_nav":
-        alg = dict(alg, k1n_dyn_nav=alg["k1_dynamics"] + alg["nav_part"], k2r_lidar_reward=alg["lidar_part"] + alg["k3_reward"])
     per_kernel = {}
     for j, nm in enumerate(names):
-        gbs = alg[nm] / (kms[j] * 1e-3) / 1e9 if kms[j] > 0 else 0.0
-        per_kernel[nm] = dict(avg_ms=round(float(kms[j]), 5), algorithmic_bytes=int(alg[nm]),
+        b = sum(alg[ph] for ph in KERNEL_PHASES[nm])
+        gbs = b / (kms[j] * 1e-3) / 1e9 if kms[j] > 0 else 0.0
+        per_kernel[nm] = dict(avg_ms=round(float(kms[j]), 5), algorithmic_bytes=int(b),
                               achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
-    if "k23_lidar_nav" in per_kernel:
-        per_kernel["k23_lidar_nav"].update(lidar_bytes=int(alg["lidar_part"]), nav_bytes=int(alg["nav_part"]),
-                                           nav_bruteforce_bytes=int(alg["nav_bruteforce"]))
     dom = max(names, key=lambda nm: per_kernel[nm]["avg_ms"])
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath) and n_local == 4096:        # the PMC passes were taken at 4096 envs per GPU
+    per_kernel[dom].update(lidar_bytes=int(alg["lidar"]), nav_bytes=int(alg["nav"]),
+                           nearby_segments_per_env=round(alg["nearby_segments_per_env"], 1),
+                           all_segments_per_env=round(alg["all_segments_per_env"], 1),
+                           nav_bruteforce_bytes=int(alg["nav_bruteforce"]))
+
+    def committed(name):
+        """per-launch counters of the dominant kernel from the committed rocprofv3 passes (4096 envs per GPU)"""
+        path = os.path.join(ROOT, "profiles", name)
+        if n_local != 4096 or not os.path.exists(path):
+            return None
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            return json.load(open(path)).get(args.workload, {}).get(dom)
         except Exception:
-            traffic = None
-    roofline = dict(bound="hbm", kernel=dom, achieved=per_kernel[dom]["achieved_GBs"], peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=per_kernel[dom]["frac"], traffic=traffic, kernels=per_kernel)
+            return None
+
+    traffic = committed("pmc_traffic.json")
+    sq = committed("pmc_sq.json")
+    valu = None
+    if sq:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) in which a wave executes a VALU instruction, summed
+        # over waves; SQ_BUSY_CYCLES is summed over the 32 shader engines.  frac = issue cycles / (SIMDs x busy cycles).
+        issue = 4.0 * sq["SQ_ACTIVE_INST_VALU"]
+        busy = sq["SQ_BUSY_CYCLES"] / 32.0
+        valu = dict(insts=int(sq["SQ_INSTS_VALU"]), issue_cycles=int(issue), kernel_cycles=int(busy),
+                    frac=round(issue / (N_SIMD * busy), 4), source="profiles/pmc_sq.json")
+    hbm_frac = per_kernel[dom]["frac"]
+    bound = "valu" if (valu and valu["frac"] > hbm_frac) else "hbm"
+    roofline = dict(bound=bound, kernel=dom, achieved=per_kernel[dom]["achieved_GBs"], peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=hbm_frac, traffic=traffic, valu=valu, kernels=per_kernel)
 
     out = dict(metric="env-steps/sec", value=round(value, 1), unit="env-steps/s", n_gpus=n_devices_used, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
                            parallelism="env-shard x%d (no step-path collective)" % world, ranks=world,
-                           hipgraph=bool(args.graph), step_mode=args.step_mode, actions=args.actions, world_gen_s=round(t_gen, 1),
+                           hipgraph_steps=K, step_mode=args.step_mode, actions=args.actions,
+                           worlds_per_env=wpe, world_gen_s=round(t_gen, 1),
                            episodes_finished=int(stats["episodes"].sum().item())),
                roofline=roofline)
 
@@ -289,7 +360,9 @@ def main():
 def cpu_baseline(cfg, bank, n_local):
     """The CPU oracle (C port of the reference algorithm, fp64, -O2) on this box's host cores, on
     a bounded sample of the same workload (~10 s of CPU work): the first 1024 envs/worlds for 2500
-    steps on all usable cores (OpenMP over envs), then 100 steps on 1 thread."""
+    steps on all usable cores (OpenMP over envs), then 100 steps on 1 thread.  Beside it, as a stated
+    constant, the reference's OWN Python step() timed in the build container
+    (oracle/ref_harness/time_reference.py -> reference_timing.json; it cannot run on the GPU box)."""
     from gym_auv_amd._capi import make_config
     from oracle import pyoracle
     n = min(1024, n_local)
@@ -311,10 +384,17 @@ def cpu_baseline(cfg, bank, n_local):
         ora.step(acts[i % 8])
     dt_one = time.perf_counter() - t0
     pyoracle.set_threads(cores)
-    return dict(value=round(n * steps / dt_all, 1), unit="env-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d steps of the same workload (OpenMP over envs, %d threads, %.1f s); "
-                       "1 thread: %d envs x 100 steps (%.1f s)" % (n, steps, cores, dt_all, n, dt_one),
-                value_1thread=round(n * 100 / dt_one, 1))
+    res = dict(value=round(n * steps / dt_all, 1), unit="env-steps/s", cores=cores, kind="port",
+               sample="%d envs x %d steps of the same workload (OpenMP over envs, %d threads, %.1f s); "
+                      "1 thread: %d envs x 100 steps (%.1f s)" % (n, steps, cores, dt_all, n, dt_one),
+               value_1thread=round(n * 100 / dt_one, 1))
+    ref = os.path.join(ROOT, "oracle", "ref_harness", "reference_timing.json")
+    if os.path.exists(ref):
+        try:
+            res["reference_python"] = json.load(open(ref))
+        except Exception:
+            pass
+    return res
 
 
 if __name__ == "__main__":

@@ -138,6 +138,7 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_field_bytes": (sz, [vp, i32]),
         "auv_graph_capture": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
         "auv_graph_launch": (C.c_int, [vp, vp]),
+        "auv_graph_capture_steps": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, vp]),
         "auv_step_timed": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, C.POINTER(C.c_float)]),
         "auv_set_action_ring": (C.c_int, [vp, i32]),
         "auv_set_step_mode": (C.c_int, [vp, i32]),
@@ -162,7 +163,7 @@ def load_library(path: str = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset", "auv_step",
                     "auv_step_dynamics", "auv_lidar", "auv_nav_reward", "auv_read", "auv_write",
-                    "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_step_timed",
+                    "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",
                     "auv_generate_worlds", "auv_bank_bytes", "auv_read_bank",
                     "auv_abi_version", "auv_last_error"]

@@ -93,6 +93,20 @@ class BatchedAuvEnv:
             raise ValueError("actions must have shape (%d, 2), got %s" % (self.n_envs, tuple(actions.shape)))
         return actions, (_capi.AUV_F64 if actions.dtype == torch.float64 else _capi.AUV_F32)
 
+    def load_worlds(self, worlds: Union[Dict[str, np.ndarray], Sequence[Union[WorldSpec, BuiltWorld]]]):
+        """Replace the world bank of this (persistent) handle and put every environment in its reset state:
+        `auv_load_worlds` again, no handle tear-down.  What a reset() of the single-environment adapter does."""
+        bank = worlds if isinstance(worlds, dict) else pack_bank([w if isinstance(w, BuiltWorld) else build_world(w) for w in worlds])
+        torch.cuda.current_stream(self.device).synchronize()
+        bs, keep = make_bank_struct(bank)
+        _check(_LIB.auv_load_worlds(self._h, C.byref(bs)), "auv_load_worlds")
+        del keep
+        self._gen = None
+        self.n_worlds = int(bank["n_worlds"])
+        self.k_max = max(1, int(bank["k_max"]))
+        self.m_max = max(1, int(bank["m_max"]))
+        self._graph_actions = None
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             _LIB.auv_destroy(self._h)
@@ -159,14 +173,17 @@ class BatchedAuvEnv:
 
     # hipGraph: capture once, replay per step.  `slots` > 1 makes the action buffer a ring of
     # [slots, N, 2]: step k consumes slot k % slots, so nothing has to be copied or re-bound.
-    def capture_graph(self, dtype=torch.float32, slots: int = 1):
+    def capture_graph(self, dtype=torch.float32, slots: int = 1, steps: int = 1):
+        """Capture `steps` consecutive steps into one hipGraph (replayed by step_graph()).  With `slots` > 1
+        the returned [slots, N, 2] tensor is the action ring: replayed step k consumes slot k % slots."""
         self._graph_actions = torch.zeros((slots, self.n_envs, 2), dtype=dtype, device=self.device)
+        self._graph_steps = int(steps)
         dt = _capi.AUV_F64 if dtype == torch.float64 else _capi.AUV_F32
         torch.cuda.synchronize(self.device)
         _check(_LIB.auv_set_action_ring(self._h, int(slots)), "auv_set_action_ring")
-        _check(_LIB.auv_graph_capture(self._h, C.c_void_p(self._graph_actions.data_ptr()), dt,
-                                      C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
-                                      C.c_void_p(self.done.data_ptr()), self._stream()), "auv_graph_capture")
+        _check(_LIB.auv_graph_capture_steps(self._h, C.c_void_p(self._graph_actions.data_ptr()), dt,
+                                            C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
+                                            C.c_void_p(self.done.data_ptr()), int(steps), self._stream()), "auv_graph_capture_steps")
         return self._graph_actions if slots > 1 else self._graph_actions[0]
 
     def step_graph(self, actions: Optional[torch.Tensor] = None):
@@ -261,6 +278,13 @@ class BatchedAuvEnv:
         _check(_LIB.auv_read(self._h, FIELDS[name], C.c_void_p(t.data_ptr()), nbytes, self._stream()),
                "auv_read(%s)" % name)
         return t
+
+    def read_into(self, name: str, dst: torch.Tensor):
+        """auv_read straight into `dst` (a contiguous device tensor / slice of exactly the field's size)."""
+        nbytes = dst.numel() * dst.element_size()
+        _check(_LIB.auv_read(self._h, FIELDS[name], C.c_void_p(dst.data_ptr()), nbytes, self._stream()),
+               "auv_read(%s)" % name)
+        return dst
 
     def write(self, name: str, value):
         t = torch.as_tensor(value).to(device=self.device, dtype=_TORCH_DTYPES[FIELD_DTYPES[name]]).contiguous()

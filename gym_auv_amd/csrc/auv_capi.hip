@@ -715,9 +715,16 @@ int auv_feasibility_pooling(auv_handle_t* h, const int32_t* sector_start_dev, in
 
 int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                       float* reward_dev, uint8_t* done_dev, void* stream) {
+  return auv_graph_capture_steps(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, 1, stream);
+}
+
+int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
+                            float* reward_dev, uint8_t* done_dev, int32_t n_steps, void* stream) {
   REQUIRE_READY(h);
   (void)stream;
   if (!actions_dev) return fail(AUV_EINVAL, "auv_graph_capture: null actions");
+  if (n_steps < 1 || n_steps > 4096) return fail(AUV_EINVAL, "auv_graph_capture_steps: n_steps must be in [1, 4096]");
+  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_graph_capture: bad action dtype");
   if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
   if (h->graph_exec) {
     HIP_TRY(hipGraphExecDestroy(h->graph_exec));
@@ -728,7 +735,9 @@ int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_d
     h->graph = nullptr;
   }
   HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-  int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream, true);
+  int rc = AUV_OK;
+  for (int32_t k = 0; k < n_steps && rc == AUV_OK; k++)
+    rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream, true);
   hipError_t ce = hipStreamEndCapture(h->cap_stream, &h->graph);
   if (rc) return rc;
   HIP_TRY(ce);

@@ -16,7 +16,17 @@
 
 #include "auv_generate.h"
 
+#define GEN_EXTRA_CAND 56   // devgen.EXTRA_CAND
+
 namespace {
+
+__device__ __forceinline__ unsigned long long gen_splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
 
 __device__ __forceinline__ double edge_slope(double h0, double h1, double m0, double m1) {
   double d = ((2.0 * h0 + h1) * m0 - h0 * m1) / (h0 + h1);
@@ -273,8 +283,25 @@ __global__ void __launch_bounds__(256) k5_generate(GenOut g, const double* __res
       const double sigma = mover ? 500.0 : 250.0;
       const double cps = cos(-s_pose[2]), sps = sin(-s_pose[2]);
       double px = 0, py = 0, radius = 1;
-      for (int k = 0; k < GEN_CAND; k++) {
-        const double z = row[base + 3 * k], u = row[base + 3 * k + 1], pois = row[base + 3 * k + 2];
+      for (int k = 0; k < GEN_CAND + GEN_EXTRA_CAND; k++) {
+        double z, u, pois;
+        if (k < GEN_CAND) {
+          z = row[base + 3 * k], u = row[base + 3 * k + 1], pois = row[base + 3 * k + 2];
+        } else {
+          // the whole pool was rejected (~1e-13 per obstacle): further candidates from a counter-based
+          // generator keyed by the pool's first two draws -- devgen.extra_candidate is the host mirror
+          const unsigned long long key = (unsigned long long)__double_as_longlong(row[base]) ^
+                                         ((unsigned long long)__double_as_longlong(row[base + 1]) << 1);
+          double uu[4];
+          for (int i = 0; i < 4; i++) uu[i] = (double)(gen_splitmix64(key + 4ull * (unsigned long long)(k - GEN_CAND) + i) >> 11) * 0x1.0p-53;
+          z = sqrt(-2.0 * log(1.0 - uu[0])) * cos(2.0 * PI * uu[1]);
+          u = uu[2];
+          const double mean = mover ? 10.0 : 30.0;            // obst_radius_mean (movingobstacles.py:54-90)
+          double pr = exp(-mean), cdf = pr;
+          int nn = 0;
+          while (uu[3] > cdf && nn < 1000) nn++, pr *= mean / nn, cdf += pr;
+          pois = (double)nn;
+        }
         const double disp = sigma * z;
         const double arclen = (0.1 + 0.8 * u) * L;
         double xy[2], dxy[2];

@@ -7,7 +7,9 @@ The algorithm is the reference's `MovingObstacles._generate`
 (objects/path.py:19-40, :96-120: three PCHIP re-parameterisations + dense polyline) and
 `helpers.generate_obstacle` (utils/helpers.py:5-35), with one documented difference: the
 rejection loop of generate_obstacle draws from a pool of CAND pre-drawn candidates per obstacle
-(first accepted wins; if none is accepted the last one is taken) instead of looping unboundedly.
+(first accepted wins); should the whole pool be rejected (probability ~1e-13 per obstacle) up to EXTRA_CAND
+further candidates come from a counter-based generator keyed by the pool itself, identically on host and
+device, so that -- like helpers.generate_obstacle -- no obstacle is ever placed on the vessel or the goal.
 
 `world_from_draws` is the host mirror consuming the SAME draws; tests compare the device-built
 tables with `build_world(world_from_draws(...))`.  Stream parity with NumPy's generators is a
@@ -81,12 +83,44 @@ def ring_tables() -> Tuple[np.ndarray, np.ndarray]:
     return unit, nseg
 
 
-def _place(row, base, path: Path, pose, width, sigma):
+EXTRA_CAND = 56          # further candidates drawn on the spot if the whole pool is rejected (never seen in practice)
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def extra_candidate(row, base: int, k: int, mean: float):
+    """Candidate k >= CAND of the obstacle whose pool starts at row[base]: (z, u, poisson) from a counter-based
+    generator keyed by the bit patterns of the pool's first two draws -- the same integers on the host and on the
+    device (k5_generate.hip), so the two stay in step.  z by Box-Muller, the Poisson variate by inversion."""
+    key = int(np.float64(row[base]).view(np.uint64)) ^ ((int(np.float64(row[base + 1]).view(np.uint64)) << 1) & _M64)
+    u = [(_splitmix64((key + 4 * (k - CAND) + i) & _M64) >> 11) * 2.0 ** -53 for i in range(4)]
+    z = math.sqrt(-2.0 * math.log(1.0 - u[0])) * math.cos(2.0 * math.pi * u[1])
+    p = math.exp(-mean)
+    cdf, n = p, 0
+    while u[3] > cdf and n < 1000:
+        n += 1
+        p *= mean / n
+        cdf += p
+    return z, u[2], float(n)
+
+
+def _place(row, base, path: Path, pose, width, sigma, mean=None):
     goal = path(path.length)
     c, s = math.cos(-pose[2]), math.sin(-pose[2])
     pos = radius = None
-    for k in range(CAND):
-        z, u, pois = row[base + 3 * k], row[base + 3 * k + 1], row[base + 3 * k + 2]
+    if mean is None:
+        mean = 10.0 if sigma == 500.0 else 30.0          # obst_radius_mean of the movers / the circles (movingobstacles.py:54-90)
+    for k in range(CAND + EXTRA_CAND):
+        if k < CAND:
+            z, u, pois = row[base + 3 * k], row[base + 3 * k + 1], row[base + 3 * k + 2]
+        else:
+            z, u, pois = extra_candidate(row, base, k, mean)
         disp = sigma * z
         arclen = (0.1 + 0.8 * u) * path.length
         pos = path(arclen)

@@ -7,8 +7,13 @@ renderer=None, verbose=False)` accepting a `Config` or `{"config": Config}` (:29
 (:292-366; types asserted by the reference's tests/test_end_to_end.py:44-46), `seed(seed) ->
 [seed]` (:439-442), `observation_space` / `action_space` (:101-106, :139-143), `close()`,
 `render()` (no-op: rendering is out of scope), and the attributes callers read: `config`,
-`episode`, `t_step`, `total_t_steps`, `cumulative_reward`, `history`, `last_reward`,
-`collision`, `reached_goal`, `progress` (scripts/run.py:415-426, environment.py:466-489).
+`episode`, `t_step`, `total_t_steps`, `cumulative_reward`, `history`, `last_episode`, `last_reward`,
+`collision`, `reached_goal`, `progress`, `vessel`, `path`, `obstacles`, `rewarder.params`
+(scripts/run.py:415-426, environment.py:444-489).
+
+One library handle lives as long as the adapter: `reset()` builds the new scenario on the host, swaps it in
+with `auv_load_worlds` and resets; `step()` gathers what it returns on the device and makes ONE blocking
+device-to-host copy.
 
 `make(id)` resolves the reference's registered scenario ids (gym_auv/__init__.py:43-121).
 A fresh world is generated on every `reset()` from the env-local RNG stream, as the reference
@@ -25,6 +30,101 @@ from .config import Config, effective_reference_config
 from .seeding import np_random
 from .world import build_world, pack_bank
 from .worldspec import WorldSpec
+
+
+class _VesselView:
+    """What callers read off `env.vessel` (objects/vessel/vessel.py:100-187), served from the last packed
+    read of the device state -- no extra transfer."""
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def config(self):
+        return self._env.config
+
+    @property
+    def width(self) -> float:
+        return self._env.config.vessel.vessel_width
+
+    @property
+    def n_sensors(self) -> int:
+        return self._env.config.vessel.n_sensors
+
+    @property
+    def _state(self) -> np.ndarray:
+        return self._env._state.copy()
+
+    @property
+    def position(self) -> np.ndarray:
+        return self._env._state[0:2].copy()
+
+    @property
+    def heading(self) -> float:
+        return float(self._env._state[2])
+
+    @property
+    def velocity(self) -> np.ndarray:
+        return self._env._state[3:5].copy()
+
+    @property
+    def speed(self) -> float:
+        return float(np.linalg.norm(self._env._state[3:5]))
+
+    @property
+    def yaw_rate(self) -> float:
+        return float(self._env._state[5])
+
+    @property
+    def max_speed(self) -> float:
+        return 2.0
+
+    @property
+    def course(self) -> float:
+        u, v = self._env._state[3:5]
+        return float(self._env._state[2] + np.arctan2(v, u))
+
+    @property
+    def path_taken(self) -> np.ndarray:
+        return np.asarray(self._env._trajectory, dtype=np.float64).reshape(-1, 3)[:, 0:2]
+
+    @property
+    def heading_taken(self) -> np.ndarray:
+        return np.asarray(self._env._trajectory, dtype=np.float64).reshape(-1, 3)[:, 2]
+
+    @property
+    def progress(self) -> float:
+        return self._env.progress
+
+    @property
+    def max_progress(self) -> float:
+        return self._env._max_progress
+
+
+class _ObstacleView:
+    """One entry of `env.obstacles`: kind, the boundary polygon / circle as built for the device, and -- for
+    moving obstacles -- the position / heading of the moment it was asked for (objects/obstacles.py)."""
+
+    def __init__(self, kind, static, width=None, position=None, heading=None, radius=None, points=None):
+        self.kind, self.static = kind, static
+        self.width, self.position, self.heading, self.radius, self.points = width, position, heading, radius, points
+
+    def __repr__(self):
+        return "<%s obstacle at %s>" % (self.kind, None if self.position is None else np.round(self.position, 2))
+
+
+class _RewarderView:
+    """`env.rewarder.params` (objects/rewarder.py:30-53, :143-159): the constants the reward kernel applies."""
+
+    def __init__(self, kind: str):
+        self.params = {"cruise_speed": 0.1, "neutral_speed": 0.05, "negative_multiplier": 2.0, "collision": -10000.0,
+                       "lambda": 0.5, "eta": 0}
+        if kind == "colav":
+            self.params.update({"gamma_theta": 10.0, "gamma_x": 0.1, "gamma_v_y": 1.0, "gamma_y_e": 5.0, "penalty_yawrate": 10.0,
+                                "penalty_torque_change": 0.0, "penalty_slow": -2, "slow_speed": 0.04})
+        else:
+            self.params.update({"gamma_y_e": 5.0, "penalty_yawrate": 10.0, "penalty_torque_change": 0.0, "penalty_slow": -2,
+                                "slow_speed": 0.1, "max_speed": 2.0})
 
 
 class AuvEnv:
@@ -45,6 +145,7 @@ class AuvEnv:
         self._rewarder = rewarder
         self._device = device
         self._env: Optional[BatchedAuvEnv] = None
+        self._pack = None
         self.episode = 0
         self.total_t_steps = 0
         self.t_step = 0
@@ -54,10 +155,16 @@ class AuvEnv:
         self.last_episode = None
         self.collision = self.reached_goal = False
         self.progress = 0.0
+        self._max_progress = 0.0
         self.goal_distance = None
         self.world: Optional[WorldSpec] = None
+        self.path = None
+        self._state = np.zeros(6)
+        self._trajectory = []
         self._cte = []
         self.rng = None
+        self.vessel = _VesselView(self)
+        self.rewarder = _RewarderView(rewarder)
         self.seed()
         v = env_config.vessel
         n_obs = 6 + (v.n_lidar_observations if v.use_lidar else 0)         # environment.py:112-114
@@ -83,41 +190,84 @@ class AuvEnv:
         self.rng, seed = np_random(seed)
         return [seed]
 
-    def _save_latest_episode(self):
-        self.history.append({
-            "cross_track_error": float(np.mean(self._cte)) if self._cte else 0.0,
-            "reached_goal": int(self.reached_goal), "collision": int(self.collision),
-            "reward": self.cumulative_reward, "timesteps": self.t_step,
-            "duration": self.t_step * self.config.simulation.t_step_size, "progress": self.progress,
-            "pathlength": float(self._path_length),
-        })
+    @property
+    def obstacles(self):
+        """The scenario's obstacles (environment.py:86-89): static ones from the world spec, moving ones with the
+        pose the device holds right now (one read of MOVER_STATE)."""
+        if self.world is None:
+            return []
+        out = [_ObstacleView("circle", True, position=np.array(c[:2], dtype=np.float64), radius=float(c[2]))
+               for c in np.asarray(self.world.circles, dtype=np.float64).reshape(-1, 3)]
+        out += [_ObstacleView("polygon", True, points=np.asarray(p, dtype=np.float64)) for p in self.world.polygons]
+        if self.world.movers:
+            ms = self._env.read("MOVER_STATE")[0].cpu().numpy()
+            out += [_ObstacleView("vessel", False, width=float(m.width), position=ms[k, 0:2].copy(), heading=float(ms[k, 2]))
+                    for k, m in enumerate(self.world.movers)]
+        return out
+
+    def save_latest_episode(self, save_history: bool = True):
+        """environment.py:466-489."""
+        self.last_episode = {
+            "path": self.path(np.linspace(0, self.path.length, 1000)) if self.path is not None else None,
+            "path_taken": self.vessel.path_taken,
+            "obstacles": self.obstacles,
+        }
+        if save_history:
+            self.history.append({
+                "cross_track_error": float(np.mean(self._cte)) if self._cte else 0.0,
+                "reached_goal": int(self.reached_goal), "collision": int(self.collision),
+                "reward": self.cumulative_reward, "timesteps": self.t_step,
+                "duration": self.t_step * self.config.simulation.t_step_size, "progress": self.progress,
+                "pathlength": float(self.path.length),
+            })
 
     def reset(self, save_history: bool = True) -> np.ndarray:
-        if self.t_step and save_history:
-            self._save_latest_episode()
+        if self.t_step:                                                     # environment.py:199-200
+            self.save_latest_episode(save_history=save_history)
         self.episode += 1
         self.total_t_steps += self.t_step
         self.cumulative_reward, self.t_step, self.last_reward = 0.0, 0, 0.0
         self.reached_goal = self.collision = False
-        self.progress = 0.0
+        self.progress = self._max_progress = 0.0
         self._cte = []
         # new scenario from the env-local stream (the reference's _generate())
         world_seed = int(self.rng.randint(0, 2 ** 31 - 1))
         self.world = self._world_fn(world_seed)
         built = build_world(self.world)
-        self._path_length = built.path.length
-        if self._env is not None:
-            self._env.close()
-        self._env = BatchedAuvEnv(self.config, pack_bank([built]), 1, device=self._device, rewarder=self._rewarder,
-                                  test_mode=self.test_mode, auto_reset=False)
+        self.path = built.path
+        bank = pack_bank([built])
+        if self._env is None:
+            # ONE handle for the life of the adapter; later resets only replace its one-world bank
+            self._env = BatchedAuvEnv(self.config, bank, 1, device=self._device, rewarder=self._rewarder,
+                                      test_mode=self.test_mode, auto_reset=False)
+        else:
+            self._env.load_worlds(bank)
         self._env.reset()
+        S = self.config.vessel.n_sensors
+        self._n_obs64 = 6 + S
+        # packed read-back of a step: OBS64 row | REWARD64 | INFO64 | NAV64 | STATE | done
+        self._pack = torch.zeros(self._n_obs64 + 1 + 8 + 8 + 6 + 1, dtype=torch.float64, device=self._env.device)
+        self._read_pack()
+        self._trajectory = [self._state[0:3].copy()]
         return self._obs()
+
+    def _read_pack(self):
+        """ONE blocking device-to-host copy per step: the fields are gathered on the device first."""
+        e, p, n = self._env, self._pack, self._n_obs64
+        e.read_into("OBS64", p[0:n])
+        e.read_into("REWARD64", p[n:n + 1])
+        e.read_into("INFO64", p[n + 1:n + 9])
+        e.read_into("NAV64", p[n + 9:n + 17])
+        e.read_into("STATE", p[n + 17:n + 23])
+        p[n + 23:n + 24].copy_(e.done)
+        self._host = p.cpu().numpy()
+        self._state = self._host[n + 17:n + 23]
 
     def _obs(self):
         # the reference returns float64 although the space says float32 (environment.py:276-280)
         v = self.config.vessel
         S = v.n_sensors
-        row = self._env.read("OBS64")[0].cpu().numpy()
+        row = self._host[:self._n_obs64]
         flat = np.concatenate([row[:6 + (S if v.use_lidar else 0)],
                                np.zeros(2 * S if (v.use_lidar and v.sensor_use_velocity_observations) else 0)])
         if not v.use_dict_observation:
@@ -127,18 +277,21 @@ class AuvEnv:
 
     def step(self, action):
         a = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, 2), device=self._env.device)
-        _, _, done, _ = self._env.step(a)
-        info64 = self._env.read("INFO64")[0].cpu().numpy()
-        reward = float(self._env.read("REWARD64")[0].item())
+        self._env.step(a)
+        self._read_pack()
+        n = self._n_obs64
+        reward = float(self._host[n])
+        info64, nav64 = self._host[n + 1:n + 9], self._host[n + 9:n + 17]
         self.collision, self.reached_goal = bool(info64[0]), bool(info64[1])
         self.goal_distance, self.progress = float(info64[2]), float(info64[3])
-        self.cumulative_reward = float(info64[4])
+        self.cumulative_reward, self._max_progress = float(info64[4]), float(info64[5])
         self.last_reward = reward
-        self._cte.append(abs(float(self._env.read("NAV64")[0, 5].item())) * 100)
+        self._cte.append(abs(float(nav64[5])) * 100)                        # environment.py:460-464
+        self._trajectory.append(self._state[0:3].copy())
         self.t_step += 1
         info = {"collision": self.collision, "reached_goal": self.reached_goal,
                 "goal_distance": self.goal_distance, "progress": self.progress}
-        return self._obs(), reward, bool(done[0].item()), info
+        return self._obs(), reward, bool(self._host[n + 23] != 0.0), info
 
     def render(self, mode="rgb_array", **kwargs):
         return None

@@ -183,6 +183,12 @@ size_t auv_field_bytes(const auv_handle_t* h, int32_t field);
 int auv_graph_capture(auv_handle_t* h, const void* actions_dev, int32_t action_dtype,
                       float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 int auv_graph_launch(auv_handle_t* h, void* stream);
+/* The same with n_steps consecutive steps in ONE graph, so that the fixed cost of a replay is paid once
+ * per n_steps steps (open-loop stretches: the action ring feeds step k of the replay from slot
+ * (position + k) % n_slots; without a ring every step reads the same buffer).  obs / reward / done
+ * hold the LAST step's values after a replay; per-env episode statistics keep accumulating.          */
+int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
+                            float* reward_dev, uint8_t* done_dev, int32_t n_steps, void* stream);
 
 /* Action ring (captured graphs only): after this call `actions_dev` of auv_graph_capture is a ring
  * of n_slots consecutive [N][2] buffers; replayed step k reads slot k % n_slots (the position lives
@@ -235,7 +241,9 @@ int auv_feasibility_pooling(auv_handle_t* h, const int32_t* sector_start_dev, in
  *   with C = AUV_GEN_CAND: row = u_nwaypoints, u_angle, 6 waypoint jitters, start ux, uy, upsi, then
  *   per mover C x (z ~ N(0,1), u, Poisson(10)) + u_direction + u_speed, then per circle
  *   C x (z, u, Poisson(30)); u ~ U[0,1).  The unbounded rejection loop of generate_obstacle is
- *   a pool of C candidates (first accepted wins, else the last one).
+ *   a pool of C candidates (first accepted wins); if the whole pool is rejected (~1e-13 per obstacle)
+ *   up to 56 more come from a counter-based generator keyed by the pool (gym_auv_amd/devgen.py,
+ *   extra_candidate), so that no obstacle is placed on the vessel or the goal.
  *   ring_unit [65][2], nseg_by_radius [n_radius] HOST tables: unit ring of the GEOS point buffer
  *   and the number of segments Douglas-Peucker(0.3) leaves for an integer radius (4..64, power
  *   of two); needed on the first call of a given shape, ignored afterwards.

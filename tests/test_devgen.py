@@ -55,3 +55,56 @@ def test_world_from_draws_is_a_valid_moving_obstacles_world():
         # the vessel does not start inside an accepted obstacle
         dist = np.hypot(spec.circles[:, 0] - spec.vessel_init[0], spec.circles[:, 1] - spec.vessel_init[1]) - spec.circles[:, 2]
         assert np.all(dist > 0)
+
+
+def test_exhausted_candidate_pool_redraws_instead_of_placing_on_the_vessel():
+    """helpers.generate_obstacle (utils/helpers.py:13-33) loops until the obstacle is clear of the vessel and the
+    goal; the device generator has a pool of CAND pre-drawn candidates.  (a) over a few hundred random worlds count
+    how far into the pool the placements go: the pool is never exhausted (one rejection needs an obstacle on top of
+    the vessel or the goal, ~1 % per candidate); (b) adversarial draws whose WHOLE pool is rejected (radius 6 km
+    for every candidate of three obstacles) get a fresh candidate from the keyed generator, so the result is still
+    clear of vessel and goal -- VERDICT r1 weak #10: it used to keep the last rejected candidate."""
+    import math
+    d = devgen.sample_draws(150, 17, 11, seed=123).numpy()
+    deepest = 0
+    for row in d:
+        spec = devgen.world_from_draws(row)
+        path = build_world(spec).path
+        goal = path(path.length)
+        col = 11
+        for j in range(28):
+            sigma = 500.0 if j < 17 else 250.0
+            # replay the pool to see which candidate was accepted
+            acc = None
+            for k in range(devgen.CAND):
+                z, u, pois = row[col + 3 * k: col + 3 * k + 3]
+                arclen = (0.1 + 0.8 * u) * path.length
+                ang = devgen._princip(path.get_direction(arclen) - np.pi / 2)
+                pos = path(arclen) + sigma * z * np.array([np.cos(ang), np.sin(ang)])
+                rad = max(1.0, pois)
+                vd = math.hypot(pos[0] - spec.vessel_init[0], pos[1] - spec.vessel_init[1]) - devgen.VESSEL_WIDTH - rad
+                gd = math.hypot(pos[0] - goal[0], pos[1] - goal[1]) - rad
+                if min(vd, gd) > 0:
+                    acc = k
+                    break
+            assert acc is not None, "pool of %d exhausted on random draws" % devgen.CAND
+            deepest = max(deepest, acc)
+            col += 3 * devgen.CAND + (2 if j < 17 else 0)
+    assert deepest <= 3, deepest                        # 4200 placements: at most a few rejections in a row
+    # (b) adversarial: every pooled candidate of mover 0, mover 5 and circle 2 has a 600 m radius
+    row = d[0].copy()
+    for base in (11, 11 + 5 * (3 * devgen.CAND + 2), 11 + 17 * (3 * devgen.CAND + 2) + 2 * 3 * devgen.CAND):
+        row[base + 2: base + 3 * devgen.CAND: 3] = 6000.0
+    spec = devgen.world_from_draws(row)
+    path = build_world(spec).path
+    goal = path(path.length)
+    rad = np.array([spec.movers[0].width, spec.movers[5].width, spec.circles[2, 2]])
+    pos = np.array([spec.movers[0].pos0, spec.movers[5].pos0, spec.circles[2, :2]])
+    assert np.all(rad < 100)                            # Poisson(10) / Poisson(30) from the keyed generator, not 6000
+    vd = np.hypot(*(pos - spec.vessel_init[:2]).T) - devgen.VESSEL_WIDTH - rad
+    gd = np.hypot(*(pos - goal).T) - rad
+    assert np.all(vd > 0) and np.all(gd > 0)
+    # the keyed generator is a function of the pool alone
+    assert devgen.extra_candidate(row, 11, devgen.CAND, 10.0) == devgen.extra_candidate(row.copy(), 11, devgen.CAND, 10.0)
+    zs = [devgen.extra_candidate(row, 11, devgen.CAND + i, 30.0) for i in range(devgen.EXTRA_CAND)]
+    assert abs(np.mean([z[2] for z in zs]) - 30.0) < 5 and all(0 <= z[1] < 1 for z in zs)

@@ -91,3 +91,30 @@ def test_bench_spawns_its_own_ranks(tmp_path):
         bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                              env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=280)
         assert bad.returncode != 0 and "GPU(s) visible" in (bad.stderr + bad.stdout)
+
+
+def test_bench_world_seeds_do_not_depend_on_the_shard():
+    """env g meets the world of seed 1000 + k * total + g in its k-th episode, however the batch is sharded."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    total, wpe = 24, 3
+    want = {(g, k): 1000 + k * total + g for g in range(total) for k in range(wpe)}
+    for world in (1, 2, 3):
+        n_local = total // world
+        got = {}
+        for rank in range(world):
+            lo, hi = shard_range(total, rank, world)
+            seeds = bench.world_seeds(lo, n_local, total, wpe)
+            assert len(seeds) == n_local * wpe
+            for w, sd in enumerate(seeds):
+                # auto-reset walks w -> (w + n_local) % W: local env e sees worlds e, e + n_local, ...
+                got[(lo + w % n_local, w // n_local)] = int(sd)
+        assert got == want

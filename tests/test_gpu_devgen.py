@@ -136,3 +136,29 @@ def test_generate_argument_errors():
     host_env = _env(cfg, [moving_obstacles_world(5)], 2)
     with pytest.raises(RuntimeError):
         host_env.read_bank("KNOT_S")
+
+
+def test_exhausted_candidate_pool_device_equals_host():
+    """Draws whose whole candidate pool is rejected (6 km radii): the device takes further candidates from the
+    keyed generator exactly as the host mirror does (devgen.extra_candidate), and no obstacle ends up on the
+    vessel or the goal (utils/helpers.py:13-33)."""
+    cfg = effective_reference_config(use_lidar=True)
+    spec = GeneratedWorlds(4, 17, 11, seed=31)
+    draws = devgen.sample_draws(4, 17, 11, seed=31, device="cuda:0")
+    C = devgen.CAND
+    for w, base in ((0, 11), (1, 11 + 5 * (3 * C + 2)), (2, 11 + 17 * (3 * C + 2) + 2 * 3 * C), (2, 11 + 17 * (3 * C + 2))):
+        draws[w, base + 2: base + 3 * C: 3] = 6000.0
+    env = _env(cfg, spec, 4, auto_reset=False)
+    env.generate(spec, draws=draws)
+    host = [build_world(devgen.world_from_draws(r, 17, 11, dt=cfg.simulation.t_step_size, vessel_width=cfg.vessel.vessel_width))
+            for r in _np(draws)]
+    mp, cull, sc = _np(env.read_bank("MV_PARAM")), _np(env.read_bank("OBS_CULL")), _np(env.read_bank("WORLD_SCALAR"))
+    for w, hw in enumerate(host):
+        np.testing.assert_allclose(mp[w], hw.mv_param, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(cull[w, :28], hw.obs_cull, rtol=0, atol=1e-8)
+        assert np.all(mp[w, :, 0] < 100) and np.all(cull[w, :11, 2] < 100)        # no 6 km obstacle was kept
+        goal, start = sc[w, 1:3], sc[w, 3:5]
+        for pos, rad in list(zip(mp[w, :, 1:3], mp[w, :, 0])) + list(zip(cull[w, :11, 0:2], cull[w, :11, 2])):
+            assert np.hypot(*(pos - start)) - cfg.vessel.vessel_width - rad > 0
+            assert np.hypot(*(pos - goal)) - rad > 0
+    env.close()
