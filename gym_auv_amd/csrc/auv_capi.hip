@@ -200,7 +200,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
   HIP_TRY(auv_k2_prepare(d));
   HIP_TRY(auv_step_fused_prepare(d));
-  if ((size_t)AUV_ENVS_PER_BLOCK * d.nch_max * 4 > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
+  if ((size_t)AUV_ENVS_PER_BLOCK * (d.nch_max * 4 + 512) > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;

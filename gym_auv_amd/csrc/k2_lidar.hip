@@ -350,8 +350,26 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
             const ObsLds o = L.obs[lo];
             const int si = t - L.sbase[lo];
             const double4 sg = (o.kind == AUV_OBS_MOVER) ? mover_segs(L.mvrot[o.seg_off], L.mvw[o.seg_off])[si] : d.seg[o.seg_off + si];
-            const double dist = auv_pt_seg_dist(px, py, sg.x, sg.y, sg.z, sg.w);
-            if (dist - W < R) atomicOr(&L.par[lo], 1);
+            // fp32 screen of dist - W < R: the point-segment distance of vessel-relative coordinates
+            // (< ~1 km) is good to well under a millimetre in fp32; only within 1 cm of the threshold
+            // does the exact fp64 distance decide
+            const float ax = (float)(sg.x - px), ay = (float)(sg.y - py), bx = (float)(sg.z - px), by = (float)(sg.w - py);
+            const float ex = bx - ax, ey = by - ay, l2 = ex * ex + ey * ey;
+            const float dt = -(ax * ex + ay * ey);
+            float d2f;
+            if (l2 == 0.0f || dt <= 0.0f) d2f = ax * ax + ay * ay;
+            else if (dt >= l2) d2f = bx * bx + by * by;
+            else {
+              const float cr = ax * ey - ay * ex;
+              d2f = cr * cr / l2;
+            }
+            const float thr = (float)(R + W);
+            const float df = sqrtf(d2f);
+            int verdict = df < thr - 1e-2f ? 1 : (df > thr + 1e-2f ? 0 : 2);
+            if (__any(verdict == 2)) {
+              if (verdict == 2) verdict = (auv_pt_seg_dist(px, py, sg.x, sg.y, sg.z, sg.w) - W < R) ? 1 : 0;
+            }
+            if (verdict == 1) atomicOr(&L.par[lo], 1);
           }
         }
         auv_wave_lds_sync();
@@ -413,15 +431,51 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
           } else {
             cx = scx, cy = scy, rho = srho;
           }
-          double relx = cx - px, rely = cy - py;
-          double bearing = atan2(rely, relx) - psi;          // not wrapped (sensor.py:54)
-          double dist = sqrt(relx * relx + rely * rely);
-          double safe = dist > 1e-8 ? dist : 1e-8;
-          double q = rho / safe;
-          double f = (q > 1.0 || q < -1.0 || isnan(q)) ? AUV_PI : asin(q);   // NaN -> pi (sensor.py:34-36)
-          // |bearing| < 2 pi and f <= pi, so both indices lie in (-S, 2S): int32 is ample
-          int imin = (int)floor((AUV_PI + (bearing - f)) / dangle);
-          int imax = (int)ceil((AUV_PI + (bearing + f)) / dangle);
+          const double relx = cx - px, rely = cy - py;
+          // The two limits are floor / ceil of (pi + bearing -+ f) / dangle with bearing = atan2(rel) - psi
+          // (not wrapped, sensor.py:54) and f = asin(rho / dist) (pi inside the circle, sensor.py:34-36).
+          // fp32 atan2f / asinf give both quotients to a few 1e-4 of a ray; unless one of them comes that
+          // close to an integer, floor / ceil of the fp32-based value IS the fp64 result, and the fp64
+          // atan2 / asin / sqrt / division chain (a quarter of this phase) is not needed.  Error budget in
+          // radians, twice what OpenCL guarantees for atan2f (6 ulp of <= pi) and asinf (4 ulp of <= pi/2)
+          // plus the input roundings, the latter amplified by 1 / sqrt(1 - q^2); doubled once more below.
+          int imin = 0, imax = 0;
+          bool exact = true;
+          {
+            const float rxf = (float)relx, ryf = (float)rely;
+            const float df = sqrtf(rxf * rxf + ryf * ryf);
+            const float qf = (float)rho / df;
+            const bool outside = qf < 0.999f, inside = qf > 1.001f;       // (NaN / inf: neither)
+            if ((outside || inside) && df > 1e-3f) {
+              const float th = atan2f(ryf, rxf);
+              double f64 = AUV_PI, err = 3.0e-6;
+              if (outside) {
+                const float amp = 1.0f / sqrtf(1.0f - qf * qf);
+                f64 = (double)asinf(qf);
+                err += 1.0e-6 + 6.0e-7 * (double)amp;
+              }
+              const double b64 = (double)th - psi;
+              const double xmin = (AUV_PI + (b64 - f64)) / dangle, xmax = (AUV_PI + (b64 + f64)) / dangle;
+              const double fl = floor(xmin), ce = ceil(xmax);
+              const double tol = 2.0 * err / dangle;
+              if (xmin - fl > tol && (fl + 1.0) - xmin > tol && ce - xmax > tol && xmax - (ce - 1.0) > tol) {
+                imin = (int)fl, imax = (int)ce;
+                exact = false;
+              }
+            }
+          }
+          if (__any(exact)) {
+            if (exact) {
+              double bearing = atan2(rely, relx) - psi;          // not wrapped (sensor.py:54)
+              double dist = sqrt(relx * relx + rely * rely);
+              double safe = dist > 1e-8 ? dist : 1e-8;
+              double q = rho / safe;
+              double f = (q > 1.0 || q < -1.0 || isnan(q)) ? AUV_PI : asin(q);   // NaN -> pi (sensor.py:34-36)
+              // |bearing| < 2 pi and f <= pi, so both indices lie in (-S, 2S): int32 is ample
+              imin = (int)floor((AUV_PI + (bearing - f)) / dangle);
+              imax = (int)ceil((AUV_PI + (bearing + f)) / dangle);
+            }
+          }
           lim = make_int2(imin, imax);
           start = imin - 1;
           stop = auv_pymod(imax, S);                           // range(i_min - 1, i_max % S)

@@ -391,38 +391,41 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
   const double2* xy = d.poly_xy + ed.p0;
   double U = 1.7976931348623157e308;
   int n_act = 0;
+  int cstar = -1;                                  // the chunk whose segments sA / sB / scum hold (register-resident route)
+  double2 sA = make_double2(0.0, 0.0), sB = sA;
+  double scum = 0.0;
   if (nch <= NAV_CPL * AUV_WAVE) {
     double4 b[NAV_CPL];
     double cdist[NAV_CPL];
+    // hint: the chunk that held the nearest point LAST step (its arclength is in INFO64; the dense polyline
+    // is uniform in the spline parameter, so arclength / L locates the segment to within a few).  Its 64
+    // segments are requested together with the chunk circles: the exact distance to them bounds the
+    // distance to the path within centimetres, without a second trip to memory
+    {
+      int jh = (int)(prog.x / sp.L * (double)(P - 1));
+      jh = jh < 0 ? 0 : (jh > P - 2 ? P - 2 : jh);
+      cstar = jh / AUV_CHUNK;
+    }
 #pragma unroll
     for (int i = 0; i < NAV_CPL; i++) {
       const int c = i * AUV_WAVE + lane;
       b[i] = cb[c < nch ? c : nch - 1];
     }
+    const int jhl = cstar * AUV_CHUNK + lane;
+    {
+      const int jj = jhl < P - 1 ? jhl : 0;
+      sA = xy[jj], sB = xy[jj + 1], scum = d.poly_cum[ed.p0 + jj];   // kept if this chunk survives
+    }
 #pragma unroll
     for (int i = 0; i < NAV_CPL; i++) {
       const double dx = qx - b[i].x, dy = qy - b[i].y;
       cdist[i] = sqrt(dx * dx + dy * dy);
+      if (i * AUV_WAVE + lane < nch) U = fmin(U, cdist[i] + b[i].z);   // from the circles: min of |q - c| + rad
     }
-    // upper bound on the distance to the path: first from the circles (min of |q - c| + rad), then the
-    // EXACT distance to the 64 segments of the chunk that gave it -- within a few centimetres of the
-    // truth instead of a chunk diameter, so that typically one or two chunks survive
-    MinIdx ub;
-    ub.d = 1.7976931348623157e308, ub.j = 0;
-#pragma unroll
-    for (int i = 0; i < NAV_CPL; i++) {
-      const int c = i * AUV_WAVE + lane;
-      if (c < nch && cdist[i] + b[i].z < ub.d) ub.d = cdist[i] + b[i].z, ub.j = c;
-    }
-    ub = wave_min_first(ub);
     {
-      const int j = ub.j * AUV_CHUNK + lane;
       double dd = 1.7976931348623157e308;
-      if (j < P - 1) {
-        const double2 A = xy[j], B = xy[j + 1];
-        dd = auv_pt_seg_dist(qx, qy, A.x, A.y, B.x, B.y);
-      }
-      U = fmin(ub.d, auv_wave_min(dd)) + slack;
+      if (jhl < P - 1) dd = auv_pt_seg_dist(qx, qy, sA.x, sA.y, sB.x, sB.y);
+      U = auv_wave_min(fmin(U, dd)) + slack;
     }
 #pragma unroll
     for (int i = 0; i < NAV_CPL; i++) {
@@ -460,9 +463,13 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
     sp.A[q] = sp.B[q] = make_double2(0.0, 0.0);
     sp.cum[q] = 0.0;
     if (sp.in_regs && q < n_act) {
-      const int j = list[q] * AUV_CHUNK + lane;
-      const int jj = j < P - 1 ? j : 0;
-      sp.A[q] = xy[jj], sp.B[q] = xy[jj + 1], sp.cum[q] = d.poly_cum[ed.p0 + jj];
+      if (list[q] == cstar) {                      // (uniform) already fetched for the upper bound
+        sp.A[q] = sA, sp.B[q] = sB, sp.cum[q] = scum;
+      } else {
+        const int j = list[q] * AUV_CHUNK + lane;
+        const int jj = j < P - 1 ? j : 0;
+        sp.A[q] = xy[jj], sp.B[q] = xy[jj + 1], sp.cum[q] = d.poly_cum[ed.p0 + jj];
+      }
     }
   }
   if (win_slots && lane < 3) {
@@ -628,11 +635,21 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
 }
 
 // the navigation of one environment in one go (no pose guess): the per-kernel API, the reset pass and the
-// launch shapes that run it behind a finished dynamics kernel
-__device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const int lane, int* list,
+// launch shapes that run it behind a finished dynamics kernel.  `scratch`: NAV_SCRATCH_BYTES(nch_max) of
+// LDS, 16-byte aligned: three parked spline windows, then the list of surviving chunks.
+#define NAV_WIN_BYTES (3 * 20 * 8)
+#define NAV_SCRATCH_BYTES(nch_max) ((NAV_WIN_BYTES + (size_t)(nch_max) * sizeof(int) + 15) & ~(size_t)15)
+__device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const int lane, unsigned char* scratch,
                                            float* __restrict__ obs_out, const EnvPre* pre = nullptr) {
-  NavSpec none;
-  nav_finish(d, e, lane, list, obs_out, pre, none, false, nullptr, nullptr);
+  double* wins = (double*)scratch;
+  int* list = (int*)(scratch + NAV_WIN_BYTES);
+  const size_t n = (size_t)d.n;
+  // (no spline windows ahead of time here: with nothing to overlap them with, requesting them early only
+  // lengthened the search -- measured 8.8 -> 9.9 us per navigation wave in the side-by-side launch)
+  (void)wins;
+  const NavSpec sp = nav_speculate(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
+                                   0.0, nullptr);
+  nav_finish(d, e, lane, list, obs_out, pre, sp, true, nullptr, nullptr);
 }
 
 // ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----
@@ -739,7 +756,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav_reward(AuvDev d, int mode, f
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
-  if (mode != 2) k3_nav_env(d, e, lane, (int*)smem + (size_t)wave * d.nch_max, obs_out);
+  if (mode != 2) k3_nav_env(d, e, lane, smem + (size_t)wave * NAV_SCRATCH_BYTES(d.nch_max), obs_out);
   k3_reward_env(d, e, lane, mode != 1, mode == 2 ? nullptr : obs_out, reward_out, done_out, nullptr, -1, mode == 2);
 }
 
@@ -749,7 +766,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_nav(AuvDev d, float* __restrict_
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
-  k3_nav_env(d, e, lane, (int*)smem + (size_t)wave * d.nch_max, obs_out);
+  k3_nav_env(d, e, lane, smem + (size_t)wave * NAV_SCRATCH_BYTES(d.nch_max), obs_out);
 }
 
 __global__ void __launch_bounds__(AUV_BLOCK) k3_reward(AuvDev d, float* __restrict__ obs_out,
@@ -766,7 +783,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_observe_fresh(AuvDev d, float* _
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int nf = *d.fresh_count;
-  int* list = (int*)smem + (size_t)wave * d.nch_max;
+  unsigned char* list = smem + (size_t)wave * NAV_SCRATCH_BYTES(d.nch_max);
   for (int i = blockIdx.x * AUV_ENVS_PER_BLOCK + wave; i < nf; i += gridDim.x * AUV_ENVS_PER_BLOCK) {
     const int e = auv_uniform(d.fresh_list[i]);
     k3_nav_env(d, e, lane, list, obs_out);
@@ -812,7 +829,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k_harvest(AuvDev d, int count) {
 }  // namespace
 
 #ifndef AUV_DEVICE_FUNCS_ONLY
-static size_t k3_lds_bytes(const AuvDev& d) { return (size_t)AUV_ENVS_PER_BLOCK * d.nch_max * sizeof(int); }
+static size_t k3_lds_bytes(const AuvDev& d) { return (size_t)AUV_ENVS_PER_BLOCK * NAV_SCRATCH_BYTES(d.nch_max); }
 static int env_grid(const AuvDev& d) { return (d.n + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK; }
 
 void auv_launch_k3(const AuvDev& d, int mode, float* obs, float* reward, uint8_t* done, hipStream_t st) {

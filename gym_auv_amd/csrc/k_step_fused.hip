@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
   // K1: every lane advances the (same) vessel; lane 0 writes it back
   const EnvPre pre = k1_env<AT>(d, e, actions, lane == 0);
   // K3-nav: its chunk list borrows the (not yet used) segment stage of the LiDAR slice
-  k3_nav_env(d, e, lane, (int*)L.stage, obs_out, &pre);
+  k3_nav_env(d, e, lane, (unsigned char*)L.stage, obs_out, &pre);
   auv_wave_lds_sync();
   // K2
   int collision = 0;
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* _
 #ifdef AUV_STAMPS
     const unsigned long long t_nav0 = wall_clock64();
 #endif
-    k3_nav_env(d, e, lane, (int*)slice, obs_out);
+    k3_nav_env(d, e, lane, slice, obs_out);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 12] = t_nav0, d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k2r_lidar_reward(AuvDev d, float
 }  // namespace
 
 // the nav chunk list must fit the segment stage it borrows
-bool auv_step_fused_ok(const AuvDev& d) { return (size_t)d.nch_max * sizeof(int) <= (size_t)K2_SEG_CAP * 32; }
+bool auv_step_fused_ok(const AuvDev& d) { return NAV_SCRATCH_BYTES(d.nch_max) <= (size_t)K2_SEG_CAP * 32; }
 
 void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st) {
@@ -217,7 +217,7 @@ void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, floa
 }
 
 // the navigation role keeps its chunk list at the start of the wave's slice
-bool auv_k23_ok(const AuvDev& d) { return (size_t)d.nch_max * sizeof(int) <= k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
+bool auv_k23_ok(const AuvDev& d) { return NAV_SCRATCH_BYTES(d.nch_max) <= k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
 
 // Workgroup shape of the side-by-side launch: ONE wave per workgroup, so a wave slot is handed on
 // the moment an environment's sweep ends instead of when the slowest of four does -- the

@@ -130,3 +130,52 @@ def test_more_front_facing_segments_than_the_stage_holds(cull):
     env, ora = _run(_cfg(max_timesteps=1000), [spec], len(poses), steps=12, poses=poses, cull=cull, auto_reset=False)
     d = ora.read("LIDAR_D")
     assert (d[0] < 150).all()          # inside the rings every beam returns
+
+
+def test_cull_limits_at_integer_boundaries():
+    """The cull-window limits are floor / ceil of (pi + bearing -+ f) / dangle (sensor.py:58-69).  The kernel screens
+    them with fp32 atan2f / asinf and falls back to the fp64 chain when a quotient comes within its error budget of
+    an integer: poses constructed so that one quotient sits at an integer +- eps (eps from 1e-13 to 1e-3 of a ray,
+    both signs, both limits, obstacle outside / around the vessel) must give the oracle's integers exactly."""
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    from oracle.pyoracle import Oracle
+    cfg = effective_reference_config(use_lidar=True)
+    S = cfg.vessel.n_sensors
+    dang = 2 * np.pi / S
+    rs = np.random.RandomState(4)
+    specs = []
+    eps_list = [s * e for e in (1e-13, 1e-10, 1e-8, 1e-6, 1e-5, 1e-4, 3e-4, 1e-3, 0.2) for s in (1.0, -1.0)]
+    for which in ("min", "max"):
+        for inside in (False, True):
+            for eps in eps_list:
+                for _ in range(2):
+                    r = rs.uniform(5, 30)
+                    dist = rs.uniform(0.2, 0.9) * r if inside else rs.uniform(1.2, 4.0) * r
+                    ang = rs.uniform(-np.pi, np.pi)
+                    px, py = rs.uniform(-50, 50, 2)
+                    cx, cy = px + dist * np.cos(ang), py + dist * np.sin(ang)
+                    psi = rs.uniform(-3.0, 3.0)
+                    f = np.pi if inside else np.arcsin(r / np.hypot(cx - px, cy - py))
+                    b = np.arctan2(cy - py, cx - px) - psi
+                    x = (np.pi + (b - f)) / dang if which == "min" else (np.pi + (b + f)) / dang
+                    # lowering psi by delta raises x by delta / dang: put x at an integer + eps
+                    psi2 = psi + (x - (np.round(x) + eps)) * dang
+                    if not (-np.pi <= psi2 < np.pi):
+                        continue
+                    specs.append(WorldSpec(waypoints=np.array([[px, px + 500.0], [py, py]]), vessel_init=np.array([px, py, psi2]),
+                                           circles=np.array([[cx, cy, r]]), polygons=[], movers=[], name="lim"))
+    n = len(specs)
+    assert n > 120
+    bank = pack_bank([build_world(s) for s in specs])
+    env = BatchedAuvEnv(cfg, bank, n, device="cuda:0", auto_reset=False)
+    ora = Oracle(make_config(cfg), n, bank)
+    env.reset(), ora.reset()
+    np.testing.assert_array_equal(_np(env.read("CULL_LIMITS")), ora.read("CULL_LIMITS"))
+    np.testing.assert_array_equal(_np(env.read("NEARBY")), ora.read("NEARBY"))
+    np.testing.assert_allclose(_np(env.read("LIDAR_D")), ora.read("LIDAR_D"), rtol=0, atol=1e-9)
+    a = np.zeros((n, 2))
+    a[:, 0] = 1.0
+    for _ in range(5):
+        env.step(torch.as_tensor(a, device="cuda:0")), ora.step(a)
+        np.testing.assert_array_equal(_np(env.read("CULL_LIMITS")), ora.read("CULL_LIMITS"))
+    env.close()

@@ -7,11 +7,11 @@ from gym_auv_amd.config import effective_reference_config
 from gym_auv_amd.world import build_bank_parallel
 cfg = effective_reference_config(use_lidar=True)
 n = 4096
-z = np.load("/tmp/bank.polygons50.0.4096.npz"); bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
+z = np.load("/tmp/bank.polygons50.0.4096.4096.2.npz"); bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
 env = BatchedAuvEnv(cfg, bank, n, auto_reset=True)
 env.reset()
 a = torch.rand((n, 2), device="cuda:0") * 2 - 1
-for i in range(30): env.step(a)
+for i in range(int(os.environ.get("STEPS", "30"))): env.step(torch.rand((n, 2), device="cuda:0") * torch.tensor([2.0, 0.3], device="cuda:0") - torch.tensor([1.0, 0.15], device="cuda:0"))
 torch.cuda.synchronize()
 st = env.read("STAMPS").cpu().numpy().astype(np.float64)
 names = ["K2.front", "K2.pairs", "K2.back", "-", "-", "K2 active segs", "K2 work items", "K2.pairs stage",

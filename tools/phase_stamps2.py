@@ -6,7 +6,7 @@ from gym_auv_amd.batched_env import BatchedAuvEnv
 from gym_auv_amd.config import effective_reference_config
 cfg = effective_reference_config(use_lidar=True)
 n = 4096
-z = np.load("/tmp/bank.polygons50.0.4096.npz"); bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
+z = np.load("/tmp/bank.polygons50.0.4096.4096.2.npz"); bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
 env = BatchedAuvEnv(cfg, bank, n, auto_reset=True)
 env.set_step_mode(os.environ.get("MODE", "two_kernels"))
 env.reset()
