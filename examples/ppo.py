@@ -42,7 +42,8 @@ class ActorCritic(nn.Module):
         return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
 
 
-def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=5):
+def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=5, log_every=1,
+          task="colav"):
     from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
@@ -50,13 +51,17 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     from gym_auv_amd.world import build_bank_parallel
     rank, world = D.rank(), D.world_size()
     torch.manual_seed(seed + rank)
-    cfg = effective_reference_config(use_lidar=True)
+    # task "colav": MovingObstaclesNoRules-v0 (17 moving + 11 static obstacles, LiDAR on, ColavRewarder);
+    # task "pathfollow": PathFollowNoObstacles-v0 (no obstacles, LiDAR off, PathFollowRewarder) -- gym_auv/__init__.py:105-121
+    colav = task == "colav"
+    cfg = effective_reference_config(use_lidar=colav)
+    nm, ns = (17, 11) if colav else (0, 0)
     if worlds == "generated":
-        bank = GeneratedWorlds(n_worlds=envs, seed=1000 * seed + rank)
+        bank = GeneratedWorlds(envs, nm, ns, seed=1000 * seed + rank)
     else:
         bank = build_bank_parallel("moving_obstacles_world", range(5000 + 512 * rank, 5000 + 512 * rank + min(envs, 512)),
-                                   procs=min(8, os.cpu_count() or 1))
-    env = BatchedAuvEnv(cfg, bank, envs, device=device, auto_reset=True)
+                                   procs=min(8, os.cpu_count() or 1), **({} if colav else dict(n_moving=0, n_static=0)))
+    env = BatchedAuvEnv(cfg, bank, envs, device=device, auto_reset=True, rewarder="colav" if colav else "pathfollow")
     low = torch.as_tensor(env.action_space.low, device=device)
     high = torch.as_tensor(env.action_space.high, device=device)
     net = ActorCritic(env.obs_dim).to(device)
@@ -68,9 +73,9 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     obs = env.reset().clone()
     history = []
     for upd in range(updates):
-        if worlds == "generated" and upd and upd % regen == 0:
+        if worlds == "generated" and regen > 0 and upd and upd % regen == 0:
             # fresh scenarios for every environment, built on the device; all envs restart
-            env.generate(GeneratedWorlds(n_worlds=envs, seed=1000 * seed + rank + 7919 * upd))
+            env.generate(GeneratedWorlds(envs, nm, ns, seed=1000 * seed + rank + 7919 * upd))
             obs = env.reset().clone()
         t0 = time.time()
         O, A, LP, R, Dn, V = [], [], [], [], [], []
@@ -115,10 +120,14 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
         torch.cuda.synchronize()
         mean_r = float(torch.stack(R).mean().item()) / 0.01
         sps = world * envs * rollout / (time.time() - t0)
-        history.append((mean_r, float(loss.item()), sps))
-        if rank == 0:
-            log("update %3d  mean step reward %8.3f  loss %8.4f  rollout %.2e env-steps/s (policy in the loop), "
-                "%.2e env-steps/s incl. learning" % (upd, mean_r, loss.item(), world * envs * rollout / t_roll, sps))
+        # what the policy does, read off the observations of the rollout (vessel.py:24-35: surge, sway, yaw
+        # rate, look-ahead heading error, heading error, cross-track error / 100)
+        surge, he, cte = float(O[:, 0].mean()), float(O[:, 4].abs().mean()), float(O[:, 5].abs().mean()) * 100
+        history.append((mean_r, float(loss.item()), sps, surge, he, cte))
+        if rank == 0 and (upd % log_every == 0 or upd == updates - 1):
+            log("update %3d  mean step reward %8.3f  surge %.3f m/s  |heading error| %.2f rad  |cross-track| %6.1f m  loss %8.4f  "
+                "rollout %.2e env-steps/s (policy in the loop), %.2e incl. learning"
+                % (upd, mean_r, surge, he, cte, loss.item(), world * envs * rollout / t_roll, sps))
     # the one collective of the environment side: finished-episode statistics of all ranks
     stats = D.gather_episode_stats(env.episode_stats())
     if rank == 0:
@@ -127,6 +136,11 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             int(stats["episodes"].sum()), float(stats["episode_return"][fin].mean()) if fin.any() else float("nan"),
             float(stats["collision"][fin].mean()) if fin.any() else float("nan"),
             float(stats["reached_goal"][fin].mean()) if fin.any() else float("nan")))
+        k = max(1, min(10, len(history) // 4))
+        first, last = history[:k], history[-k:]
+        log("learning: mean step reward %.3f -> %.3f, surge %.3f -> %.3f m/s, |heading error| %.2f -> %.2f rad (first / last %d updates)"
+            % (sum(h[0] for h in first) / k, sum(h[0] for h in last) / k, sum(h[3] for h in first) / k, sum(h[3] for h in last) / k,
+               sum(h[4] for h in first) / k, sum(h[4] for h in last) / k, k))
     env.close()
     return history
 
@@ -138,7 +152,9 @@ if __name__ == "__main__":
     ap.add_argument("--rollout", type=int, default=32)
     ap.add_argument("--worlds", default="generated", choices=["generated", "host"])
     ap.add_argument("--regen", type=int, default=5, help="regenerate the world bank on the device every this many updates")
+    ap.add_argument("--log-every", type=int, default=1)
+    ap.add_argument("--task", default="colav", choices=["colav", "pathfollow"])
     a = ap.parse_args()
     from gym_auv_amd import distributed as D
     _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
-    train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, worlds=a.worlds, regen=a.regen)
+    train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, worlds=a.worlds, regen=a.regen, log_every=a.log_every, task=a.task)
