@@ -640,7 +640,8 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
 #define NAV_WIN_BYTES (3 * 20 * 8)
 #define NAV_SCRATCH_BYTES(nch_max) ((NAV_WIN_BYTES + (size_t)(nch_max) * sizeof(int) + 15) & ~(size_t)15)
 __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const int lane, unsigned char* scratch,
-                                           float* __restrict__ obs_out, const EnvPre* pre = nullptr) {
+                                           float* __restrict__ obs_out, const EnvPre* pre = nullptr,
+                                           const double2* pose_cs = nullptr) {
   double* wins = (double*)scratch;
   int* list = (int*)(scratch + NAV_WIN_BYTES);
   const size_t n = (size_t)d.n;
@@ -649,7 +650,7 @@ __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const i
   (void)wins;
   const NavSpec sp = nav_speculate(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
                                    0.0, nullptr);
-  nav_finish(d, e, lane, list, obs_out, pre, sp, true, nullptr, nullptr);
+  nav_finish(d, e, lane, list, obs_out, pre, sp, true, nullptr, pose_cs ? pose_cs + e : nullptr);
 }
 
 // ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----

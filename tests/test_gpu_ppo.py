@@ -28,4 +28,4 @@ def test_ppo_learns_path_following():
     mean = lambda rows, i: sum(r[i] for r in rows) / len(rows)   # noqa: E731
     assert mean(last, 3) > mean(first, 3) + 0.12, (mean(first, 3), mean(last, 3))     # surge speed: it learnt to use the thruster
     assert mean(last, 4) < mean(first, 4) - 0.15, (mean(first, 4), mean(last, 4))     # |heading error|: ... and the rudder
-    assert mean(last, 0) > mean(first, 0) + 0.2, (mean(first, 0), mean(last, 0))      # the reward says so too
+    assert mean(last, 0) > hist[0][0] + 0.3, (hist[0][0], mean(last, 0))              # the step reward against the untrained policy's

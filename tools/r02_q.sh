@@ -1,0 +1,10 @@
+#!/bin/bash
+set -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+O=gpurun_out/${TAG:-r02_q}; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
+for a in "" "" "--steps 20 --warmup 5" "--workload mixed47 --envs 8192"; do
+python bench.py --bank-cache /tmp/bank --cpu-baseline 0 $a 2>/dev/null | python -c "
+import json,sys; b=json.loads(sys.stdin.read()); print('$a', b['value'], b['ms_per_step'], b['config']['episodes_finished'], {k:v['avg_ms'] for k,v in b['roofline']['kernels'].items()})"
+done
