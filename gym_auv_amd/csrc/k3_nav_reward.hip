@@ -371,6 +371,7 @@ struct NavSpec {
   bool in_regs;                      // n_list <= NAV_SPEC: their segments are in A / B / cum below
   double2 A[NAV_SPEC], B[NAV_SPEC];  // this lane's segment of speculative chunk q
   double cum[NAV_SPEC];              // cumulative arclength at its first vertex
+  double dist[NAV_SPEC];             // exact distance of the guess q to that segment where it was already formed (else < 0)
 };
 
 // win_slots: LDS, [3][20] doubles of this wave, or nullptr: the spline windows around last step's arclength
@@ -393,7 +394,7 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
   int n_act = 0;
   int cstar = -1;                                  // the chunk whose segments sA / sB / scum hold (register-resident route)
   double2 sA = make_double2(0.0, 0.0), sB = sA;
-  double scum = 0.0;
+  double scum = 0.0, sdist = -1.0;
   if (nch <= NAV_CPL * AUV_WAVE) {
     double4 b[NAV_CPL];
     double cdist[NAV_CPL];
@@ -425,6 +426,7 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
     {
       double dd = 1.7976931348623157e308;
       if (jhl < P - 1) dd = auv_pt_seg_dist(qx, qy, sA.x, sA.y, sB.x, sB.y);
+      sdist = dd;
       U = auv_wave_min(fmin(U, dd)) + slack;
     }
 #pragma unroll
@@ -462,9 +464,10 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
   for (int q = 0; q < NAV_SPEC; q++) {
     sp.A[q] = sp.B[q] = make_double2(0.0, 0.0);
     sp.cum[q] = 0.0;
+    sp.dist[q] = -1.0;
     if (sp.in_regs && q < n_act) {
       if (list[q] == cstar) {                      // (uniform) already fetched for the upper bound
-        sp.A[q] = sA, sp.B[q] = sB, sp.cum[q] = scum;
+        sp.A[q] = sA, sp.B[q] = sB, sp.cum[q] = scum, sp.dist[q] = sdist;
       } else {
         const int j = list[q] * AUV_CHUNK + lane;
         const int jj = j < P - 1 ? j : 0;
@@ -500,6 +503,7 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
     usable = (mx * mx + my * my) <= NAV_DELTA * NAV_DELTA;   // (NaN compares false)
   }
   if (!usable) sp = nav_speculate(d, e, lane, list, px, py, 0.0, nullptr);   // (parked spline windows stay valid: they do not depend on the pose)
+  const bool same_pose = (px == sp.qx) && (py == sp.qy);
   const EnvDesc ed = sp.ed;
   const double L = sp.L;
   double* inf = d.info64 + 8 * (size_t)e;
@@ -532,7 +536,9 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
       if (q < n_act) {
         const int j = list[q] * AUV_CHUNK + lane;
         if (j < P - 1) {
-          const double dd = auv_pt_seg_dist(px, py, sp.A[q].x, sp.A[q].y, sp.B[q].x, sp.B[q].y);
+          // (the very same distance was formed for the upper bound when the guess IS the pose)
+          const double dd = (same_pose && sp.dist[q] >= 0.0) ? sp.dist[q]
+                                                             : auv_pt_seg_dist(px, py, sp.A[q].x, sp.A[q].y, sp.B[q].x, sp.B[q].y);
           if (dd < best.d) best.d = dd, best.j = j, bA = sp.A[q], bB = sp.B[q], my_cum = sp.cum[q];   // ascending j: strict '<' keeps the first minimum
         }
       }
@@ -555,12 +561,21 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
     // cumulative length at this lane's candidate, requested while the reduction runs
     my_cum = d.poly_cum[p0 + (best.j < P - 1 ? best.j : 0)];
   }
-  const int my_j = best.j;
-  best = wave_min_first(best);
+  // (distance, first index) minimum over the wave: the smallest distance first; among the lanes that hold it
+  // (almost always one; a shared vertex gives two) the smallest segment index -- "first minimum wins"
+  const double dmin = auv_wave_min(best.d);
+  unsigned long long wmask = __ballot(best.d == dmin);
+  if (__popcll(wmask) > 1) {
+    int jm = (best.d == dmin) ? best.j : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int t = __shfl_xor(jm, o, AUV_WAVE);
+      jm = t < jm ? t : jm;
+    }
+    wmask = __ballot(best.d == dmin && best.j == jm);
+  }
   AUV_STAMP()
-  const int bj = best.j;
   // the winning lane hands over its segment (no second trip to memory)
-  const unsigned long long wmask = __ballot(my_j == bj);
   const int src = wmask ? __ffsll((long long)wmask) - 1 : 0;
   double2 A, B;
   A.x = __shfl(bA.x, src, AUV_WAVE), A.y = __shfl(bA.y, src, AUV_WAVE);
