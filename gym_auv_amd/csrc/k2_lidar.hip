@@ -89,8 +89,12 @@ struct MoverSegs {
   }
 };
 
+#ifndef K2_SEG_CAP
 #define K2_SEG_CAP 96    // staged segments per wave and batch (slice <= 10 KiB -> 16 waves per CU)
+#endif
+#ifndef K2_RAW_CAP
 #define K2_RAW_CAP 192   // boundary segments looked at per batch; only the front-facing ones are staged
+#endif
 #define K2_ITEM_RAYS 8    // rays per work item of the pair sweep
 
 // per-wave LDS slice (decreasing alignment):

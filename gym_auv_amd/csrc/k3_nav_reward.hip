@@ -673,6 +673,71 @@ __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const i
 // from_buffers: form the two reward terms here from NAV64 / INFO64 / LIDAR_D as they stand (the
 //               per-function test hook) instead of taking what K2 / the navigation phase left
 // lidar_obs:    emit the float32 closeness columns (false when K2 has already written them)
+// One environment's reward / done / bookkeeping (rewarder.py:78-140, :167-241; environment.py:333-347, :375-384),
+// scalar: by lane 0 of the environment's wave, or by the environment's lane of k3_reward_lanes.  The LiDAR term
+// was formed by K2 (rew_lidar), the path-following term by the navigation phase (rew_path); here they are only
+// combined.  `cnt` in/out; returns whether the environment is to be auto-reset.
+__device__ __forceinline__ int reward_block(const AuvDev& d, const int e, const int collision, int4& cnt,
+                                            const bool from_buffers, const double lidar_term, const double* rew_lidar_pre,
+                                            float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
+                                            const bool advance_ring) {
+  double* inf = d.info64 + 8 * (size_t)e;
+  const double* nv = d.nav64 + 8 * (size_t)e;
+  const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
+  const double lambda = 0.5, eta = 0.0, penalty_yawrate = 10.0, neutral_speed = 0.05, max_speed = 2.0;
+  // everything the block reads is requested up front (one trip to memory, whatever branch follows)
+  const double2 uv = ((const double2*)nv)[0];           // rows are 64-byte records: 16-byte accesses
+  const double u = uv.x, v = uv.y, yaw_rate = nv[2];
+  // (the LiDAR term arrives in a register when the sweep ran in this very wave)
+  const double rew_path_in = d.rew_path[e], rew_lidar_in = rew_lidar_pre ? *rew_lidar_pre : d.rew_lidar[e];
+  const double2 gp = ((const double2*)inf)[1];
+  const double cum_in = inf[4], reached_in = inf[1], goal_in = gp.x, progress_in = gp.y;
+  double reward;
+  if (collision) {
+    reward = -10000.0 * (1 - lambda);
+  } else {
+    const double speed = sqrt(u * u + v * v);
+    const double path_reward = from_buffers ? reward_path_term(d, u, v, nv[4], nv[5], inf[3], inf[5]) : rew_path_in;
+    const double living_penalty = lambda * (2 * neutral_speed + 1) + eta * neutral_speed;
+    if (!colav) {
+      double slow_penalty = (speed < 0.1) ? -2 : 0;
+      reward = path_reward - living_penalty + eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) +
+               slow_penalty;
+    } else {
+      const double closeness_reward = (from_buffers || !d.cfg.use_lidar) ? lidar_term : rew_lidar_in;
+      double slow_penalty = (speed < 0.04) ? -2 : 0;
+      reward = lambda * path_reward + (1 - lambda) * closeness_reward - living_penalty +
+               eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) + slow_penalty;
+      if (reward < 0) reward *= 2.0;
+    }
+  }
+  // ---- environment.py:333-347, :375-384 ----
+  d.reward64[e] = reward;
+  double cum = cum_in + reward;
+  inf[4] = cum;
+  const int t_step = cnt.x;
+  const int done = collision || (reached_in != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
+                   (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);
+  cnt.x = t_step + 1;
+  {
+    double2* si = (double2*)(d.step_info + 4 * (size_t)e);   // environment.py:336-340
+    si[0] = make_double2(collision, reached_in), si[1] = make_double2(goal_in, progress_in);
+  }
+  if (reward_out) reward_out[e] = (float)reward;
+  if (done_out) done_out[e] = (uint8_t)done;
+  if (done) {
+    double2* ep = (double2*)(d.episode + 4 * (size_t)e);
+    ep[0] = make_double2(cum, t_step + 1), ep[1] = make_double2(collision, reached_in);
+    cnt.z += 1;
+  }
+  const int do_reset = done && d.cfg.auto_reset;
+  if (!do_reset) d.counters[e] = cnt;
+  // next action slot (the single-kernel step advances the ring from the host or a follow-up node:
+  // other waves of that kernel may still be reading the position)
+  if (e == 0 && d.ring_slots > 1 && d.ring_slot_host < 0 && advance_ring) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
+  return do_reset;
+}
+
 __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, const bool full,
                               float* __restrict__ obs_out, float* __restrict__ reward_out,
                               uint8_t* __restrict__ done_out, const EnvPre* pre = nullptr, const int collision_pre = -1,
@@ -682,73 +747,18 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
   int4 cnt = pre ? pre->cnt : d.counters[e];
   const int w = d.world_idx[e];
   double* inf = d.info64 + 8 * (size_t)e;
-  const double* nv = d.nav64 + 8 * (size_t)e;
   const double* ob = d.obs64 + (size_t)e * (6 + S);
   const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
   const int DL = 6 + (d.cfg.use_lidar ? S : 0);                                        // columns this path writes
   const int collision = collision_pre >= 0 ? collision_pre : d.collision[e];
   if (lane == 0) inf[0] = collision;
   if (full) {
-    // ---- reward (rewarder.py:78-140, :167-241): the LiDAR term was formed by K2 (rew_lidar), the
-    // path-following term by the navigation phase (rew_path); here they are only combined ----
     const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
     // without a LiDAR sweep the ranges rest at sensor_range and K2 leaves no term: form it here
     double lidar_term = 0.0;
     if (colav && (from_buffers || !d.cfg.use_lidar)) lidar_term = reward_lidar_term_wave(d, d.lidar_d + (size_t)e * S, lane);
     int do_reset = 0;
-    if (lane == 0) {
-      const double lambda = 0.5, eta = 0.0, penalty_yawrate = 10.0, neutral_speed = 0.05, max_speed = 2.0;
-      // everything the block reads is requested up front (one trip to memory, whatever branch follows)
-      const double2 uv = ((const double2*)nv)[0];           // rows are 64-byte records: 16-byte accesses
-      const double u = uv.x, v = uv.y, yaw_rate = nv[2];
-      // (the LiDAR term arrives in a register when the sweep ran in this very wave)
-      const double rew_path_in = d.rew_path[e], rew_lidar_in = rew_lidar_pre ? *rew_lidar_pre : d.rew_lidar[e];
-      const double2 gp = ((const double2*)inf)[1];
-      const double cum_in = inf[4], reached_in = inf[1], goal_in = gp.x, progress_in = gp.y;
-      double reward;
-      if (collision) {
-        reward = -10000.0 * (1 - lambda);
-      } else {
-        const double speed = sqrt(u * u + v * v);
-        const double path_reward = from_buffers ? reward_path_term(d, u, v, nv[4], nv[5], inf[3], inf[5]) : rew_path_in;
-        const double living_penalty = lambda * (2 * neutral_speed + 1) + eta * neutral_speed;
-        if (!colav) {
-          double slow_penalty = (speed < 0.1) ? -2 : 0;
-          reward = path_reward - living_penalty + eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) +
-                   slow_penalty;
-        } else {
-          const double closeness_reward = (from_buffers || !d.cfg.use_lidar) ? lidar_term : rew_lidar_in;
-          double slow_penalty = (speed < 0.04) ? -2 : 0;
-          reward = lambda * path_reward + (1 - lambda) * closeness_reward - living_penalty +
-                   eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) + slow_penalty;
-          if (reward < 0) reward *= 2.0;
-        }
-      }
-      // ---- environment.py:333-347, :375-384 ----
-      d.reward64[e] = reward;
-      double cum = cum_in + reward;
-      inf[4] = cum;
-      const int t_step = cnt.x;
-      const int done = collision || (reached_in != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
-                       (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);
-      cnt.x = t_step + 1;
-      {
-        double2* si = (double2*)(d.step_info + 4 * (size_t)e);   // environment.py:336-340
-        si[0] = make_double2(collision, reached_in), si[1] = make_double2(goal_in, progress_in);
-      }
-      if (reward_out) reward_out[e] = (float)reward;
-      if (done_out) done_out[e] = (uint8_t)done;
-      if (done) {
-        double2* ep = (double2*)(d.episode + 4 * (size_t)e);
-        ep[0] = make_double2(cum, t_step + 1), ep[1] = make_double2(collision, reached_in);
-        cnt.z += 1;
-      }
-      do_reset = done && d.cfg.auto_reset;
-      if (!do_reset) d.counters[e] = cnt;
-      // next action slot (the single-kernel step advances the ring from the host or a follow-up node:
-      // other waves of that kernel may still be reading the position)
-      if (e == 0 && d.ring_slots > 1 && d.ring_slot_host < 0 && pre == nullptr) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
-    }
+    if (lane == 0) do_reset = reward_block(d, e, collision, cnt, from_buffers, lidar_term, rew_lidar_pre, reward_out, done_out, pre == nullptr);
     do_reset = __shfl(do_reset, 0, AUV_WAVE);
     if (do_reset) {
       // VecEnv auto-reset: rebind to the next world of the bank and copy its reset rows
@@ -792,6 +802,34 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_reward(AuvDev d, float* __restri
   const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
   k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, nullptr, -1, false, lidar_obs != 0);
+}
+
+// The same for the step path when the LiDAR launch has already written the float32 closeness columns: lanes <->
+// environments (64 per wave instead of one), so the launch is 64x fewer waves -- at 8192 environments the
+// one-wave-per-environment form no longer fits the chip in one round.  Environments that ended are then
+// restored by the whole wave, one after the other (a handful per step in the whole batch).
+__global__ void __launch_bounds__(AUV_WAVE) k3_reward_lanes(AuvDev d, float* __restrict__ obs_out,
+                                                            float* __restrict__ reward_out,
+                                                            uint8_t* __restrict__ done_out) {
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x * AUV_WAVE + lane;
+  int do_reset = 0, w = 0;
+  int4 cnt = make_int4(0, 0, 0, 0);
+  if (e < d.n) {
+    cnt = d.counters[e];
+    w = d.world_idx[e];
+    const int collision = d.collision[e];
+    d.info64[8 * (size_t)e] = collision;
+    do_reset = reward_block(d, e, collision, cnt, false, 0.0, nullptr, reward_out, done_out, true);
+  }
+  unsigned long long m = __ballot(do_reset);
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int er = auv_uniform(__shfl(e, src, AUV_WAVE));
+    const int wr = __shfl(w, src, AUV_WAVE), ep = __shfl(cnt.z, src, AUV_WAVE);
+    restore_env(d, er, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
+  }
 }
 
 // reset pass: first observation of the environments on the fresh list
@@ -859,7 +897,10 @@ void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st) {
 // lidar_obs = 0: the LiDAR launch before it has written the float32 closeness columns itself
 void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st,
                           hipEvent_t ev0, hipEvent_t ev1) {
-  hipExtLaunchKernelGGL(k3_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, ev0, ev1, 0, d, obs, reward, done, lidar_obs);
+  if (d.cfg.use_lidar && !lidar_obs)   // the step path behind a LiDAR launch that wrote the float32 closeness itself
+    hipExtLaunchKernelGGL(k3_reward_lanes, dim3((d.n + AUV_WAVE - 1) / AUV_WAVE), dim3(AUV_WAVE), 0, st, ev0, ev1, 0, d, obs, reward, done);
+  else
+    hipExtLaunchKernelGGL(k3_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, ev0, ev1, 0, d, obs, reward, done, lidar_obs);
 }
 
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st) {

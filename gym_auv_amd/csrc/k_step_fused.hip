@@ -17,6 +17,10 @@
 #include "k2_lidar.hip"
 #include "k3_nav_reward.hip"
 
+#ifndef AUV_K23_MIN_WAVES
+#define AUV_K23_MIN_WAVES 4   // waves per SIMD the LiDAR launches are compiled for (128 VGPRs)
+#endif
+
 namespace {
 
 template <typename AT>
@@ -50,7 +54,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
 // new vessel state, so they run side by side (the LiDAR workgroups are dispatched first and fill
 // the chip; navigation workgroups move in as those retire) -- the concurrency of two streams
 // without the ~8 us a cross-stream event wait costs on each side.
-__global__ void __launch_bounds__(AUV_BLOCK, 4) k23_lidar_nav(AuvDev d, float* __restrict__ obs_out) {
+__global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(AuvDev d, float* __restrict__ obs_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int S = d.cfg.n_sensors;
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(K1N_THREADS, 5) k1n_dyn_nav(AuvDev d, const AT
 #endif
 }
 
-__global__ void __launch_bounds__(AUV_BLOCK, 4) k2r_lidar_reward(AuvDev d, float* __restrict__ obs_out,
+__global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k2r_lidar_reward(AuvDev d, float* __restrict__ obs_out,
                                                                  float* __restrict__ reward_out,
                                                                  uint8_t* __restrict__ done_out) {
   extern __shared__ __align__(16) unsigned char smem[];

@@ -1,0 +1,9 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+python bench.py --bank-cache /tmp/bank --steps 20 --cpu-baseline 0 > /dev/null 2>&1
+for rep in 1 2; do
+for v in csrc csrc_cap64 csrc_w5; do
+AUV_HIP_LIB=gym_auv_amd/$v/libauv_hip.so python bench.py --bank-cache /tmp/bank --cpu-baseline 0 2>/dev/null | python -c "
+import json,sys; b=json.loads(sys.stdin.read()); print('$v', b['value'], b['ms_per_step'], {k:v['avg_ms'] for k,v in b['roofline']['kernels'].items()})"
+done; done
