@@ -68,6 +68,13 @@ class BatchedAuvEnv:
             bs, keep = make_bank_struct(bank)
             _check(_LIB.auv_load_worlds(self._h, C.byref(bs)), "auv_load_worlds")
             del keep
+        if auto_reset and self.n_worlds <= self.n_envs:
+            # auto-reset rebinds env e to world (w + n_envs) % n_worlds: with no more worlds than envs that is the
+            # world it has just finished (the reference draws a new scenario on every reset, movingobstacles.py:28-95)
+            import warnings
+            warnings.warn("BatchedAuvEnv: %d worlds for %d auto-resetting envs -- a finished episode restarts in the SAME world; "
+                          "give the bank at least 2 worlds per env (or regenerate it with env.generate()) for new scenarios"
+                          % (self.n_worlds, self.n_envs), stacklevel=2)
         # observation_space / action_space exactly as environment.py:101-106, :139-143
         self.action_space = Box(low=np.array([-1, -0.15]), high=np.array([1, 0.15]), dtype=np.float32)
         self.observation_space = Box(low=np.array([-1] * self.obs_dim), high=np.array([1] * self.obs_dim),
