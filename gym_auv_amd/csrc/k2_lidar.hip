@@ -55,6 +55,7 @@ struct ObsLds {        // per-obstacle scratch in LDS (24 B)
 
 struct EnvHdr {        // head of each wave's LDS slice: what the pair sweep needs to know
   double px, py;
+  double cpsi, spsi;   // cos / sin of the heading, parked here between their (early) evaluation and phase C
   int n_act;           // obstacles with a non-empty ray window
   int pad[3];
 };
@@ -218,6 +219,49 @@ __device__ __forceinline__ int inside_flag_wave(double px, double py, SegPtr g, 
   return (on_any ? 2 : 0) | (cross & 1);
 }
 
+// ---- phase C: ray vectors, vessel.py:66-68, :317 (only if some obstacle has rays to test) ----
+// cos / sin of (beam angle + psi) by the addition theorem from the per-config table of beam
+// angles (built at load time): one sincos per environment instead of one per ray
+__device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const Slice& L) {
+  const int S = d.cfg.n_sensors;
+  const double R = d.cfg.sensor_range;
+  const double px = L.hdr->px, py = L.hdr->py;
+  double sin_psi, cos_psi;
+  if (S <= 4 * AUV_WAVE) {
+    // the usual shapes: all passes' table entries are requested before the sincos, so the passes
+    // do not each wait for their own trip to memory
+    double2 b[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = q * AUV_WAVE + lane;
+      b[q] = d.beam_cs[i < S ? i : 0];                      // cos, sin of -pi + (i + 1) * dangle
+    }
+    cos_psi = L.hdr->cpsi, sin_psi = L.hdr->spsi;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (q * AUV_WAVE >= S) break;                         // (uniform: 180 beams are three passes)
+      const int i = q * AUV_WAVE + lane;
+      if (i < S) {
+        const double c = cos_psi * b[q].x - sin_psi * b[q].y, s = sin_psi * b[q].x + cos_psi * b[q].y;
+        // end point minus origin, formed exactly as the reference forms the end point
+        double ex = px + c * R, ey = py + s * R;
+        L.rayv[i] = make_double2(ex - px, ey - py);
+        L.dbits[i] = d2u(2.0);   // no hit yet (hits have t in [0, 1])
+      }
+    }
+  } else {
+    cos_psi = L.hdr->cpsi, sin_psi = L.hdr->spsi;
+    for (int i = lane; i < S; i += AUV_WAVE) {
+      const double2 b = d.beam_cs[i];
+      const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
+      double ex = px + c * R, ey = py + s * R;
+      L.rayv[i] = make_double2(ex - px, ey - py);
+      L.dbits[i] = d2u(2.0);
+    }
+  }
+  auv_wave_lds_sync();
+}
+
 // phases A, C, B, S for one environment, by one wave
 // cs_pre: cos / sin of the heading when the dynamics kernel of this step has left them (pose_cs);
 // nullptr = form them here (same function, same argument: the same bits)
@@ -229,8 +273,20 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
                psi = pre ? pre->s[2] : d.state[2 * n + e];
   const EnvDesc ed = d.env_desc[e];
-  double2 cs_in = make_double2(0.0, 0.0);
-  if (cs_pre) cs_in = cs_pre[e];
+  // cos / sin of the heading for the ray table (phase C): formed right here, as soon as psi is known, so that
+  // the ~100 dependent fp64 instructions are off the chain that follows phase B (the obstacle records were also
+  // requested ahead of it once: 11 more live registers, 10 spilled, and the gain was gone)
+  {
+    double2 cs_in;
+    if (cs_pre) {
+      cs_in = cs_pre[e];
+    } else {
+      double sn, co;
+      sincos(psi, &sn, &co);
+      cs_in = make_double2(co, sn);
+    }
+    if (lane == 0) L.hdr->cpsi = cs_in.x, L.hdr->spsi = cs_in.y;   // (read back after the LDS sync that ends phase B)
+  }
   const long long k0 = ed.k0;
   const int K = ed.K;
   const long long m0 = ed.m0;
@@ -521,45 +577,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     if (lane == 0) L.sbase[0] = 0;
   }
   if (n_act == 0) return 0;                                  // nothing in sight: no rays, no sweep (k2_back writes the free row)
-  // ---- phase C: ray vectors, vessel.py:66-68, :317 (only if some obstacle has rays to test) ----
-  // cos / sin of (beam angle + psi) by the addition theorem from the per-config table of beam
-  // angles (built at load time): one sincos per environment instead of one per ray
-  double sin_psi, cos_psi;
-  if (S <= 4 * AUV_WAVE) {
-    // the usual shapes: all passes' table entries are requested before the sincos, so the passes
-    // do not each wait for their own trip to memory
-    double2 b[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int i = q * AUV_WAVE + lane;
-      b[q] = d.beam_cs[i < S ? i : 0];                      // cos, sin of -pi + (i + 1) * dangle
-    }
-    if (cs_pre) cos_psi = cs_in.x, sin_psi = cs_in.y;
-    else sincos(psi, &sin_psi, &cos_psi);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      if (q * AUV_WAVE >= S) break;                         // (uniform: 180 beams are three passes)
-      const int i = q * AUV_WAVE + lane;
-      if (i < S) {
-        const double c = cos_psi * b[q].x - sin_psi * b[q].y, s = sin_psi * b[q].x + cos_psi * b[q].y;
-        // end point minus origin, formed exactly as the reference forms the end point
-        double ex = px + c * R, ey = py + s * R;
-        L.rayv[i] = make_double2(ex - px, ey - py);
-        L.dbits[i] = d2u(2.0);   // no hit yet (hits have t in [0, 1])
-      }
-    }
-  } else {
-    if (cs_pre) cos_psi = cs_in.x, sin_psi = cs_in.y;
-    else sincos(psi, &sin_psi, &cos_psi);
-    for (int i = lane; i < S; i += AUV_WAVE) {
-      const double2 b = d.beam_cs[i];
-      const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
-      double ex = px + c * R, ey = py + s * R;
-      L.rayv[i] = make_double2(ex - px, ey - py);
-      L.dbits[i] = d2u(2.0);
-    }
-  }
-  auv_wave_lds_sync();
+  k2_rays(d, lane, L);                                       // phase C
   return n_act;
 }
 
