@@ -175,7 +175,9 @@ def spawn_ranks(args):
     if failed:
         sys.stderr.write("bench.py: rank(s) failed: %s\n" % failed)
         return 1
-    sys.stdout.write("".join(outs) if args.dry_run else outs[0])
+    # relay the JSON line(s) only (gloo / RCCL may chat on a rank's stdout)
+    lines = [l for o in (outs if args.dry_run else outs[:1]) for l in o.splitlines() if l.startswith("{")]
+    sys.stdout.write("\n".join(lines) + "\n")
     sys.stdout.flush()
     return 0
 

@@ -15,7 +15,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(run, "bench_*.json")) + [os.path.join(run, n) for n in (
-        "kernel_trace_summary.txt", "kernel_stats.csv", "pmc_summary.json", "pmc_sq_summary.json", "pmc_sq_kernel_durations.txt")]:
+        "kernel_trace_summary.txt", "kernel_stats.csv", "pmc_summary.json", "pmc_sq_summary.json", "pmc_sq_kernel_durations.txt",
+        "bench_2ranks_refused.out")]:
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, dst)
 clean = lambda k: k.split("<")[0]   # noqa: E731

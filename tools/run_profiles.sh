@@ -25,6 +25,9 @@ $B --workload mixed47 --envs 8192 --graph 16 --cpu-baseline 0 > $OUT/bench_mixed
 $B --workload mixed47 --envs 8192 --cpu-baseline 0 > $OUT/bench_mixed47_8192_b.json 2>/dev/null
 $B --workload mixed47 --envs 8192 --graph 16 --cpu-baseline 0 > $OUT/bench_mixed47_8192_graph16_b.json 2>/dev/null
 $B --envs 32768 --steps 100 --warmup 20 --worlds-per-env 1 --cpu-baseline 0 > $OUT/bench_polygons50_32768.json 2>/dev/null
+# two ranks started by bench.py itself, sharing the one GPU of this box (gloo instead of RCCL): the N > 1 code path on hardware
+python bench.py --gpus 2 --rehearse 1 --steps 500 --warmup 100 --bank-cache /tmp/bank --cpu-baseline 0 > $OUT/bench_2ranks_rehearsal_1gpu.json 2> $OUT/bench_2ranks_rehearsal_1gpu.err
+python bench.py --gpus 2 --steps 10 > $OUT/bench_2ranks_refused.out 2>&1; echo "exit code $? (two ranks without --rehearse on a 1-GPU box must be refused)" >> $OUT/bench_2ranks_refused.out
 echo "benches done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --bank-cache /tmp/bank --cpu-baseline 0 > $OUT/bench_under_rocprof.json 2>/dev/null
