@@ -15,3 +15,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_collection_modifyitems(config, items):
+    # small world banks are the rule in tests: the "no more worlds than auto-resetting envs" hint is noise there
+    for it in items:
+        it.add_marker(pytest.mark.filterwarnings("ignore:BatchedAuvEnv.*auto-resetting envs"))
