@@ -155,23 +155,33 @@ def spawn_ranks(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    import tempfile
+    procs, files = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if args.rehearse and ndev < n:
             env.setdefault("AUV_DIST_BACKEND", "gloo")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE, text=True))
-    outs, failed = [], []
-    for r, p in enumerate(procs):
-        out, _ = p.communicate()
-        outs.append(out)
-        if p.returncode != 0:
-            failed.append((r, p.returncode))
-            for q in procs:                       # a dead rank leaves the others in a collective: end exactly those
-                if q.poll() is None:
-                    q.kill()
+        f = tempfile.TemporaryFile(mode="w+")
+        files.append(f)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=f))
+    # wait for all ranks; a rank that dies leaves the others in a collective, so end exactly those (by PID)
+    failed = []
+    while any(p.poll() is None for p in procs) and not failed:
+        time.sleep(0.2)
+        failed = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+    if failed:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    for p in procs:
+        p.wait()
+    failed = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+    outs = []
+    for f in files:
+        f.seek(0)
+        outs.append(f.read())
+        f.close()
     if failed:
         sys.stderr.write("bench.py: rank(s) failed: %s\n" % failed)
         return 1
