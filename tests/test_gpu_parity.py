@@ -363,3 +363,43 @@ def test_long_soak_vs_oracle():
                 np.testing.assert_array_equal(_np(env.read(f)), ora.read(f), err_msg="%s step %d" % (f, t))
             np.testing.assert_allclose(_np(obs), o_obs, rtol=0, atol=1e-6)
     assert n_done >= 3 * n
+
+
+def test_two_kernel_mode_vs_oracle_incl_speculation_miss():
+    """The two-kernel step searches the path against the pose BEFORE the step and finishes with the new one.  With
+    dt = 0.5 s the vessel moves a fraction of a metre and the guess always covers it; with dt = 8 s it moves several
+    metres per step, the guess is rejected (|p - q| > NAV_DELTA) and the search is redone for the real pose.  Both
+    regimes against the oracle, every field, plus bitwise agreement with the default launch shape."""
+    n = 96
+    bank = _mixed_bank(32)
+    for dt in (0.5, 8.0):
+        cfg = effective_reference_config(use_lidar=True)
+        cfg.simulation.t_step_size = dt
+        cfg.episode.max_timesteps = 40
+        env = _env(cfg, bank, n, auto_reset=True)
+        env.set_step_mode("two_kernels")
+        ref = _env(cfg, bank, n, auto_reset=True)
+        ora = _oracle(cfg, bank, n, auto_reset=True)
+        env.reset(), ref.reset(), ora.reset()
+        rs = np.random.RandomState(17)
+        moved = 0.0
+        for t in range(60):
+            a = rs.uniform([-1, -0.15], [1, 0.15], (n, 2))
+            a[:, 0] = 1.0                                   # full thrust: largest displacement per step
+            before = _np(env.read("STATE"))[:2].copy()
+            at = torch.as_tensor(a, device="cuda:0")
+            obs, rew, done, _ = env.step(at)
+            o2, r2, d2, _ = ref.step(at)
+            o_obs, o_rew, o_done = ora.step(a)
+            assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(done, d2), (dt, t)
+            np.testing.assert_array_equal(_np(done), o_done, err_msg="done dt=%g step %d" % (dt, t))
+            after = _np(env.read("STATE"))[:2]
+            keep = _np(done) == 0
+            if keep.any():
+                moved = max(moved, float(np.hypot(*(after - before))[keep].max()))
+            for f in ("STATE", "LIDAR_D", "OBS64", "REWARD64", "INFO64", "NAV64", "MOVER_STATE"):
+                np.testing.assert_allclose(_np(env.read(f)), ora.read(f), rtol=0, atol=ATOL if dt < 1 else 1e-7,
+                                           err_msg="%s dt=%g step %d" % (f, dt, t))
+            np.testing.assert_array_equal(_np(env.read("CULL_LIMITS")), ora.read("CULL_LIMITS"))
+        assert (moved < 1.0) if dt < 1 else (moved > 1.5), (dt, moved)   # the second regime really leaves the guess behind
+        env.close(), ref.close()
