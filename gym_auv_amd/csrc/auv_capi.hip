@@ -40,6 +40,7 @@ void auv_launch_k1n(const AuvDev& d, const void* actions, int dtype, float* obs,
                     hipEvent_t ev1 = nullptr);
 void auv_launch_k2r(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
                     hipEvent_t ev1 = nullptr);
+void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
                    float* out_closeness, hipStream_t st);
 
@@ -556,8 +557,10 @@ int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx
 // One step: K1, then K2 (LiDAR) on the caller's stream with K3-nav forked onto the auxiliary
 // stream (they are independent given the new state), joined before K3-reward.  Works the same
 // eagerly and under stream capture (the fork/join events become graph edges).
+// `skip_k1`: the dynamics of this step were done by the previous step's fused kernel; `fuse_next`: this step's
+// reward phase also runs the dynamics of the NEXT step (both only inside a captured graph of several steps)
 static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, float* obs, float* reward, uint8_t* done,
-                        hipStream_t st, bool capturing) {
+                        hipStream_t st, bool capturing, bool skip_k1 = false, bool fuse_next = false) {
   // The action ring belongs to captured graphs only: an eager step reads `actions` as ONE plain
   // [N][2] buffer and neither reads nor advances the ring position (a caller that launches
   // eagerly can pass a different pointer every step).
@@ -578,9 +581,12 @@ static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, flo
   }
   if (h->step_mode != AUV_STEP_TWO_STREAMS && auv_k23_ok(d)) {
     // default: K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward, one stream
-    auv_launch_k1(d, actions, dtype, st);
-    auv_launch_k23(d, obs, st);
-    auv_launch_k3_reward(d, obs, reward, done, d.cfg.use_lidar ? 0 : 1, st);
+    if (!skip_k1) auv_launch_k1(d, actions, dtype, st);
+    auv_launch_k23(d, obs, st);                       // (advances a captured graph's action ring)
+    AuvDev dr = d;
+    if (d.ring_slots > 1) dr.ring_slot_host = -2;     // ... so the reward phase does not
+    if (fuse_next) auv_launch_k31(dr, actions, dtype, obs, reward, done, st);
+    else auv_launch_k3_reward(dr, obs, reward, done, d.cfg.use_lidar ? 0 : 1, st);
     return AUV_OK;
   }
   auv_launch_k1(d, actions, dtype, st);
@@ -736,8 +742,12 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
   }
   HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
   int rc = AUV_OK;
+  // inside the graph, step k's reward phase and step k+1's dynamics share a launch (side-by-side shape with a LiDAR
+  // sweep: the shapes whose reward kernel maps lanes to environments)
+  const bool fuse = n_steps > 1 && h->step_mode == AUV_STEP_SIDE_BY_SIDE && auv_k23_ok(h->d) && h->d.cfg.use_lidar;
   for (int32_t k = 0; k < n_steps && rc == AUV_OK; k++)
-    rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream, true);
+    rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream, true,
+                      fuse && k > 0, fuse && k + 1 < n_steps);
   hipError_t ce = hipStreamEndCapture(h->cap_stream, &h->graph);
   if (rc) return rc;
   HIP_TRY(ce);

@@ -734,7 +734,10 @@ __device__ __forceinline__ int reward_block(const AuvDev& d, const int e, const 
   if (!do_reset) d.counters[e] = cnt;
   // next action slot (the single-kernel step advances the ring from the host or a follow-up node:
   // other waves of that kernel may still be reading the position)
-  if (e == 0 && d.ring_slots > 1 && d.ring_slot_host < 0 && advance_ring) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
+  // (ring_slot_host: >= 0 the host names the slot; -1 the device position, advanced here; -2 the device position,
+  // advanced by another kernel of the step -- the side-by-side shape does it in k23_lidar_nav, so that a reward phase
+  // fused with the NEXT step's dynamics never races with its own readers)
+  if (e == 0 && d.ring_slots > 1 && d.ring_slot_host == -1 && advance_ring) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
   return do_reset;
 }
 

@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
   } else {
     const int e = auv_uniform((int)blockIdx.x * wpb + wave);
     if (e >= d.n) return;
+    // next action slot of a captured graph's ring: the dynamics kernel of this step has read the position, the
+    // one of the next step has not been launched yet
+    if (e == 0 && lane == 0 && d.ring_slots > 1 && d.ring_slot_host == -1) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
     const Slice L = carve(slice, S, d.k_max, d.m_max);
     AUV_STAMP_DECL
 #ifdef AUV_STAMPS
@@ -205,7 +208,47 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k2r_lidar_reward
 #endif
 }
 
+// ---- inside a captured graph of several steps: reward / done / auto-reset of step t and Vessel.step of step t + 1
+// in ONE launch (the actions of an open-loop stretch are in the ring already, so nothing sits between the two).
+// Lanes <-> environments for both: the scalar form of the dynamics (k1_env: the same operations in the same order
+// as the eight-lane kernel, bit-identical) has the same dependent chain, and 64 of them share a wave.
+template <typename AT>
+__global__ void __launch_bounds__(AUV_WAVE) k31_reward_dyn(AuvDev d, const AT* __restrict__ actions, float* __restrict__ obs_out,
+                                                           float* __restrict__ reward_out, uint8_t* __restrict__ done_out) {
+  const int lane = threadIdx.x;
+  const int e = blockIdx.x * AUV_WAVE + lane;
+  int do_reset = 0, w = 0;
+  int4 cnt = make_int4(0, 0, 0, 0);
+  if (e < d.n) {
+    cnt = d.counters[e];
+    w = d.world_idx[e];
+    const int collision = d.collision[e];
+    d.info64[8 * (size_t)e] = collision;
+    do_reset = reward_block(d, e, collision, cnt, false, 0.0, nullptr, reward_out, done_out, false);
+  }
+  unsigned long long m = __ballot(do_reset);
+  const bool any_reset = m != 0;
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int er = auv_uniform(__shfl(e, src, AUV_WAVE));
+    const int wr = __shfl(w, src, AUV_WAVE), ep = __shfl(cnt.z, src, AUV_WAVE);
+    restore_env(d, er, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
+  }
+  // a restored environment's state was written by lane 0, its dynamics below read it from another lane
+  if (any_reset) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  if (e < d.n) k1_env<AT>(d, e, actions, true);
+}
+
 }  // namespace
+
+void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st) {
+  const dim3 grid((d.n + AUV_WAVE - 1) / AUV_WAVE), block(AUV_WAVE);
+  if (dtype == AUV_F64)
+    hipLaunchKernelGGL(k31_reward_dyn<double>, grid, block, 0, st, d, (const double*)actions, obs, reward, done);
+  else
+    hipLaunchKernelGGL(k31_reward_dyn<float>, grid, block, 0, st, d, (const float*)actions, obs, reward, done);
+}
 
 // the nav chunk list must fit the segment stage it borrows
 bool auv_step_fused_ok(const AuvDev& d) { return NAV_SCRATCH_BYTES(d.nch_max) <= (size_t)K2_SEG_CAP * 32; }
