@@ -84,7 +84,7 @@ class BatchedAuvEnv:
             self.reward = torch.zeros((self.n_envs,), dtype=torch.float32, device=self.device)
             self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
         self._graph_actions = None
-        self.step_mode = "side_by_side"
+        self.step_mode = "paired"
 
     # ------------------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -155,12 +155,13 @@ class BatchedAuvEnv:
     def _lazy_info(self):
         return _LazyInfo(self)
 
-    STEP_MODES = {"side_by_side": 0, "one_kernel": 1, "two_streams": 2, "two_kernels": 3}
+    STEP_MODES = {"side_by_side": 0, "one_kernel": 1, "two_streams": 2, "two_kernels": 3, "paired": 4}
 
     def set_step_mode(self, mode: str):
-        """"side_by_side" (default): K1 -> [K2 + K3-nav in one launch] -> K3-reward; "two_kernels": [K1 -> K3-nav]
+        """"side_by_side": K1 -> [K2 + K3-nav in one launch] -> K3-reward; "paired": the same without the third
+        launch, the second of an environment's two waves runs K3-reward; "two_kernels": [K1 -> K3-nav]
         -> [K2 -> K3-reward]; "one_kernel": the whole step in one kernel; "two_streams": K3-nav forked
-        beside K2.  All four give the same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise)."""
+        beside K2.  All give the same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise)."""
         _check(_LIB.auv_set_step_mode(self._h, self.STEP_MODES[mode]), "auv_set_step_mode")
         self.step_mode = mode
 
@@ -215,7 +216,11 @@ class BatchedAuvEnv:
         return [float(x) for x in ms]
 
     def timed_kernel_names(self):
-        return ["k1n_dyn_nav", "k2r_lidar_reward"] if self.step_mode == "two_kernels" else ["k1_dynamics", "k23_lidar_nav", "k3_reward"]
+        if self.step_mode == "two_kernels":
+            return ["k1n_dyn_nav", "k2r_lidar_reward"]
+        if self.step_mode == "paired" and self.config.vessel.use_lidar:
+            return ["k1_dynamics", "k23_lidar_nav_paired"]      # (the kernel trace calls it k23_lidar_nav<true>)
+        return ["k1_dynamics", "k23_lidar_nav", "k3_reward"]
 
     # ------------------------------------------------------------------------------ optional post-kernel
     def feasibility_pooling(self, width: Optional[float] = None):

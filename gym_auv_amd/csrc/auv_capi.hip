@@ -36,6 +36,9 @@ hipError_t auv_step_fused_prepare(const AuvDev& d);
 void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st);
 bool auv_two_kernel_ok(const AuvDev& d);
+bool auv_paired_ok(const AuvDev& d);
+void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
+                           hipEvent_t ev1 = nullptr);
 void auv_launch_k1n(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr,
                     hipEvent_t ev1 = nullptr);
 void auv_launch_k2r(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
@@ -72,11 +75,20 @@ struct auv_handle {
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
   int step_mode;                 // AUV_STEP_* (include/auv_hip.h)
+  int32_t* pair_error_host;      // pinned, mapped: set by a navigation wave of the paired step that gave up polling
   hipEvent_t ev[6];
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
   GenOut gen;
 };
+
+// paired step: a navigation wave that gave up polling for its sweep's word has left the step unfinished
+#define PAIR_CHECK(h)                                                                                           \
+  do {                                                                                                          \
+    if ((h)->pair_error_host && *(volatile int32_t*)(h)->pair_error_host)                                       \
+      return fail(AUV_ESTATE, "paired step: a navigation wave timed out waiting for its LiDAR sweep; results " \
+                              "since then are incomplete (auv_set_step_mode(AUV_STEP_SIDE_BY_SIDE) avoids it)"); \
+  } while (0)
 
 template <typename T>
 static int dev_alloc(std::vector<void*>& pool, T** out, size_t count) {
@@ -165,6 +177,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.collision, n);
   rc |= dev_alloc(ep, &d.step_info, n * 4);
   rc |= dev_alloc(ep, &d.pose_cs, n);
+  rc |= dev_alloc(ep, &d.pair_word, n);
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
   rc |= dev_alloc(ep, &d.stamps, n * 16);
@@ -195,6 +208,16 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   d.ring_slots = 1;
   d.ring_slot_host = -1;
   HIP_TRY(hipMemset(d.ring_pos, 0, sizeof(int32_t)));
+  {
+    // paired step: no sweep has left a word yet
+    std::vector<unsigned long long> empty(n ? n : 1, AUV_PAIR_EMPTY);
+    HIP_TRY(hipMemcpy(d.pair_word, empty.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    if (!h->pair_error_host) {
+      HIP_TRY(hipHostMalloc((void**)&h->pair_error_host, sizeof(int32_t), hipHostMallocMapped));
+      *h->pair_error_host = 0;
+      HIP_TRY(hipHostGetDevicePointer((void**)&d.pair_error, h->pair_error_host, 0));
+    }
+  }
   d.w_ready = 0;
   auv_launch_derive(d, nullptr);
   std::vector<int32_t> wi(n);
@@ -221,6 +244,15 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     HIP_TRY(hipDeviceSynchronize());
   }
   d.w_ready = 1;
+  {
+    // the device-side copy of this struct: what the rarely taken paths of the paired step read their tables from
+    if (!d.self) {
+      AuvDev* p = nullptr;
+      HIP_TRY(hipMalloc((void**)&p, sizeof(AuvDev)));
+      d.self = p;
+    }
+    HIP_TRY(hipMemcpy((void*)d.self, &d, sizeof(AuvDev), hipMemcpyHostToDevice));
+  }
   // initial binding e -> world e % W, reset-time state (the first reset() call is then a copy)
   for (size_t e = 0; e < n; e++) wi[e] = (int32_t)(e % (size_t)W);
   HIP_TRY(hipMemcpy(d.world_idx, wi.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -254,7 +286,7 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->graph = nullptr;
   h->graph_exec = nullptr;
   h->cap_stream = nullptr;
-  h->step_mode = AUV_STEP_SIDE_BY_SIDE;
+  h->step_mode = AUV_STEP_PAIRED;
   h->gen_worlds = 0;
   h->aux_stream = nullptr;
   h->ev_fork = h->ev_join = nullptr;
@@ -283,6 +315,8 @@ int auv_destroy(auv_handle_t* h) {
     if (e) (void)hipEventDestroy(e);
   free_pool(h->env_allocs);
   free_pool(h->bank_allocs);
+  if (h->pair_error_host) (void)hipHostFree(h->pair_error_host);
+  if (h->d.self) (void)hipFree((void*)h->d.self);
   delete h;
   return AUV_OK;
 }
@@ -579,6 +613,12 @@ static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, flo
     auv_launch_k2r(d, obs, reward, done, st);
     return AUV_OK;
   }
+  if (h->step_mode == AUV_STEP_PAIRED && auv_paired_ok(d)) {
+    // K1 -> [K2 and K3-nav side by side, the second of an environment's two waves runs K3-reward]: two launches
+    auv_launch_k1(d, actions, dtype, st);
+    auv_launch_k23_paired(d, obs, reward, done, st);   // (advances a captured graph's action ring)
+    return AUV_OK;
+  }
   if (h->step_mode != AUV_STEP_TWO_STREAMS && auv_k23_ok(d)) {
     // default: K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward, one stream
     if (!skip_k1) auv_launch_k1(d, actions, dtype, st);
@@ -605,6 +645,7 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
   REQUIRE_READY(h);
   if (!actions_dev) return fail(AUV_EINVAL, "auv_step: null actions");
   if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_step: bad action dtype");
+  PAIR_CHECK(h);
   int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream, false);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -626,8 +667,15 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
 
 int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   if (!h) return fail(AUV_EINVAL, "null handle");
-  if (mode < 0 || mode > 3) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
+  if (mode < 0 || mode > 4) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
   h->step_mode = mode;
+  {
+    // test hook of the paired step: AUV_PAIR_SKEW=k leaves k idle workgroups between the two roles, which puts an
+    // environment's two waves on different XCDs (read here, not cached, so that a test can switch it)
+    const char* v = getenv("AUV_PAIR_SKEW");
+    const int k = v ? atoi(v) : 0;
+    h->d.pair_skew = (k > 0 && k < 8) ? k : 0;
+  }
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;
@@ -744,10 +792,16 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
   int rc = AUV_OK;
   // inside the graph, step k's reward phase and step k+1's dynamics share a launch (side-by-side shape with a LiDAR
   // sweep: the shapes whose reward kernel maps lanes to environments)
-  const bool fuse = n_steps > 1 && h->step_mode == AUV_STEP_SIDE_BY_SIDE && auv_k23_ok(h->d) && h->d.cfg.use_lidar;
+  // (also for the paired shape: inside a graph of several steps the fused reward + dynamics launch is worth more than
+  // the paired finish -- 97.2 M against 95.5 M env-steps/s at 16 steps per graph -- and the bits are the same)
+  const bool fuse = n_steps > 1 && (h->step_mode == AUV_STEP_SIDE_BY_SIDE || h->step_mode == AUV_STEP_PAIRED) &&
+                    auv_k23_ok(h->d) && h->d.cfg.use_lidar;
+  const int mode_was = h->step_mode;
+  if (fuse) h->step_mode = AUV_STEP_SIDE_BY_SIDE;
   for (int32_t k = 0; k < n_steps && rc == AUV_OK; k++)
     rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream, true,
                       fuse && k > 0, fuse && k + 1 < n_steps);
+  h->step_mode = mode_was;
   hipError_t ce = hipStreamEndCapture(h->cap_stream, &h->graph);
   if (rc) return rc;
   HIP_TRY(ce);
@@ -758,6 +812,7 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
 int auv_graph_launch(auv_handle_t* h, void* stream) {
   REQUIRE_READY(h);
   if (!h->graph_exec) return fail(AUV_ESTATE, "auv_graph_launch: no captured graph");
+  PAIR_CHECK(h);
   HIP_TRY(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
   return AUV_OK;
 }
@@ -766,6 +821,7 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
                    uint8_t* done_dev, void* stream, float* out_ms4) {
   REQUIRE_READY(h);
   if (!actions_dev || !out_ms4) return fail(AUV_EINVAL, "auv_step_timed: null argument");
+  PAIR_CHECK(h);
   hipStream_t st = (hipStream_t)stream;
   for (auto& e : h->ev)
     if (!e) HIP_TRY(hipEventCreate(&e));
@@ -777,6 +833,10 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   if (h->step_mode == AUV_STEP_TWO_KERNELS && auv_two_kernel_ok(d)) {
     auv_launch_k1n(d, actions_dev, action_dtype, obs_dev, st, h->ev[0], h->ev[1]);
     auv_launch_k2r(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
+    nk = 2;
+  } else if (h->step_mode == AUV_STEP_PAIRED && auv_paired_ok(d)) {
+    auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
+    auv_launch_k23_paired(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
     nk = 2;
   } else {
     if (!auv_k23_ok(d)) return fail(AUV_EINVAL, "auv_step_timed: path too long for the side-by-side launch");

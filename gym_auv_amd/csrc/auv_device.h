@@ -76,6 +76,12 @@ struct AuvDev {
   uint8_t* collision;  // [N]
   double* step_info;   // [N][4] info of the last step (terminal values survive an auto-reset)
   double2* pose_cs;    // [N] cos, sin of the heading K1 has just produced (K1 -> LiDAR within one step only)
+  unsigned long long* pair_word; // [N] paired step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
+  int32_t* pair_error; // [1] paired step: set when a navigation wave gave up waiting for its sweep
+  int32_t pair_skew;   // paired step, test hook: idle workgroups between the two roles (puts them on different XCDs)
+  const struct AuvDev* self;  // this struct in device memory (as of the last bank load): the paired step's restore path
+                              // reads its ~25 table pointers through it at the point of use -- as kernel arguments
+                              // they would all be fetched (and spilled) at the entry of every wave of both roles
   int32_t* fresh_count; // [1]  } work list of the load-time pass that computes the reset rows
   int32_t* fresh_list;  // [N]  }
   // ---- per-world reset rows (derived once at load time by running the reset observation of
@@ -179,6 +185,54 @@ __device__ __forceinline__ int auv_pymod(int a, int s) {
   int r = a % s;
   return r < 0 ? r + s : r;
 }
+
+#define AUV_PAIR_EMPTY 0x7ff8dead00000001ull       // paired step: "no word yet" (a NaN payload no arithmetic produces)
+#define AUV_PAIR_COLLISION 0x7ff8dead00000002ull   //              "the sweep found a collision"
+
+// Stores and loads that are coherent over the whole device one by one (relaxed agent-scope atomics: the
+// `sc1` forms, written through / read past the XCD's L2, which is not coherent with the other seven).  WT = false:
+// plain accesses.  Used by the paired step, where two waves on possibly different XCDs hand rows to each other
+// inside one launch (k_step_fused.hip: pair_finish).
+template <bool WT> __device__ __forceinline__ void auv_st(double* p, const double v) {
+  if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool WT> __device__ __forceinline__ void auv_st(float* p, const float v) {
+  if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool WT> __device__ __forceinline__ void auv_st(uint8_t* p, const uint8_t v) {
+  if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool WT> __device__ __forceinline__ void auv_st(int2* p, const int2 v) {
+  if constexpr (WT) {
+    __hip_atomic_store((unsigned long long*)p, ((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+template <bool WT> __device__ __forceinline__ void auv_st(double2* p, const double2 v) {
+  if constexpr (WT) {
+    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+template <bool WT> __device__ __forceinline__ void auv_st(double4* p, const double4 v) {
+  if constexpr (WT) {
+    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->z, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->w, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+template <bool WT, typename T> __device__ __forceinline__ T auv_ld(const T* p) {
+  if constexpr (WT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+// every global store this wave has issued so far is complete (for the sc1 forms: visible to the whole device)
+__device__ __forceinline__ void auv_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // LDS hand-off between lanes of the SAME wave: a wave's LDS operations execute in order, so
 // only outstanding operations must be waited for and the compiler kept from reordering.

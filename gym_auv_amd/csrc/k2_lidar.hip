@@ -265,6 +265,7 @@ __device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const S
 // phases A, C, B, S for one environment, by one wave
 // cs_pre: cos / sin of the heading when the dynamics kernel of this step has left them (pose_cs);
 // nullptr = form them here (same function, same argument: the same bits)
+template <bool WT = false>
 __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
                         const EnvPre* pre = nullptr, const double2* cs_pre = nullptr) {
   const int S = d.cfg.n_sensors;
@@ -320,7 +321,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       st.z = atan2(dy, dx);
       st.x = st.x + dx;
       st.y = st.y + dy;
-      d.mover[(size_t)e * d.m_max + m] = st;
+      auv_st<WT>(&d.mover[(size_t)e * d.m_max + m], st);
     }
     const double wd = par_m.x;
     double s, c;
@@ -436,8 +437,9 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
         if (state == 2) state = L.par[pos] ? 1 : 0;
         auv_wave_lds_sync();                                     // (the scratch is reused by the next block of obstacles)
       }
-      if (k < K) d.nearby[(size_t)e * d.k_max + k] = (uint8_t)state;   // read back below by the same lane
+      if (k < K) auv_st<WT>(&d.nearby[(size_t)e * d.k_max + k], (uint8_t)state);   // read back below by the same lane
     }
+    if constexpr (WT) auv_stores_done();   // (the read below goes past the caches that a write-through store does not update)
   }
 
   // ---- phase B: cull windows of the nearby obstacles; compaction of obstacles with a window ----
@@ -476,7 +478,8 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
           o.kind |= K2_PIP_FLAG;
         }
       }
-      const uint8_t near = d.nearby[(size_t)e * d.k_max + k];
+      // (after a write-through refresh the flag is read past the caches; otherwise it is an ordinary load)
+      const uint8_t near = (WT && refresh) ? auv_ld<WT>(&d.nearby[(size_t)e * d.k_max + k]) : d.nearby[(size_t)e * d.k_max + k];
       int2 lim = make_int2(INT32_MIN, INT32_MIN);
       if (near) {
         int start, stop;
@@ -546,14 +549,14 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
           active = true;
         }
       }
-      d.limits[(size_t)e * d.k_max + k] = lim;
+      auv_st<WT>(&d.limits[(size_t)e * d.k_max + k], lim);
       L.obs[k] = o;
     }
     const unsigned long long mask = __ballot(active);
     if (active) L.act[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = k;
     n_act += __popcll(mask);
   }
-  for (int k = K + lane; k < d.k_max; k += AUV_WAVE) d.limits[(size_t)e * d.k_max + k] = make_int2(INT32_MIN, INT32_MIN);
+  for (int k = K + lane; k < d.k_max; k += AUV_WAVE) auv_st<WT>(&d.limits[(size_t)e * d.k_max + k], make_int2(INT32_MIN, INT32_MIN));
   if (lane == 0) L.hdr->n_act = n_act;
   auv_wave_lds_sync();
   // prefix of boundary-segment counts over the active list (wave scan, 64 entries per pass);
@@ -809,6 +812,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 // evaluated over that dense list only (typically one pass of 64 instead of S / 64).
 // n_act == 0 (no obstacle had a ray to test): the whole row is free, nothing was swept.
 #define K2_HIT_CAP (K2_SEG_CAP * 8)    // ints that fit the (by now idle) segment stage
+template <bool WT = false>
 __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, const int n_act,
                        float* __restrict__ obs_out = nullptr, double* rew_lidar_out = nullptr) {
   const int S = d.cfg.n_sensors;
@@ -820,13 +824,13 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
   float* oo = obs_out ? obs_out + (size_t)e * D + 6 : nullptr;
   if (n_act == 0) {
     for (int i = lane; i < S; i += AUV_WAVE) {
-      dd[i] = R, ob[i] = 0.0;
-      if (oo) oo[i] = 0.0f;
+      auv_st<WT>(dd + i, R), auv_st<WT>(ob + i, 0.0);
+      if (oo) auv_st<WT>(oo + i, 0.0f);
     }
     const double term = colav ? d.derived[3] : 0.0;
     if (lane == 0) {
-      d.collision[e] = 0;
-      if (colav) d.rew_lidar[e] = term;
+      auv_st<WT>(d.collision + e, (uint8_t)0);
+      if (colav) auv_st<WT>(d.rew_lidar + e, term);
     }
     if (rew_lidar_out) *rew_lidar_out = term;
     return 0;
@@ -844,8 +848,8 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
       const int i = i0 + lane;
       const bool hit = (i < S) && (u2d(L.dbits[i]) <= 1.0);
       if (i < S && !hit) {
-        dd[i] = R, ob[i] = 0.0;                            // sensor.py:156; closeness 1 - clip(x / x) = 0
-        if (oo) oo[i] = 0.0f;
+        auv_st<WT>(dd + i, R), auv_st<WT>(ob + i, 0.0);    // sensor.py:156; closeness 1 - clip(x / x) = 0
+        if (oo) auv_st<WT>(oo + i, 0.0f);
         if (colav) num += d.beam_w[i] * raw_free;          // gamma_theta from the per-config table
       }
       const unsigned long long m = __ballot(hit);
@@ -864,11 +868,11 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
         const double X = px + t * r.x, Y = py + t * r.y;
         const double dx = X - px, dy = Y - py;
         const double di = sqrt(dx * dx + dy * dy);
-        dd[i] = di;
+        auv_st<WT>(dd + i, di);
         double cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0) : 1 - auv_clip(di / R, 0.0, 1.0);
         cl = auv_clip(cl, -1.0, 1.0);
-        ob[i] = cl;
-        if (oo) oo[i] = (float)cl;
+        auv_st<WT>(ob + i, cl);
+        if (oo) auv_st<WT>(oo + i, (float)cl);
         if (colav) num += d.beam_w[i] * ((di != R) ? R * exp(-0.1 * di) : raw_free);   // gamma_x
         col |= (di < W);
       }
@@ -884,12 +888,12 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
         const double dx = X - px, dy = Y - py;
         di = sqrt(dx * dx + dy * dy);
       }
-      dd[i] = di;
+      auv_st<WT>(dd + i, di);
       double cl = 0.0;
       if (t <= 1.0) cl = d.cfg.sensor_log_transform ? 1 - auv_clip(log(1 + di) / logR, 0.0, 1.0) : 1 - auv_clip(di / R, 0.0, 1.0);
       cl = auv_clip(cl, -1.0, 1.0);
-      ob[i] = cl;
-      if (oo) oo[i] = (float)cl;
+      auv_st<WT>(ob + i, cl);
+      if (oo) auv_st<WT>(oo + i, (float)cl);
       if (colav) num += d.beam_w[i] * ((di != R) ? R * exp(-0.1 * di) : raw_free);
       col |= (di < W);
     }
@@ -898,8 +902,8 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
   if (colav) num = auv_wave_sum(num);
   const double term = (colav && S > 0) ? -num / d.derived[2] : 0.0;   // the same in every lane
   if (lane == 0) {
-    d.collision[e] = (uint8_t)(col != 0);
-    if (colav) d.rew_lidar[e] = term;
+    auv_st<WT>(d.collision + e, (uint8_t)(col != 0));
+    if (colav) auv_st<WT>(d.rew_lidar + e, term);
   }
   if (rew_lidar_out) *rew_lidar_out = term;
   return col != 0;

@@ -486,9 +486,17 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
   return sp;
 }
 
+// what the navigation leaves for the reward phase (lane 0; also stored to REW_PATH / INFO64)
+struct NavOut {
+  double rew_path, reached, goal, progress;
+  double u, v, r;                   // the velocities it was computed with (STATE rows 3..5)
+};
+
+// WT: the rows are stored write-through (auv_st), for the paired step.  `out`: lane 0's NavOut, or nullptr.
+template <bool WT = false>
 __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const int lane, int* list,
                                            float* __restrict__ obs_out, const EnvPre* pre, NavSpec sp, const bool have_spec,
-                                           const double* win_slots, const double2* pose_cs_in) {
+                                           const double* win_slots, const double2* pose_cs_in, NavOut* out = nullptr) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
@@ -619,17 +627,24 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
     // rows are written with 16-byte stores (NAV64 / INFO64 rows are 64-byte records)
     const double cte100 = cte / 100;
     double2* nv2 = (double2*)nv;
-    nv2[0] = make_double2(u, v), nv2[1] = make_double2(r, la), nv2[2] = make_double2(he, cte100), nv2[3] = make_double2(chi, s_t);
+    auv_st<WT>(nv2 + 0, make_double2(u, v)), auv_st<WT>(nv2 + 1, make_double2(r, la)), auv_st<WT>(nv2 + 2, make_double2(he, cte100)),
+        auv_st<WT>(nv2 + 3, make_double2(chi, s_t));
     double2* inf2 = (double2*)inf;
-    inf[1] = reached, inf2[1] = make_double2(goal, progress), inf[5] = maxp, inf2[3] = make_double2(s, 0.0);
+    auv_st<WT>(inf + 1, (double)reached), auv_st<WT>(inf2 + 1, make_double2(goal, progress)), auv_st<WT>(inf + 5, maxp),
+        auv_st<WT>(inf2 + 3, make_double2(s, 0.0));
     // path-following term of the reward: everything it needs is at hand here, so the
     // transcendentals stay out of the reward phase
-    d.rew_path[e] = reward_path_term_cos(d, u, v, cos_he, cte100, progress, maxp);
+    const double rew_path = reward_path_term_cos(d, u, v, cos_he, cte100, progress, maxp);
+    auv_st<WT>(d.rew_path + e, rew_path);
+    if (out) out->rew_path = rew_path, out->reached = reached, out->goal = goal, out->progress = progress, out->u = u, out->v = v, out->r = r;
     // environment.py:276-280; lane 0 also emits the float32 copies of its own six values.  OBS64 rows
     // start 16-byte aligned when 6 + S is even, float32 rows 8-byte aligned when their stride is even.
     const double c0 = auv_clip(u, -1.0, 1.0), c1 = auv_clip(v, -1.0, 1.0), c2 = auv_clip(r, -1.0, 1.0),
                  c3 = auv_clip(la, -1.0, 1.0), c4 = auv_clip(he, -1.0, 1.0), c5 = auv_clip(cte100, -1.0, 1.0);
-    if (((6 + S) & 1) == 0) {
+    if (WT) {
+      auv_st<WT>(ob + 0, c0), auv_st<WT>(ob + 1, c1), auv_st<WT>(ob + 2, c2), auv_st<WT>(ob + 3, c3), auv_st<WT>(ob + 4, c4),
+          auv_st<WT>(ob + 5, c5);
+    } else if (((6 + S) & 1) == 0) {
       double2* ob2 = (double2*)ob;
       ob2[0] = make_double2(c0, c1), ob2[1] = make_double2(c2, c3), ob2[2] = make_double2(c4, c5);
     } else {
@@ -637,7 +652,10 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
     }
     if (obs_out) {
       float* oo = obs_out + (size_t)e * D;
-      if ((D & 1) == 0) {
+      if (WT) {
+        auv_st<WT>(oo + 0, (float)c0), auv_st<WT>(oo + 1, (float)c1), auv_st<WT>(oo + 2, (float)c2), auv_st<WT>(oo + 3, (float)c3),
+            auv_st<WT>(oo + 4, (float)c4), auv_st<WT>(oo + 5, (float)c5);
+      } else if ((D & 1) == 0) {
         float2* oo2 = (float2*)oo;
         oo2[0] = make_float2((float)c0, (float)c1), oo2[1] = make_float2((float)c2, (float)c3), oo2[2] = make_float2((float)c4, (float)c5);
       } else {
@@ -654,9 +672,10 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
 // LDS, 16-byte aligned: three parked spline windows, then the list of surviving chunks.
 #define NAV_WIN_BYTES (3 * 20 * 8)
 #define NAV_SCRATCH_BYTES(nch_max) ((NAV_WIN_BYTES + (size_t)(nch_max) * sizeof(int) + 15) & ~(size_t)15)
+template <bool WT = false>
 __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const int lane, unsigned char* scratch,
                                            float* __restrict__ obs_out, const EnvPre* pre = nullptr,
-                                           const double2* pose_cs = nullptr) {
+                                           const double2* pose_cs = nullptr, NavOut* out = nullptr) {
   double* wins = (double*)scratch;
   int* list = (int*)(scratch + NAV_WIN_BYTES);
   const size_t n = (size_t)d.n;
@@ -665,7 +684,7 @@ __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const i
   (void)wins;
   const NavSpec sp = nav_speculate(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
                                    0.0, nullptr);
-  nav_finish(d, e, lane, list, obs_out, pre, sp, true, nullptr, pose_cs ? pose_cs + e : nullptr);
+  nav_finish<WT>(d, e, lane, list, obs_out, pre, sp, true, nullptr, pose_cs ? pose_cs + e : nullptr, out);
 }
 
 // ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----
@@ -677,34 +696,35 @@ __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const i
 // scalar: by lane 0 of the environment's wave, or by the environment's lane of k3_reward_lanes.  The LiDAR term
 // was formed by K2 (rew_lidar), the path-following term by the navigation phase (rew_path); here they are only
 // combined.  `cnt` in/out; returns whether the environment is to be auto-reset.
-__device__ __forceinline__ int reward_block(const AuvDev& d, const int e, const int collision, int4& cnt,
-                                            const bool from_buffers, const double lidar_term, const double* rew_lidar_pre,
+// the values the block works on, wherever they came from
+struct RewardIn {
+  double u, v, yaw_rate;            // vessel velocities after the step
+  double path_reward, closeness_reward;
+  double reached, goal, progress;   // INFO64 [1] [2] [3] of this step
+  double cum;                       // cumulative reward before this step
+};
+
+__device__ __forceinline__ int reward_apply(const AuvDev& d, const int e, const int collision, int4& cnt, const RewardIn in,
                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
                                             const bool advance_ring) {
   double* inf = d.info64 + 8 * (size_t)e;
-  const double* nv = d.nav64 + 8 * (size_t)e;
   const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
   const double lambda = 0.5, eta = 0.0, penalty_yawrate = 10.0, neutral_speed = 0.05, max_speed = 2.0;
-  // everything the block reads is requested up front (one trip to memory, whatever branch follows)
-  const double2 uv = ((const double2*)nv)[0];           // rows are 64-byte records: 16-byte accesses
-  const double u = uv.x, v = uv.y, yaw_rate = nv[2];
-  // (the LiDAR term arrives in a register when the sweep ran in this very wave)
-  const double rew_path_in = d.rew_path[e], rew_lidar_in = rew_lidar_pre ? *rew_lidar_pre : d.rew_lidar[e];
-  const double2 gp = ((const double2*)inf)[1];
-  const double cum_in = inf[4], reached_in = inf[1], goal_in = gp.x, progress_in = gp.y;
+  const double u = in.u, v = in.v, yaw_rate = in.yaw_rate;
+  const double cum_in = in.cum, reached_in = in.reached, goal_in = in.goal, progress_in = in.progress;
   double reward;
   if (collision) {
     reward = -10000.0 * (1 - lambda);
   } else {
     const double speed = sqrt(u * u + v * v);
-    const double path_reward = from_buffers ? reward_path_term(d, u, v, nv[4], nv[5], inf[3], inf[5]) : rew_path_in;
+    const double path_reward = in.path_reward;
     const double living_penalty = lambda * (2 * neutral_speed + 1) + eta * neutral_speed;
     if (!colav) {
       double slow_penalty = (speed < 0.1) ? -2 : 0;
       reward = path_reward - living_penalty + eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) +
                slow_penalty;
     } else {
-      const double closeness_reward = (from_buffers || !d.cfg.use_lidar) ? lidar_term : rew_lidar_in;
+      const double closeness_reward = in.closeness_reward;
       double slow_penalty = (speed < 0.04) ? -2 : 0;
       reward = lambda * path_reward + (1 - lambda) * closeness_reward - living_penalty +
                eta * speed / max_speed - penalty_yawrate * fabs(yaw_rate) + slow_penalty;
@@ -739,6 +759,28 @@ __device__ __forceinline__ int reward_block(const AuvDev& d, const int e, const 
   // fused with the NEXT step's dynamics never races with its own readers)
   if (e == 0 && d.ring_slots > 1 && d.ring_slot_host == -1 && advance_ring) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
   return do_reset;
+}
+
+__device__ __forceinline__ int reward_block(const AuvDev& d, const int e, const int collision, int4& cnt,
+                                            const bool from_buffers, const double lidar_term, const double* rew_lidar_pre,
+                                            float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
+                                            const bool advance_ring) {
+  const double* inf = d.info64 + 8 * (size_t)e;
+  const double* nv = d.nav64 + 8 * (size_t)e;
+  // everything the block reads is requested up front (one trip to memory, whatever branch follows)
+  const double2 uv = ((const double2*)nv)[0];           // rows are 64-byte records: 16-byte accesses
+  RewardIn in;
+  in.u = uv.x, in.v = uv.y, in.yaw_rate = nv[2];
+  // (the LiDAR term arrives in a register when the sweep ran in this very wave)
+  const double rew_path_in = d.rew_path[e], rew_lidar_in = rew_lidar_pre ? *rew_lidar_pre : d.rew_lidar[e];
+  const double2 gp = ((const double2*)inf)[1];
+  in.cum = inf[4], in.reached = inf[1], in.goal = gp.x, in.progress = gp.y;
+  in.path_reward = rew_path_in, in.closeness_reward = rew_lidar_in;
+  if (!collision) {
+    if (from_buffers) in.path_reward = reward_path_term(d, in.u, in.v, nv[4], nv[5], inf[3], inf[5]);
+    if (from_buffers || !d.cfg.use_lidar) in.closeness_reward = lidar_term;
+  }
+  return reward_apply(d, e, collision, cnt, in, reward_out, done_out, advance_ring);
 }
 
 __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, const bool full,

@@ -49,57 +49,180 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
   k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, &pre, collision, false, !d.cfg.use_lidar);
 }
 
+// ---- the paired finish: reward / done / auto-reset inside the side-by-side launch -------------------
+// An environment's LiDAR wave and its navigation wave are two one-wave workgroups of the same launch; the
+// navigation wave also runs the reward phase (rewarder.py:78-140, :167-241; environment.py:333-347, :375-384) --
+// no third launch.  What it needs of the sweep is one 64-bit word per environment (the LiDAR term of the reward,
+// or a marker for "collision"): the LiDAR wave stores it last, the navigation wave requests it when it starts
+// (almost always it is there by then: navigation workgroups are dispatched behind all LiDAR workgroups and get
+// their slot when a sweep retires), consumes it at its end and puts the "empty" marker back.
+//   Coherence without device-scope fences (their L2 write-back per wave is what made round 1's attempt 5x slower):
+//   * the word goes by relaxed agent-scope atomic store / load (sc1: written through and read past the XCD's
+//     L2, which is not coherent with the other seven);
+//   * every row the LiDAR wave writes is stored write-through too (WT = true in k2_front / k2_back), and the wave
+//     waits for the completion of all its stores before it stores the word.  A navigation wave that has seen the
+//     word therefore knows that nothing of its environment is in flight or dirty in another L2: its plain stores
+//     (reward phase; restore_env, which overwrites the sweep's rows when the episode ended) are the last word
+//     whichever XCDs the two ran on.  Rows of other environments share cache lines but not bytes.
+//   * the launch places the two waves of an environment on the same XCD (workgroups go round-robin over the
+//     eight XCDs; the navigation role starts at a multiple of 8), which keeps the word in one L2; correctness
+//     does not depend on it (tests run with the roles skewed onto different XCDs).
+//   * a navigation wave whose sweep is still running (a handful per launch) polls.  Its LiDAR workgroup has a
+//     smaller index in the same launch, so it was dispatched earlier and finishes without needing anything from
+//     anyone; the poll is bounded all the same: when it runs out the wave reports through `pair_error`
+//     (auv_step fails from then on) instead of hanging the device.
+#define PAIR_EMPTY AUV_PAIR_EMPTY
+#define PAIR_COLLISION AUV_PAIR_COLLISION
+#define PAIR_POLL_LIMIT (1 << 22)
+
+__device__ __forceinline__ void pair_publish_lidar(const AuvDev& d, const int e, const int lane, const int collision,
+                                                   const double term) {
+  auv_stores_done();                                       // of every lane of this wave (one counter per wave)
+  if (lane == 0)
+    __hip_atomic_store(d.pair_word + e, collision ? PAIR_COLLISION : (unsigned long long)__double_as_longlong(term),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// what the navigation wave requests before it starts working (one trip, hidden behind the search)
+struct PairPre {
+  unsigned long long word;
+  double cum;
+  int4 cnt;
+  int w;
+};
+__device__ __forceinline__ PairPre pair_prefetch(const AuvDev& d, const int e) {
+  PairPre p;
+  p.word = __hip_atomic_load(d.pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (written by earlier launches: the dynamics kernel and the previous step's reward phase)
+  p.cum = d.info64[8 * (size_t)e + 4];
+  p.cnt = d.counters[e];
+  p.w = d.world_idx[e];
+  return p;
+}
+
+__device__ __forceinline__ unsigned long long pair_uniform(const unsigned long long v) {   // (readfirstlane returns int)
+  return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+}
+
+__device__ __forceinline__ void pair_finish_nav(const AuvDev& dk, const int e, const int lane, PairPre p, const NavOut no,
+                                                float* __restrict__ obs_out, float* __restrict__ reward_out,
+                                                uint8_t* __restrict__ done_out) {
+  unsigned long long word = pair_uniform(p.word);
+  for (int polls = 0; word == PAIR_EMPTY; polls++) {
+    if (polls == PAIR_POLL_LIMIT) {
+      if (lane == 0) __hip_atomic_store(dk.pair_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+    const unsigned long long t = __hip_atomic_load(dk.pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    word = pair_uniform(t);
+  }
+#ifdef AUV_STAMPS
+  if (lane == 0) dk.stamps[(size_t)e * 16 + 7] = wall_clock64();   // the sweep's word is here: start of the reward phase
+#endif
+  int do_reset = 0;
+  int4 cnt = p.cnt;
+  const AuvDev& d = dk;
+  if (lane == 0) {
+    __hip_atomic_store(d.pair_word + e, PAIR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next step
+    RewardIn in;
+    const int collision = word == PAIR_COLLISION;
+    in.closeness_reward = collision ? 0.0 : __longlong_as_double((long long)word);
+    in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
+    in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
+    in.cum = p.cum;
+    d.info64[8 * (size_t)e] = collision;
+    do_reset = reward_apply(d, e, collision, cnt, in, reward_out, done_out, false);
+  }
+  do_reset = __builtin_amdgcn_readfirstlane(do_reset);
+  if (do_reset) {
+    // (rare) the ~25 tables of the copy are read through the device-side copy of `d` (AuvDev::self), addressed as
+    // constant memory: scalar loads at the point of use.  As kernel arguments they would be fetched -- and, the budget
+    // of scalar registers being what it is, spilled -- at the entry of every wave of BOTH roles (1.4 us of the launch).
+    const AuvDev& dc = *(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)d.self;
+    restore_env(dc, e, (int)(((long long)__builtin_amdgcn_readfirstlane(p.w) + d.n) % d.n_worlds), lane,
+                __builtin_amdgcn_readfirstlane(cnt.z), obs_out);
+  }
+}
+
 // K2 and K3-nav of ALL environments in one launch: workgroups [0, nb) sweep the LiDAR of their
-// four environments, workgroups [nb, 2 nb) navigate theirs.  The two are independent given the
+// environments, workgroups [nb, 2 nb) navigate theirs.  The two are independent given the
 // new vessel state, so they run side by side (the LiDAR workgroups are dispatched first and fill
 // the chip; navigation workgroups move in as those retire) -- the concurrency of two streams
 // without the ~8 us a cross-stream event wait costs on each side.
-__global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(AuvDev d, float* __restrict__ obs_out) {
+// PAIRED: the navigation wave also runs the reward phase (pair_finish_nav above); one-wave workgroups, nb a
+// multiple of 8 (+ pair_skew idle workgroups between the roles in the coherence tests).
+#ifndef AUV_PAIR_WT
+#define AUV_PAIR_WT 1   // (0: plain stores in the paired launch -- a measurement build only, see pair_finish)
+#endif
+template <bool PAIRED>
+__global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(AuvDev dk, float* __restrict__ obs_out,
+                                                                                 float* __restrict__ reward_out,
+                                                                                 uint8_t* __restrict__ done_out) {
+  // (every table through the device-side copy AuvDev::self instead of the kernel arguments -- no scalar register
+  // spilled any more -- was tried for the whole kernel: the loads then sit on the dependent chains, 36.3 -> 42.2 us)
+  const AuvDev& d = dk;
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int S = d.cfg.n_sensors;
   const int wpb = blockDim.x / AUV_WAVE;                            // waves per workgroup
-  const int nb = (d.n + wpb - 1) / wpb;                             // LiDAR workgroups: one env per wave
+  const int nb = PAIRED ? 8 * ((d.n + 7) / 8) : (d.n + wpb - 1) / wpb;   // LiDAR workgroups: one env per wave
+  const int nav0 = PAIRED ? nb + dk.pair_skew : nb;                 // first navigation workgroup
   const bool nav_role = (int)blockIdx.x >= nb;                      // workgroup-uniform
+  constexpr bool WT = PAIRED && AUV_PAIR_WT;
   unsigned char* slice = smem + wave * k2_slice_bytes(S, d.k_max, d.m_max);
   if (nav_role) {
-    const int e = auv_uniform(((int)blockIdx.x - nb) * wpb + wave);
-    if (e >= d.n) return;
+    const int e = auv_uniform(((int)blockIdx.x - nav0) * wpb + wave);
+    if (e < 0 || e >= d.n) return;
 #ifdef AUV_STAMPS
     const unsigned long long t_nav0 = wall_clock64();
 #endif
-    k3_nav_env(d, e, lane, slice, obs_out);
+    NavOut no;
+    no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
+    PairPre pp;
+    if constexpr (PAIRED) pp = pair_prefetch(d, e);
+    k3_nav_env(d, e, lane, slice, obs_out, nullptr, nullptr, PAIRED ? &no : nullptr);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 12] = t_nav0, d.stamps[(size_t)e * 16 + 13] = wall_clock64();
+#endif
+    if constexpr (PAIRED) pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
+#ifdef AUV_STAMPS
+    if (PAIRED && lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();     // end of the navigation wave incl. its finish
 #endif
   } else {
     const int e = auv_uniform((int)blockIdx.x * wpb + wave);
     if (e >= d.n) return;
     // next action slot of a captured graph's ring: the dynamics kernel of this step has read the position, the
     // one of the next step has not been launched yet
-    if (e == 0 && lane == 0 && d.ring_slots > 1 && d.ring_slot_host == -1) *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
+    if (e == 0 && lane == 0 && dk.ring_slots > 1 && dk.ring_slot_host == -1) *dk.ring_pos = (*dk.ring_pos + 1) % dk.ring_slots;
     const Slice L = carve(slice, S, d.k_max, d.m_max);
     AUV_STAMP_DECL
 #ifdef AUV_STAMPS
     const unsigned long long t_real0 = wall_clock64();
 #endif
-    const int n_act = k2_front(d, e, lane, L, 1);
+    const int n_act = k2_front<WT>(d, e, lane, L, 1);
     if (d.cfg.use_lidar) {
       AUV_STAMP()
 #ifdef AUV_STAMPS
       unsigned long long sub[4] = {0, 0, 0, 0};
       k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e], sub);
-      if (lane == 0) d.stamps[(size_t)e * 16 + 7] = sub[0], d.stamps[(size_t)e * 16 + 14] = sub[1], d.stamps[(size_t)e * 16 + 15] = sub[2], d.stamps[(size_t)e * 16 + 6] = sub[3];
+      if (lane == 0 && !PAIRED) d.stamps[(size_t)e * 16 + 7] = sub[0], d.stamps[(size_t)e * 16 + 14] = sub[1], d.stamps[(size_t)e * 16 + 15] = sub[2], d.stamps[(size_t)e * 16 + 6] = sub[3];
 #else
       k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
 #endif
       AUV_STAMP()
-      k2_back(d, e, lane, L, n_act, obs_out);
+      double term = 0.0;
+      const int collision = k2_back<WT>(d, e, lane, L, n_act, obs_out, &term);
       AUV_STAMP()
       AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
 #ifdef AUV_STAMPS
       if (lane == 0) d.stamps[(size_t)e * 16 + 3] = t_real0, d.stamps[(size_t)e * 16 + 4] = wall_clock64();
       if (lane == 0) d.stamps[(size_t)e * 16 + 5] = (unsigned long long)L.sbase[n_act];
+#endif
+      if constexpr (PAIRED) pair_publish_lidar(d, e, lane, collision, term);
+#ifdef AUV_STAMPS
+      if (PAIRED && lane == 0) d.stamps[(size_t)e * 16 + 14] = wall_clock64();   // end of the LiDAR wave incl. its finish
 #endif
     }
   }
@@ -283,7 +406,19 @@ void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0,
   const int wpb = k23_wpb();
   const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * wpb;
   const int nb = (d.n + wpb - 1) / wpb;
-  hipExtLaunchKernelGGL(k23_lidar_nav, dim3(2 * nb), dim3(AUV_WAVE * wpb), (uint32_t)lds, st, ev0, ev1, 0, d, obs);
+  hipExtLaunchKernelGGL(k23_lidar_nav<false>, dim3(2 * nb), dim3(AUV_WAVE * wpb), (uint32_t)lds, st, ev0, ev1, 0, d, obs,
+                        (float*)nullptr, (uint8_t*)nullptr);
+}
+
+// ... with the reward phase run by the second of an environment's two waves (the paired step; needs a LiDAR sweep)
+bool auv_paired_ok(const AuvDev& d) { return auv_k23_ok(d) && d.cfg.use_lidar; }
+
+void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0,
+                           hipEvent_t ev1) {
+  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const int nb = 8 * ((d.n + 7) / 8);
+  hipExtLaunchKernelGGL(k23_lidar_nav<true>, dim3(2 * nb + d.pair_skew), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs,
+                        reward, done);
 }
 
 // ---- launches of the two-kernel step ----
@@ -318,7 +453,9 @@ hipError_t auv_step_fused_prepare(const AuvDev& d) {
   }
   const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
   if (b <= 64 * 1024) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k23_lidar_nav<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;

@@ -250,7 +250,7 @@ def test_step_modes_agree_bitwise(dtype):
     cfg = effective_reference_config(use_lidar=True)
     cfg.episode.max_timesteps = 9
     envs = []
-    for mode in ("two_kernels", "side_by_side", "one_kernel", "two_streams"):
+    for mode in ("two_kernels", "side_by_side", "one_kernel", "two_streams", "paired"):
         e = _env(cfg, bank, n)
         e.set_step_mode(mode)
         e.reset()
@@ -260,11 +260,50 @@ def test_step_modes_agree_bitwise(dtype):
         a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=dtype, device="cuda:0")
         outs = [e.step(a)[:3] for e in envs]
         torch.cuda.synchronize()
-        for other in (1, 2, 3):
+        for other in (1, 2, 3, 4):
             for x, y in zip(outs[0], outs[other]):
                 assert torch.equal(x, y)
             for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO"):
                 assert torch.equal(envs[0].read(f), envs[other].read(f)), f
+
+
+@pytest.mark.parametrize("skew", [0, 3])
+def test_paired_step_bitwise_with_many_resets(skew, monkeypatch):
+    """The paired step (the second of an environment's two waves runs the reward phase inside the side-by-side
+    launch) against the three-launch default, bit for bit, over short episodes: every environment is restored many
+    times, by whichever of its two waves ends last.  skew = 3 puts the two roles of an environment on DIFFERENT
+    XCDs (three idle workgroups between them), so the hand-over and the restore rows cross L2s; skew = 0 is the
+    production placement (same XCD)."""
+    n = 1024
+    bank = _mixed_bank(32)
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.episode.max_timesteps = 5
+    ref = _env(cfg, bank, n)
+    ref.set_step_mode("side_by_side")
+    ref.reset()
+    monkeypatch.setenv("AUV_PAIR_SKEW", str(skew))
+    par = _env(cfg, bank, n)
+    par.set_step_mode("paired")
+    par.reset()
+    rs = np.random.RandomState(17 + skew)
+    fields = ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO",
+              "WORLD_IDX", "CULL_LIMITS", "COLLISION", "REWARD64")
+    n_done = 0
+    for k in range(60):
+        a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=torch.float32, device="cuda:0")
+        o0, r0, d0, _ = ref.step(a)
+        o1, r1, d1, _ = par.step(a)
+        torch.cuda.synchronize()
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1), k
+        n_done += int(d0.sum())
+        if k % 7 == 0 or k == 59:
+            for f in fields:
+                assert torch.equal(ref.read(f), par.read(f)), (k, f)
+    assert n_done >= 10 * n                      # every environment ended (and was restored) ten times or more
+    ms = par.step_timed(a)
+    ref.step(a)
+    torch.cuda.synchronize()
+    assert ms[2] == 0.0 and len(par.timed_kernel_names()) == 2 and torch.equal(ref.obs, par.obs)
 
 
 def test_action_ring_graph_and_eager_after_capture():
