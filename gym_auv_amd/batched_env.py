@@ -84,7 +84,7 @@ class BatchedAuvEnv:
             self.reward = torch.zeros((self.n_envs,), dtype=torch.float32, device=self.device)
             self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
         self._graph_actions = None
-        self.step_mode = "paired"
+        self.step_mode = "one_launch"
 
     # ------------------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -155,7 +155,7 @@ class BatchedAuvEnv:
     def _lazy_info(self):
         return _LazyInfo(self)
 
-    STEP_MODES = {"side_by_side": 0, "one_kernel": 1, "two_streams": 2, "two_kernels": 3, "paired": 4}
+    STEP_MODES = {"side_by_side": 0, "one_kernel": 1, "two_streams": 2, "two_kernels": 3, "paired": 4, "one_launch": 5}
 
     def set_step_mode(self, mode: str):
         """"side_by_side": K1 -> [K2 + K3-nav in one launch] -> K3-reward; "paired": the same without the third
@@ -218,6 +218,8 @@ class BatchedAuvEnv:
     def timed_kernel_names(self):
         if self.step_mode == "two_kernels":
             return ["k1n_dyn_nav", "k2r_lidar_reward"]
+        if self.step_mode == "one_launch" and self.config.vessel.use_lidar:
+            return ["k_step_roles"]
         if self.step_mode == "paired" and self.config.vessel.use_lidar:
             return ["k1_dynamics", "k23_lidar_nav_paired"]      # (the kernel trace calls it k23_lidar_nav<true>)
         return ["k1_dynamics", "k23_lidar_nav", "k3_reward"]

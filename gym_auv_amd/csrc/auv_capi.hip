@@ -37,6 +37,9 @@ void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, floa
                            hipStream_t st);
 bool auv_two_kernel_ok(const AuvDev& d);
 bool auv_paired_ok(const AuvDev& d);
+bool auv_roles_ok(const AuvDev& d);
+void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, unsigned long long seq, float* obs, float* reward,
+                           uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
                            hipEvent_t ev1 = nullptr);
 void auv_launch_k1n(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr,
@@ -76,6 +79,7 @@ struct auv_handle {
   hipGraphExec_t graph_exec;
   int step_mode;                 // AUV_STEP_* (include/auv_hip.h)
   int32_t* pair_error_host;      // pinned, mapped: set by a navigation wave of the paired step that gave up polling
+  unsigned long long step_seq;   // one-launch step: sequence number of the last launch
   hipEvent_t ev[6];
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
@@ -178,6 +182,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.step_info, n * 4);
   rc |= dev_alloc(ep, &d.pose_cs, n);
   rc |= dev_alloc(ep, &d.pair_word, n);
+  rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
   rc |= dev_alloc(ep, &d.stamps, n * 16);
@@ -286,7 +291,7 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->graph = nullptr;
   h->graph_exec = nullptr;
   h->cap_stream = nullptr;
-  h->step_mode = AUV_STEP_PAIRED;
+  h->step_mode = AUV_STEP_ONE_LAUNCH;
   h->gen_worlds = 0;
   h->aux_stream = nullptr;
   h->ev_fork = h->ev_join = nullptr;
@@ -613,7 +618,12 @@ static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, flo
     auv_launch_k2r(d, obs, reward, done, st);
     return AUV_OK;
   }
-  if (h->step_mode == AUV_STEP_PAIRED && auv_paired_ok(d)) {
+  if (h->step_mode == AUV_STEP_ONE_LAUNCH && !capturing && auv_roles_ok(d)) {
+    // dynamics, LiDAR and navigation + reward as three roles of ONE launch (csrc/k_step_fused.hip: k_step_roles)
+    auv_launch_step_roles(d, actions, dtype, ++h->step_seq, obs, reward, done, st);
+    return AUV_OK;
+  }
+  if ((h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) && auv_paired_ok(d)) {
     // K1 -> [K2 and K3-nav side by side, the second of an environment's two waves runs K3-reward]: two launches
     auv_launch_k1(d, actions, dtype, st);
     auv_launch_k23_paired(d, obs, reward, done, st);   // (advances a captured graph's action ring)
@@ -667,7 +677,7 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
 
 int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   if (!h) return fail(AUV_EINVAL, "null handle");
-  if (mode < 0 || mode > 4) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
+  if (mode < 0 || mode > 5) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
   h->step_mode = mode;
   {
     // test hook of the paired step: AUV_PAIR_SKEW=k leaves k idle workgroups between the two roles, which puts an
@@ -794,7 +804,8 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
   // sweep: the shapes whose reward kernel maps lanes to environments)
   // (also for the paired shape: inside a graph of several steps the fused reward + dynamics launch is worth more than
   // the paired finish -- 97.2 M against 95.5 M env-steps/s at 16 steps per graph -- and the bits are the same)
-  const bool fuse = n_steps > 1 && (h->step_mode == AUV_STEP_SIDE_BY_SIDE || h->step_mode == AUV_STEP_PAIRED) &&
+  const bool fuse = n_steps > 1 &&
+                    (h->step_mode == AUV_STEP_SIDE_BY_SIDE || h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) &&
                     auv_k23_ok(h->d) && h->d.cfg.use_lidar;
   const int mode_was = h->step_mode;
   if (fuse) h->step_mode = AUV_STEP_SIDE_BY_SIDE;
@@ -834,7 +845,10 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
     auv_launch_k1n(d, actions_dev, action_dtype, obs_dev, st, h->ev[0], h->ev[1]);
     auv_launch_k2r(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
     nk = 2;
-  } else if (h->step_mode == AUV_STEP_PAIRED && auv_paired_ok(d)) {
+  } else if (h->step_mode == AUV_STEP_ONE_LAUNCH && auv_roles_ok(d)) {
+    auv_launch_step_roles(d, actions_dev, action_dtype, ++h->step_seq, obs_dev, reward_dev, done_dev, st, h->ev[0], h->ev[1]);
+    nk = 1;
+  } else if ((h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) && auv_paired_ok(d)) {
     auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
     auv_launch_k23_paired(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
     nk = 2;
@@ -847,7 +861,7 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventSynchronize(h->ev[2 * nk - 1]));
-  out_ms4[2] = 0.0f;
+  out_ms4[1] = out_ms4[2] = 0.0f;
   for (int i = 0; i < nk; i++) HIP_TRY(hipEventElapsedTime(&out_ms4[i], h->ev[2 * i], h->ev[2 * i + 1]));
   HIP_TRY(hipEventElapsedTime(&out_ms4[3], h->ev[0], h->ev[2 * nk - 1]));   // whole step, first start to last stop
   return AUV_OK;

@@ -78,6 +78,7 @@ struct AuvDev {
   double2* pose_cs;    // [N] cos, sin of the heading K1 has just produced (K1 -> LiDAR within one step only)
   unsigned long long* pair_word; // [N] paired step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
   int32_t* pair_error; // [1] paired step: set when a navigation wave gave up waiting for its sweep
+  unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   int32_t pair_skew;   // paired step, test hook: idle workgroups between the two roles (puts them on different XCDs)
   const struct AuvDev* self;  // this struct in device memory (as of the last bank load): the paired step's restore path
                               // reads its ~25 table pointers through it at the point of use -- as kernel arguments
@@ -111,6 +112,7 @@ struct AuvDev {
 struct EnvPre {
   double s[6];     // x, y, psi, u, v, r after Vessel.step
   int4 cnt;        // t_step, vessel step counter (already incremented), episodes, -
+  const EnvDesc* ed = nullptr;   // the environment's descriptor where the caller has fetched it already
 };
 
 // In-kernel phase stamps (diagnostic build only: make STAMPS=1).  The stamp values leave the

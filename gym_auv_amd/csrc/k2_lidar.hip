@@ -262,44 +262,13 @@ __device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const S
   auv_wave_lds_sync();
 }
 
-// phases A, C, B, S for one environment, by one wave
-// cs_pre: cos / sin of the heading when the dynamics kernel of this step has left them (pose_cs);
-// nullptr = form them here (same function, same argument: the same bits)
+// phase A: movers (obstacles.py:195-233) -- kinematics, then pose and cull-circle centre into LDS.  Needs nothing
+// of the vessel: the one-launch step runs it while the dynamics role is still integrating.
 template <bool WT = false>
-__device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
-                        const EnvPre* pre = nullptr, const double2* cs_pre = nullptr) {
-  const int S = d.cfg.n_sensors;
-  const size_t n = (size_t)d.n;
-  const int4 cnt = pre ? pre->cnt : d.counters[e];
-  const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
-               psi = pre ? pre->s[2] : d.state[2 * n + e];
-  const EnvDesc ed = d.env_desc[e];
-  // cos / sin of the heading for the ray table (phase C): formed right here, as soon as psi is known, so that
-  // the ~100 dependent fp64 instructions are off the chain that follows phase B (the obstacle records were also
-  // requested ahead of it once: 11 more live registers, 10 spilled, and the gain was gone)
-  {
-    double2 cs_in;
-    if (cs_pre) {
-      cs_in = cs_pre[e];
-    } else {
-      double sn, co;
-      sincos(psi, &sn, &co);
-      cs_in = make_double2(co, sn);
-    }
-    if (lane == 0) L.hdr->cpsi = cs_in.x, L.hdr->spsi = cs_in.y;   // (read back after the LDS sync that ends phase B)
-  }
-  const long long k0 = ed.k0;
-  const int K = ed.K;
+__device__ __forceinline__ void k2_movers(const AuvDev& d, const int e, const int lane, const Slice& L, const EnvDesc& ed,
+                                          const int advance_movers) {
   const long long m0 = ed.m0;
   const int M = ed.M;
-  const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
-  const double dangle = 2 * AUV_PI / S;
-  if (lane == 0) {
-    L.hdr->px = px, L.hdr->py = py;
-    L.hdr->n_act = 0;
-  }
-
-  // ---- phase A: movers (obstacles.py:195-233) ---------------------------------------
   for (int m = lane; m < M; m += AUV_WAVE) {
     double4 st = d.mover[(size_t)e * d.m_max + m];
     const double4 par_m = d.mv_param[m0 + m];
@@ -334,6 +303,64 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     L.mvrot[m] = make_double4(c, s, st.x, st.y);   // the pentagon's segments are formed on demand (MoverSegs)
     L.mvw[m] = wd;
   }
+}
+
+// what phase B needs of this lane's obstacle (the first 64 of the world), fetched ahead of time
+struct K2Pre {
+  int4 meta;
+  double cx, cy, rho;
+  uint8_t near;
+};
+__device__ __forceinline__ K2Pre k2_prefetch(const AuvDev& d, const int e, const int lane, const EnvDesc& ed) {
+  K2Pre p;
+  p.meta = make_int4(0, 0, 0, 0), p.cx = p.cy = p.rho = 0.0, p.near = 0;
+  if (lane < ed.K) {
+    p.meta = d.obs_meta[ed.k0 + lane];
+    p.cx = d.obs_cull[3 * (ed.k0 + lane)], p.cy = d.obs_cull[3 * (ed.k0 + lane) + 1], p.rho = d.obs_cull[3 * (ed.k0 + lane) + 2];
+    p.near = d.nearby[(size_t)e * d.k_max + lane];
+  }
+  return p;
+}
+
+// phases A, C, B, S for one environment, by one wave
+// cs_pre: cos / sin of the heading when the dynamics kernel of this step has left them (pose_cs);
+// nullptr = form them here (same function, same argument: the same bits)
+// movers_done / kp: phase A has been run / the first 64 obstacle records have been fetched by the caller already
+template <bool WT = false>
+__device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
+                        const EnvPre* pre = nullptr, const double2* cs_pre = nullptr, const int movers_done = 0,
+                        const K2Pre* kp = nullptr) {
+  const int S = d.cfg.n_sensors;
+  const size_t n = (size_t)d.n;
+  const int4 cnt = pre ? pre->cnt : d.counters[e];
+  const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
+               psi = pre ? pre->s[2] : d.state[2 * n + e];
+  const EnvDesc ed = (pre && pre->ed) ? *pre->ed : d.env_desc[e];
+  // cos / sin of the heading for the ray table (phase C): formed right here, as soon as psi is known, so that
+  // the ~100 dependent fp64 instructions are off the chain that follows phase B (the obstacle records were also
+  // requested ahead of it once: 11 more live registers, 10 spilled, and the gain was gone)
+  {
+    double2 cs_in;
+    if (cs_pre) {
+      cs_in = cs_pre[e];
+    } else {
+      double sn, co;
+      sincos(psi, &sn, &co);
+      cs_in = make_double2(co, sn);
+    }
+    if (lane == 0) L.hdr->cpsi = cs_in.x, L.hdr->spsi = cs_in.y;   // (read back after the LDS sync that ends phase B)
+  }
+  const long long k0 = ed.k0;
+  const int K = ed.K;
+  const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
+  const double dangle = 2 * AUV_PI / S;
+  if (lane == 0) {
+    L.hdr->px = px, L.hdr->py = py;
+    L.hdr->n_act = 0;
+  }
+
+  // ---- phase A: movers (unless the caller has run it already) ----
+  if (!movers_done) k2_movers<WT>(d, e, lane, L, ed, advance_movers);
   if (!d.cfg.use_lidar) return 0;   // lidar_d stays at sensor_range from reset; collision stays 0
 
   // ---- phase B0 (every sensor_interval_load_obstacles-th vessel step, vessel.py:266-273): refresh
@@ -448,10 +475,12 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     const int k = kb + lane;
     bool active = false;
     if (k < K) {
-      const int4 meta = d.obs_meta[k0 + k];
+      const bool have = kp && kb == 0;                     // (the first 64 obstacles were fetched ahead of time)
+      const int4 meta = have ? kp->meta : d.obs_meta[k0 + k];
       const bool mover = meta.x == AUV_OBS_MOVER;
       // static cull circle (unused for movers)
-      const double scx = d.obs_cull[3 * (k0 + k)], scy = d.obs_cull[3 * (k0 + k) + 1], srho = d.obs_cull[3 * (k0 + k) + 2];
+      const double scx = have ? kp->cx : d.obs_cull[3 * (k0 + k)], scy = have ? kp->cy : d.obs_cull[3 * (k0 + k) + 1],
+                   srho = have ? kp->rho : d.obs_cull[3 * (k0 + k) + 2];
       ObsLds o;
       o.kind = meta.x;
       o.seg_off = mover ? meta.w * AUV_MOVER_NSEG : meta.y;
@@ -479,7 +508,8 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
         }
       }
       // (after a write-through refresh the flag is read past the caches; otherwise it is an ordinary load)
-      const uint8_t near = (WT && refresh) ? auv_ld<WT>(&d.nearby[(size_t)e * d.k_max + k]) : d.nearby[(size_t)e * d.k_max + k];
+      const uint8_t near = (WT && refresh) ? auv_ld<WT>(&d.nearby[(size_t)e * d.k_max + k])
+                                           : ((have && !refresh) ? kp->near : d.nearby[(size_t)e * d.k_max + k]);
       int2 lim = make_int2(INT32_MIN, INT32_MIN);
       if (near) {
         int start, stop;

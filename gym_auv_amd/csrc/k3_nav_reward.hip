@@ -377,9 +377,10 @@ struct NavSpec {
 // win_slots: LDS, [3][20] doubles of this wave, or nullptr: the spline windows around last step's arclength
 // (lane 0 will evaluate at s, lanes 1 and 2 at min(L, s + look-ahead)) are parked there
 __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, const int lane, int* list, const double qx,
-                                                 const double qy, const double slack, double* win_slots) {
+                                                 const double qy, const double slack, double* win_slots,
+                                                 const EnvDesc* ed_pre = nullptr) {
   NavSpec sp;
-  sp.ed = d.env_desc[e];
+  sp.ed = ed_pre ? *ed_pre : d.env_desc[e];
   const EnvDesc& ed = sp.ed;
   const double* ws = d.world_scalar + 8 * (size_t)ed.w;
   sp.L = ws[0], sp.goal_x = ws[1], sp.goal_y = ws[2];
@@ -683,7 +684,7 @@ __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const i
   // lengthened the search -- measured 8.8 -> 9.9 us per navigation wave in the side-by-side launch)
   (void)wins;
   const NavSpec sp = nav_speculate(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
-                                   0.0, nullptr);
+                                   0.0, nullptr, pre ? pre->ed : nullptr);
   nav_finish<WT>(d, e, lane, list, obs_out, pre, sp, true, nullptr, pose_cs ? pose_cs + e : nullptr, out);
 }
 

@@ -228,6 +228,119 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
   }
 }
 
+// ---- ONE launch per step: three roles -------------------------------------------------------------
+// k_step_roles   workgroups [0, nk) integrate the dynamics (Vessel.step, one wave = eight environments, eight lanes
+//                each: k1_group), workgroups [nk, nk + nb) sweep the LiDAR of one environment each, the rest navigate
+//                one environment each and run its reward phase (the paired finish above).  The sweep and the
+//                navigation need the state the dynamics role produces in the same launch: it hands each environment
+//                a 64-byte packet (x, y, psi, u, v, r, the vessel's step counter, the step's sequence number), stored
+//                write-through and completed before the sequence number is stored; the other two roles poll for the
+//                sequence number the host passed with the launch (the dynamics workgroups have the smallest indices,
+//                are dispatched first and wait for nobody; the poll is bounded like the paired finish's).  What is
+//                saved is the dynamics kernel's launch ramp and the kernel boundary behind it.  Eager steps only: a
+//                captured graph cannot change the sequence number, it keeps the fused shape.
+// Dynamics wave b takes the environments 8 (8 (b / 8) + g) + b % 8, g = 0..7: the ones whose other two waves run on
+// its own XCD (all three counts are multiples of 8), so the packets stay in one L2.
+__device__ __forceinline__ double pair_lane_value(const unsigned long long v, const int src) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// the state the dynamics role left for environment e in THIS launch (`seq`); false: gave up polling
+__device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, const int lane, const unsigned long long seq,
+                                                 EnvPre& pre) {
+  const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
+  unsigned long long v = 0;
+  for (int polls = 0;; polls++) {
+    v = __hip_atomic_load(pk + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one 64-byte request per wave
+    const unsigned long long got = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 7) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 7);
+    if (got == seq) break;
+    if (polls == PAIR_POLL_LIMIT) {
+      if (lane == 0) __hip_atomic_store(d.pair_error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) pre.s[i] = pair_lane_value(v, i);
+  pre.cnt.y = (int)__builtin_amdgcn_readlane((int)(unsigned)v, 6);   // the vessel's step counter of this launch
+  return true;
+}
+
+template <typename AT>
+__global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvDev dk, const AT* __restrict__ actions,
+                                                                           const unsigned long long seq,
+                                                                           float* __restrict__ obs_out,
+                                                                           float* __restrict__ reward_out,
+                                                                           uint8_t* __restrict__ done_out) {
+  const AuvDev& d = dk;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int S = d.cfg.n_sensors;
+  const int nk = 8 * ((d.n + 63) / 64);                             // dynamics workgroups
+  const int nb = 8 * ((d.n + 7) / 8);                               // LiDAR workgroups
+  const int b = (int)blockIdx.x;
+  if (b < nk) {
+    // ---- Vessel.step of eight environments ----
+    const int g = lane / K1_GROUP, c = lane % K1_GROUP;
+    const int er = 8 * (8 * (b / 8) + g) + (b % 8);
+    const bool live = er < d.n;
+    const int eg = live ? er : d.n - 1;                             // idle groups compute along, store nothing
+    const size_t n = (size_t)d.n;
+    const double t = k1_group<AT>(d, actions, eg, lane);
+    unsigned long long* pk = d.k1_pkt + 8 * (size_t)eg;
+    if (live && c < 6) {
+      auv_st<true>(&d.state[(size_t)c * n + eg], t);
+      __hip_atomic_store(pk + c, (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (live && c == 6) {
+      const int y = d.counters[eg].y + 1;                           // Vessel._step_counter (vessel.py:247)
+      __hip_atomic_store(&d.counters[eg].y, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pk + 6, (unsigned long long)(unsigned)y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    auv_stores_done();
+    if (live && c == 7) __hip_atomic_store(pk + 7, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  EnvPre pre;
+  EnvDesc ed;
+  if (b < nk + nb) {
+    // ---- _update + Vessel.perceive of one environment ----
+    const int e = auv_uniform(b - nk);
+    if (e >= d.n) return;
+    // while the dynamics role integrates: everything of the sweep that does not need the vessel's new state --
+    // descriptor and counters (written by earlier launches), the movers' kinematics, the obstacle records
+    ed = d.env_desc[e];
+    pre.cnt = d.counters[e];                               // t_step, episodes; the step counter comes with the state
+    pre.ed = &ed;
+    const Slice L = carve(smem, S, d.k_max, d.m_max);
+    k2_movers<true>(d, e, lane, L, ed, 1);
+    const K2Pre kp = k2_prefetch(d, e, lane, ed);
+    if (!roles_wait_state(d, e, lane, seq, pre)) return;
+    const int n_act = k2_front<true>(d, e, lane, L, 1, &pre, nullptr, 1, &kp);
+    k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
+    double term = 0.0;
+    const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term);
+    pair_publish_lidar(d, e, lane, collision, term);
+  } else {
+    // ---- Vessel.navigate of one environment, then its reward / done / auto-reset ----
+    const int e = auv_uniform(b - nk - nb - d.pair_skew);
+    if (e < 0 || e >= d.n) return;
+    ed = d.env_desc[e];
+    pre.cnt = d.counters[e];
+    pre.ed = &ed;
+    if (!roles_wait_state(d, e, lane, seq, pre)) return;
+    PairPre pp = pair_prefetch(d, e);
+    pp.cnt = pre.cnt;
+    NavOut no;
+    no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
+    k3_nav_env(d, e, lane, smem, obs_out, &pre, nullptr, &no);
+    pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
+  }
+}
+
 // ---- the default step: TWO launches --------------------------------------------------------------
 // k1n_dyn_nav      Vessel.step for eight environments by ONE wave (eight lanes per environment), then
 //                  Vessel.navigate of those eight by the workgroup's eight waves.  While the
@@ -443,6 +556,20 @@ void auv_launch_k2r(const AuvDev& d, float* obs, float* reward, uint8_t* done, h
   hipExtLaunchKernelGGL(k2r_lidar_reward, dim3(d.n), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs, reward, done);
 }
 
+// ---- the one-launch step (eager only: the sequence number is a launch argument) ----
+bool auv_roles_ok(const AuvDev& d) { return auv_paired_ok(d); }
+
+void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, unsigned long long seq, float* obs, float* reward,
+                           uint8_t* done, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const int nk = 8 * ((d.n + 63) / 64), nb = 8 * ((d.n + 7) / 8);
+  const dim3 grid(nk + 2 * nb + d.pair_skew), block(AUV_WAVE);
+  if (dtype == AUV_F64)
+    hipExtLaunchKernelGGL(k_step_roles<double>, grid, block, lds, st, ev0, ev1, 0, d, (const double*)actions, seq, obs, reward, done);
+  else
+    hipExtLaunchKernelGGL(k_step_roles<float>, grid, block, lds, st, ev0, ev1, 0, d, (const float*)actions, seq, obs, reward, done);
+}
+
 hipError_t auv_step_fused_prepare(const AuvDev& d) {
   {
     const size_t b1 = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
@@ -456,6 +583,10 @@ hipError_t auv_step_fused_prepare(const AuvDev& d) {
   hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k23_lidar_nav<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_step_roles<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_step_roles<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;

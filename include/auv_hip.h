@@ -211,7 +211,8 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
  *   AUV_STEP_ONE_KERNEL              the whole step in one kernel, one wave per env running
  *                                    K1 -> K3-nav -> K2 -> K3-reward back to back.
  *   AUV_STEP_TWO_STREAMS             K1 -> { K2 || K3-nav on an auxiliary stream } -> K3-reward. */
-enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2, AUV_STEP_TWO_KERNELS = 3, AUV_STEP_PAIRED = 4 };
+enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2, AUV_STEP_TWO_KERNELS = 3, AUV_STEP_PAIRED = 4,
+       AUV_STEP_ONE_LAUNCH = 5 };
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
 
 /* One step with every dispatch stamped with its own start / stop HIP event on `stream` (the kernel's

@@ -250,7 +250,7 @@ def test_step_modes_agree_bitwise(dtype):
     cfg = effective_reference_config(use_lidar=True)
     cfg.episode.max_timesteps = 9
     envs = []
-    for mode in ("two_kernels", "side_by_side", "one_kernel", "two_streams", "paired"):
+    for mode in ("two_kernels", "side_by_side", "one_kernel", "two_streams", "paired", "one_launch"):
         e = _env(cfg, bank, n)
         e.set_step_mode(mode)
         e.reset()
@@ -260,15 +260,16 @@ def test_step_modes_agree_bitwise(dtype):
         a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=dtype, device="cuda:0")
         outs = [e.step(a)[:3] for e in envs]
         torch.cuda.synchronize()
-        for other in (1, 2, 3, 4):
+        for other in (1, 2, 3, 4, 5):
             for x, y in zip(outs[0], outs[other]):
                 assert torch.equal(x, y)
             for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO"):
                 assert torch.equal(envs[0].read(f), envs[other].read(f)), f
 
 
+@pytest.mark.parametrize("mode", ["paired", "one_launch"])
 @pytest.mark.parametrize("skew", [0, 3])
-def test_paired_step_bitwise_with_many_resets(skew, monkeypatch):
+def test_paired_step_bitwise_with_many_resets(skew, mode, monkeypatch):
     """The paired step (the second of an environment's two waves runs the reward phase inside the side-by-side
     launch) against the three-launch default, bit for bit, over short episodes: every environment is restored many
     times, by whichever of its two waves ends last.  skew = 3 puts the two roles of an environment on DIFFERENT
@@ -283,7 +284,7 @@ def test_paired_step_bitwise_with_many_resets(skew, monkeypatch):
     ref.reset()
     monkeypatch.setenv("AUV_PAIR_SKEW", str(skew))
     par = _env(cfg, bank, n)
-    par.set_step_mode("paired")
+    par.set_step_mode(mode)
     par.reset()
     rs = np.random.RandomState(17 + skew)
     fields = ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO",
@@ -303,7 +304,7 @@ def test_paired_step_bitwise_with_many_resets(skew, monkeypatch):
     ms = par.step_timed(a)
     ref.step(a)
     torch.cuda.synchronize()
-    assert ms[2] == 0.0 and len(par.timed_kernel_names()) == 2 and torch.equal(ref.obs, par.obs)
+    assert ms[2] == 0.0 and len(par.timed_kernel_names()) == (2 if mode == "paired" else 1) and torch.equal(ref.obs, par.obs)
 
 
 def test_action_ring_graph_and_eager_after_capture():
