@@ -222,7 +222,13 @@ __device__ __forceinline__ int inside_flag_wave(double px, double py, SegPtr g, 
 // ---- phase C: ray vectors, vessel.py:66-68, :317 (only if some obstacle has rays to test) ----
 // cos / sin of (beam angle + psi) by the addition theorem from the per-config table of beam
 // angles (built at load time): one sincos per environment instead of one per ray
-__device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const Slice& L) {
+// `staged`: the table entries are in the ray slots already (k2_stage_beams, run ahead of time by the one-launch step)
+__device__ __forceinline__ void k2_stage_beams(const AuvDev& d, const int lane, const Slice& L) {
+  const int S = d.cfg.n_sensors;
+  for (int i = lane; i < S; i += AUV_WAVE) L.rayv[i] = d.beam_cs[i];
+}
+
+__device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const Slice& L, const bool staged = false) {
   const int S = d.cfg.n_sensors;
   const double R = d.cfg.sensor_range;
   const double px = L.hdr->px, py = L.hdr->py;
@@ -234,7 +240,7 @@ __device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const S
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int i = q * AUV_WAVE + lane;
-      b[q] = d.beam_cs[i < S ? i : 0];                      // cos, sin of -pi + (i + 1) * dangle
+      b[q] = staged ? L.rayv[i < S ? i : 0] : d.beam_cs[i < S ? i : 0];   // cos, sin of -pi + (i + 1) * dangle
     }
     cos_psi = L.hdr->cpsi, sin_psi = L.hdr->spsi;
 #pragma unroll
@@ -252,7 +258,7 @@ __device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const S
   } else {
     cos_psi = L.hdr->cpsi, sin_psi = L.hdr->spsi;
     for (int i = lane; i < S; i += AUV_WAVE) {
-      const double2 b = d.beam_cs[i];
+      const double2 b = staged ? L.rayv[i] : d.beam_cs[i];
       const double c = cos_psi * b.x - sin_psi * b.y, s = sin_psi * b.x + cos_psi * b.y;
       double ex = px + c * R, ey = py + s * R;
       L.rayv[i] = make_double2(ex - px, ey - py);
@@ -329,7 +335,7 @@ __device__ __forceinline__ K2Pre k2_prefetch(const AuvDev& d, const int e, const
 template <bool WT = false>
 __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
                         const EnvPre* pre = nullptr, const double2* cs_pre = nullptr, const int movers_done = 0,
-                        const K2Pre* kp = nullptr) {
+                        const K2Pre* kp = nullptr, const bool beams_staged = false) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const int4 cnt = pre ? pre->cnt : d.counters[e];
@@ -610,7 +616,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     if (lane == 0) L.sbase[0] = 0;
   }
   if (n_act == 0) return 0;                                  // nothing in sight: no rays, no sweep (k2_back writes the free row)
-  k2_rays(d, lane, L);                                       // phase C
+  k2_rays(d, lane, L, beams_staged);                         // phase C
   return n_act;
 }
 

@@ -239,6 +239,10 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
 //                are dispatched first and wait for nobody; the poll is bounded like the paired finish's).  What is
 //                saved is the dynamics kernel's launch ramp and the kernel boundary behind it.  Eager steps only: a
 //                captured graph cannot change the sequence number, it keeps the fused shape.
+// (Tried and dropped: the sweep waves also running the navigation's search over the chunk circles for the old pose
+// while they wait, handing the survivor list to the navigation wave in one word -- the navigation wave gets 2.5 us
+// shorter, but the extra traffic and issue slots stretch the dynamics role's chain from 6 to 7.5 us and the whole
+// launch waits for that: 98.4 M against 101.9 M env-steps/s.)
 // Dynamics wave b takes the environments 8 (8 (b / 8) + g) + b % 8, g = 0..7: the ones whose other two waves run on
 // its own XCD (all three counts are multiples of 8), so the packets stay in one L2.
 __device__ __forceinline__ double pair_lane_value(const unsigned long long v, const int src) {
@@ -251,6 +255,9 @@ __device__ __forceinline__ double pair_lane_value(const unsigned long long v, co
 __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, const int lane, const unsigned long long seq,
                                                  EnvPre& pre) {
   const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
+  // (polling harder does not pay: with two requests in flight per wave the packet is noticed sooner, but the
+  // traffic of 3500 polling waves slows the dynamics role down by more -- 102.3 M against 104.7 M env-steps/s;
+  // keeping the early waves quiet until the dynamics are about due moved every workload by +-2 % in no pattern)
   unsigned long long v = 0;
   for (int polls = 0;; polls++) {
     v = __hip_atomic_load(pk + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one 64-byte request per wave
@@ -284,11 +291,14 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
   const int b = (int)blockIdx.x;
   if (b < nk) {
     // ---- Vessel.step of eight environments ----
+    // (everybody else in the launch waits for these 512 waves: they go first wherever they share a SIMD)
+    __builtin_amdgcn_s_setprio(3);
     const int g = lane / K1_GROUP, c = lane % K1_GROUP;
     const int er = 8 * (8 * (b / 8) + g) + (b % 8);
     const bool live = er < d.n;
     const int eg = live ? er : d.n - 1;                             // idle groups compute along, store nothing
     const size_t n = (size_t)d.n;
+    const int y = d.counters[eg].y + 1;                             // Vessel._step_counter (vessel.py:247); requested up front
     const double t = k1_group<AT>(d, actions, eg, lane);
     unsigned long long* pk = d.k1_pkt + 8 * (size_t)eg;
     if (live && c < 6) {
@@ -296,13 +306,18 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
       __hip_atomic_store(pk + c, (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (live && c == 6) {
-      const int y = d.counters[eg].y + 1;                           // Vessel._step_counter (vessel.py:247)
       __hip_atomic_store(&d.counters[eg].y, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(pk + 6, (unsigned long long)(unsigned)y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     auv_stores_done();
     if (live && c == 7) __hip_atomic_store(pk + 7, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
+#ifdef AUV_STAMPS
+    if (live && c == 0) d.stamps[(size_t)eg * 16 + 0] = wall_clock64();   // the state of this environment is out
+#endif
+    return;   // (carrying on as the LiDAR wave of an environment instead of handing the slot to a fresh workgroup was
+              // tried: the merged code path costs more scalar-register spills than the later start of 512 sweeps: -2.5 %.
+              // So was the scalar form of the integrator, lanes <-> environments, on 64 waves instead of 512: its
+              // chain is 3 us longer and everybody waits for it, 97.2 M against 104.7 M env-steps/s.)
   }
   EnvPre pre;
   EnvDesc ed;
@@ -312,18 +327,36 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     if (e >= d.n) return;
     // while the dynamics role integrates: everything of the sweep that does not need the vessel's new state --
     // descriptor and counters (written by earlier launches), the movers' kinematics, the obstacle records
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 3] = wall_clock64();
+#endif
     ed = d.env_desc[e];
     pre.cnt = d.counters[e];                               // t_step, episodes; the step counter comes with the state
     pre.ed = &ed;
     const Slice L = carve(smem, S, d.k_max, d.m_max);
     k2_movers<true>(d, e, lane, L, ed, 1);
     const K2Pre kp = k2_prefetch(d, e, lane, ed);
+    k2_stage_beams(d, lane, L);
+    // (also tried here: warming the caches with the nearby obstacles' boundary segments -- it has to wait for the
+    // obstacle records, and its traffic delays the dynamics role: 102.1 M against 104.5 M env-steps/s without)
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 1] = wall_clock64();
+#endif
     if (!roles_wait_state(d, e, lane, seq, pre)) return;
-    const int n_act = k2_front<true>(d, e, lane, L, 1, &pre, nullptr, 1, &kp);
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 2] = wall_clock64();
+#endif
+    const int n_act = k2_front<true>(d, e, lane, L, 1, &pre, nullptr, 1, &kp, true);
     k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
     double term = 0.0;
     const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term);
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 4] = wall_clock64();
+#endif
     pair_publish_lidar(d, e, lane, collision, term);
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 14] = wall_clock64();
+#endif
   } else {
     // ---- Vessel.navigate of one environment, then its reward / done / auto-reset ----
     const int e = auv_uniform(b - nk - nb - d.pair_skew);
@@ -331,13 +364,25 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     ed = d.env_desc[e];
     pre.cnt = d.counters[e];
     pre.ed = &ed;
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 12] = wall_clock64();
+#endif
     if (!roles_wait_state(d, e, lane, seq, pre)) return;
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 5] = wall_clock64();
+#endif
     PairPre pp = pair_prefetch(d, e);
     pp.cnt = pre.cnt;
     NavOut no;
     no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
     k3_nav_env(d, e, lane, smem, obs_out, &pre, nullptr, &no);
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
+#endif
     pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();
+#endif
   }
 }
 
