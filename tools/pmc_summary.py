@@ -18,7 +18,7 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split()[-1]
         agg[k].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        if any(t in k for t in ("k1_", "k2_", "k3_", "k23_")):
+        if any(t in k for t in ("k1_", "k2_", "k3_", "k23_", "k_step")):
             res[k][name + "_KiB_per_launch_median"] = float(np.median(v))
             res[k]["launches"] = len(v)
 for k, v in res.items():

@@ -25,8 +25,8 @@ traffic = {clean(k): v["bytes_reads_doubled"] for k, v in pmc.items() if "fresh"
 raw = {clean(k): v["bytes_raw"] for k, v in pmc.items() if "fresh" not in k}
 tpath = os.path.join(root, "profiles", "pmc_traffic.json")
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-t[workload] = traffic
-t[workload + "_raw"] = raw
+t.setdefault(workload, {}).update(traffic)            # (kernels of launch shapes profiled in earlier runs stay)
+t.setdefault(workload + "_raw", {}).update(raw)
 t["_note"] = ("HBM bytes per launch at 4096 envs per GPU from SEPARATE rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes "
               "(tools/run_profiles.sh; profiles/%s/pmc_summary.json).  <workload>: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 "
               "correction of MI355X_MICROARCH.md for wide coalesced reads (FETCH_SIZE counts 64 B per 128-B request); "
@@ -36,7 +36,7 @@ json.dump(t, open(tpath, "w"), indent=1)
 sq = json.load(open(os.path.join(run, "pmc_sq_summary.json")))
 spath = os.path.join(root, "profiles", "pmc_sq.json")
 s = json.load(open(spath)) if os.path.exists(spath) else {}
-s[workload] = {clean(k): {c: v[c] for c in v if c.startswith("SQ_") or c == "launches"} for k, v in sq.items()}
+s.setdefault(workload, {}).update({clean(k): {c: v[c] for c in v if c.startswith("SQ_") or c == "launches"} for k, v in sq.items()})
 s["_note"] = ("SQ counters per launch (medians) at 4096 envs per GPU from one rocprofv3 --pmc pass, steady state (steps 1900-2200 of "
               "the headline run), tools/run_profiles.sh; profiles/%s/pmc_sq_summary.json.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* "
               "count quad-cycles summed over waves, SQ_INSTS_* wave-instructions, SQ_BUSY_CYCLES busy cycles summed over the 32 shader "

@@ -14,6 +14,8 @@ echo "headline: $(cut -c1-120 $OUT/bench_polygons50.json)"
 python bench.py --gpus 1 --steps 20 --warmup 5 --bank-cache /tmp/bank --cpu-baseline 0 > $OUT/bench_driver_command.json 2>/dev/null
 $B --graph 16 --cpu-baseline 0 > $OUT/bench_polygons50_graph16.json 2>/dev/null
 $B --worlds-per-env 1 --cpu-baseline 0 > $OUT/bench_polygons50_worlds1.json 2>/dev/null
+$B --step-mode paired --cpu-baseline 0 > $OUT/bench_polygons50_paired.json 2>/dev/null
+$B --step-mode side_by_side --cpu-baseline 0 > $OUT/bench_polygons50_side_by_side.json 2>/dev/null
 $B --step-mode two_kernels --cpu-baseline 0 > $OUT/bench_polygons50_two_kernels.json 2>/dev/null
 $B --step-mode two_streams --cpu-baseline 0 > $OUT/bench_polygons50_two_streams.json 2>/dev/null
 $B --step-mode one_kernel --cpu-baseline 0 > $OUT/bench_polygons50_one_kernel.json 2>/dev/null

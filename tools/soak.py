@@ -13,7 +13,7 @@ from oracle import pyoracle
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-mode = sys.argv[3] if len(sys.argv) > 3 else "side_by_side"
+mode = sys.argv[3] if len(sys.argv) > 3 else "one_launch"
 specs = []
 for i in range(96):
     specs.append([moving_obstacles_world, lambda s: static_circles_world(s, 20), lambda s: polygon_world(s, 50),
