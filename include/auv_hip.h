@@ -201,8 +201,21 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
 int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 
 /* How auv_step / auv_graph_capture run a step (same results, bit for bit):
- *   AUV_STEP_SIDE_BY_SIDE (default)  K1 -> one launch whose workgroups do K2 for all envs and
- *                                    K3-nav for all envs side by side -> K3-reward; one stream.
+ *   AUV_STEP_ONE_LAUNCH (default)    the whole step in ONE launch of one-wave workgroups with three roles: the
+ *                                    first n / 8 integrate the dynamics (K1, eight environments per wave), the
+ *                                    next n sweep the LiDAR of one environment each (K2), the last n navigate one
+ *                                    environment each (K3-nav) and run its reward / done / auto-reset (K3-reward).
+ *                                    The roles hand their results on inside the launch through per-environment
+ *                                    words stored and loaded coherently (csrc/k_step_fused.hip: k_step_roles,
+ *                                    pair_finish_nav); waves that need a result poll for it, bounded -- if a
+ *                                    poll ever runs out, every later auv_step / auv_graph_launch / auv_step_timed
+ *                                    fails with AUV_ESTATE.  Needs the LiDAR on; without it, and inside a
+ *                                    captured graph, the step falls back to the shapes below.
+ *   AUV_STEP_PAIRED                  K1 -> one launch whose workgroups do K2 for all envs and K3-nav for all envs
+ *                                    side by side, the navigation wave also running K3-reward.  Two launches.
+ *   AUV_STEP_SIDE_BY_SIDE            K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward; inside a
+ *                                    captured graph of several steps K3-reward of step t and K1 of step t + 1
+ *                                    share a launch (also what a graph captured in the two modes above uses).
  *   AUV_STEP_TWO_KERNELS             [K1 -> K3-nav] -> [K2 -> K3-reward]: Vessel.step of eight
  *                                    environments by one wave while the workgroup's other eight run
  *                                    their navigation's search against the pose before the step;
@@ -216,9 +229,11 @@ enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS 
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
 
 /* One step with every dispatch stamped with its own start / stop HIP event on `stream` (the kernel's
- * own duration, as a kernel trace reports it).  In AUV_STEP_TWO_KERNELS mode
- * out_ms[0..3] = [K1 + K3-nav], [K2 + K3-reward], 0, whole step (first start .. last stop); in any
- * other mode the side-by-side shape is timed: K1, [K2 + K3-nav], K3-reward, whole step.          */
+ * own duration, as a kernel trace reports it).  out_ms[0..3] by mode:
+ *   AUV_STEP_ONE_LAUNCH   the one launch, 0, 0, whole step
+ *   AUV_STEP_PAIRED       K1, [K2 + K3-nav + K3-reward], 0, whole step (first start .. last stop)
+ *   AUV_STEP_TWO_KERNELS  [K1 + K3-nav], [K2 + K3-reward], 0, whole step
+ *   any other mode        the side-by-side shape is timed: K1, [K2 + K3-nav], K3-reward, whole step. */
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                    float* reward_dev, uint8_t* done_dev, void* stream, float* out_ms4);
 
