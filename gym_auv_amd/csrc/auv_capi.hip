@@ -38,8 +38,8 @@ void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, floa
 bool auv_two_kernel_ok(const AuvDev& d);
 bool auv_paired_ok(const AuvDev& d);
 bool auv_roles_ok(const AuvDev& d);
-void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, unsigned long long seq, float* obs, float* reward,
-                           uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
+                           hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
                            hipEvent_t ev1 = nullptr);
 void auv_launch_k1n(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr,
@@ -79,7 +79,6 @@ struct auv_handle {
   hipGraphExec_t graph_exec;
   int step_mode;                 // AUV_STEP_* (include/auv_hip.h)
   int32_t* pair_error_host;      // pinned, mapped: set by a navigation wave of the paired step that gave up polling
-  unsigned long long step_seq;   // one-launch step: sequence number of the last launch
   hipEvent_t ev[6];
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
@@ -183,6 +182,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.pose_cs, n);
   rc |= dev_alloc(ep, &d.pair_word, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
+  rc |= dev_alloc(ep, &d.k1_done, 4);
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
   rc |= dev_alloc(ep, &d.stamps, n * 16);
@@ -222,6 +222,9 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
       *h->pair_error_host = 0;
       HIP_TRY(hipHostGetDevicePointer((void**)&d.pair_error, h->pair_error_host, 0));
     }
+    *h->pair_error_host = 0;   // (a new bank starts with a clean slate; see PAIR_CHECK)
+    HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d.k1_done, 0, sizeof(int32_t)));
   }
   d.w_ready = 0;
   auv_launch_derive(d, nullptr);
@@ -618,9 +621,10 @@ static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, flo
     auv_launch_k2r(d, obs, reward, done, st);
     return AUV_OK;
   }
-  if (h->step_mode == AUV_STEP_ONE_LAUNCH && !capturing && auv_roles_ok(d)) {
-    // dynamics, LiDAR and navigation + reward as three roles of ONE launch (csrc/k_step_fused.hip: k_step_roles)
-    auv_launch_step_roles(d, actions, dtype, ++h->step_seq, obs, reward, done, st);
+  if (h->step_mode == AUV_STEP_ONE_LAUNCH && auv_roles_ok(d)) {
+    // dynamics, LiDAR and navigation + reward as three roles of ONE launch (csrc/k_step_fused.hip: k_step_roles;
+    // inside a captured graph its dynamics role advances the action ring)
+    auv_launch_step_roles(d, actions, dtype, obs, reward, done, st);
     return AUV_OK;
   }
   if ((h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) && auv_paired_ok(d)) {
@@ -802,8 +806,10 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
   int rc = AUV_OK;
   // inside the graph, step k's reward phase and step k+1's dynamics share a launch (side-by-side shape with a LiDAR
   // sweep: the shapes whose reward kernel maps lanes to environments)
-  // (also for the paired shape: inside a graph of several steps the fused reward + dynamics launch is worth more than
-  // the paired finish -- 97.2 M against 95.5 M env-steps/s at 16 steps per graph -- and the bits are the same)
+  // (also for the paired and one-launch shapes: replayed launches cost ~3 us more than eager ones on this stack, and
+  // inside a graph of several steps the fused reward + dynamics launch makes up for more of that than they do --
+  // 97.6 M against 95.5 M (paired) and 96.6 M (one launch) env-steps/s at 16 steps per graph, 95.3 against 90.6 M at
+  // 8192 x 256 -- and the bits are the same.  A graph of ONE step keeps the handle's own shape.)
   const bool fuse = n_steps > 1 &&
                     (h->step_mode == AUV_STEP_SIDE_BY_SIDE || h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) &&
                     auv_k23_ok(h->d) && h->d.cfg.use_lidar;
@@ -846,7 +852,7 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
     auv_launch_k2r(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
     nk = 2;
   } else if (h->step_mode == AUV_STEP_ONE_LAUNCH && auv_roles_ok(d)) {
-    auv_launch_step_roles(d, actions_dev, action_dtype, ++h->step_seq, obs_dev, reward_dev, done_dev, st, h->ev[0], h->ev[1]);
+    auv_launch_step_roles(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, st, h->ev[0], h->ev[1]);
     nk = 1;
   } else if ((h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) && auv_paired_ok(d)) {
     auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);

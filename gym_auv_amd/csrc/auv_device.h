@@ -79,6 +79,7 @@ struct AuvDev {
   unsigned long long* pair_word; // [N] paired step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
   int32_t* pair_error; // [1] paired step: set when a navigation wave gave up waiting for its sweep
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
+  int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position
   int32_t pair_skew;   // paired step, test hook: idle workgroups between the two roles (puts them on different XCDs)
   const struct AuvDev* self;  // this struct in device memory (as of the last bank load): the paired step's restore path
                               // reads its ~25 table pointers through it at the point of use -- as kernel arguments

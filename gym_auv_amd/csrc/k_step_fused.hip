@@ -233,12 +233,16 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
 //                each: k1_group), workgroups [nk, nk + nb) sweep the LiDAR of one environment each, the rest navigate
 //                one environment each and run its reward phase (the paired finish above).  The sweep and the
 //                navigation need the state the dynamics role produces in the same launch: it hands each environment
-//                a 64-byte packet (x, y, psi, u, v, r, the vessel's step counter, the step's sequence number), stored
-//                write-through and completed before the sequence number is stored; the other two roles poll for the
-//                sequence number the host passed with the launch (the dynamics workgroups have the smallest indices,
-//                are dispatched first and wait for nobody; the poll is bounded like the paired finish's).  What is
-//                saved is the dynamics kernel's launch ramp and the kernel boundary behind it.  Eager steps only: a
-//                captured graph cannot change the sequence number, it keeps the fused shape.
+//                a 64-byte packet (x, y, psi, u, v, r, the vessel's step counter, a "ready" mark), stored
+//                write-through and completed before the mark is stored; the other two roles poll for the mark (the
+//                dynamics workgroups have the smallest indices, are dispatched first and wait for nobody; the poll
+//                is bounded like the paired finish's).  The navigation wave takes the mark away again when it has
+//                finished the environment's step (its sweep wave has read the packet long before: the navigation
+//                wave has consumed the word the sweep stores last), so the next launch finds every mark down.  What
+//                is saved is the dynamics kernel's launch ramp and the kernel boundary behind it.  No launch
+//                argument changes from step to step, so the shape can be captured in a hipGraph; there the dynamics
+//                waves count themselves off and the last one advances the action ring (every one of them has read
+//                the position by then).
 // (Tried and dropped: the sweep waves also running the navigation's search over the chunk circles for the old pose
 // while they wait, handing the survivor list to the navigation wave in one word -- the navigation wave gets 2.5 us
 // shorter, but the extra traffic and issue slots stretch the dynamics role's chain from 6 to 7.5 us and the whole
@@ -251,9 +255,10 @@ __device__ __forceinline__ double pair_lane_value(const unsigned long long v, co
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// the state the dynamics role left for environment e in THIS launch (`seq`); false: gave up polling
-__device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, const int lane, const unsigned long long seq,
-                                                 EnvPre& pre) {
+#define ROLES_READY 1ull
+// the state the dynamics role left for environment e in this launch; false: gave up polling
+__device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, const int lane, EnvPre& pre) {
+  const unsigned long long seq = ROLES_READY;
   const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
   // (polling harder does not pay: with two requests in flight per wave the packet is noticed sooner, but the
   // traffic of 3500 polling waves slows the dynamics role down by more -- 102.3 M against 104.7 M env-steps/s;
@@ -278,7 +283,6 @@ __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, c
 
 template <typename AT>
 __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvDev dk, const AT* __restrict__ actions,
-                                                                           const unsigned long long seq,
                                                                            float* __restrict__ obs_out,
                                                                            float* __restrict__ reward_out,
                                                                            uint8_t* __restrict__ done_out) {
@@ -310,7 +314,16 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
       __hip_atomic_store(pk + 6, (unsigned long long)(unsigned)y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     auv_stores_done();
-    if (live && c == 7) __hip_atomic_store(pk + 7, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (live && c == 7) __hip_atomic_store(pk + 7, ROLES_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a captured graph's action ring: every dynamics wave has read the position before it counts itself off, so
+    // the last one to do so may move it on
+    if (d.ring_slots > 1 && d.ring_slot_host == -1 && lane == 0) {
+      const int old = __hip_atomic_fetch_add(d.k1_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == nk - 1) {
+        *d.ring_pos = (*d.ring_pos + 1) % d.ring_slots;
+        __hip_atomic_store(d.k1_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
 #ifdef AUV_STAMPS
     if (live && c == 0) d.stamps[(size_t)eg * 16 + 0] = wall_clock64();   // the state of this environment is out
 #endif
@@ -342,7 +355,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 1] = wall_clock64();
 #endif
-    if (!roles_wait_state(d, e, lane, seq, pre)) return;
+    if (!roles_wait_state(d, e, lane, pre)) return;
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 2] = wall_clock64();
 #endif
@@ -367,7 +380,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 12] = wall_clock64();
 #endif
-    if (!roles_wait_state(d, e, lane, seq, pre)) return;
+    if (!roles_wait_state(d, e, lane, pre)) return;
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 5] = wall_clock64();
 #endif
@@ -380,6 +393,8 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif
     pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
+    // the environment's step is complete (and its sweep wave gone): the packet's mark comes down for the next launch
+    if (lane == 0) __hip_atomic_store(d.k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();
 #endif
@@ -601,18 +616,18 @@ void auv_launch_k2r(const AuvDev& d, float* obs, float* reward, uint8_t* done, h
   hipExtLaunchKernelGGL(k2r_lidar_reward, dim3(d.n), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs, reward, done);
 }
 
-// ---- the one-launch step (eager only: the sequence number is a launch argument) ----
+// ---- the one-launch step ----
 bool auv_roles_ok(const AuvDev& d) { return auv_paired_ok(d); }
 
-void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, unsigned long long seq, float* obs, float* reward,
-                           uint8_t* done, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
+                           hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
   const int nk = 8 * ((d.n + 63) / 64), nb = 8 * ((d.n + 7) / 8);
   const dim3 grid(nk + 2 * nb + d.pair_skew), block(AUV_WAVE);
   if (dtype == AUV_F64)
-    hipExtLaunchKernelGGL(k_step_roles<double>, grid, block, lds, st, ev0, ev1, 0, d, (const double*)actions, seq, obs, reward, done);
+    hipExtLaunchKernelGGL(k_step_roles<double>, grid, block, lds, st, ev0, ev1, 0, d, (const double*)actions, obs, reward, done);
   else
-    hipExtLaunchKernelGGL(k_step_roles<float>, grid, block, lds, st, ev0, ev1, 0, d, (const float*)actions, seq, obs, reward, done);
+    hipExtLaunchKernelGGL(k_step_roles<float>, grid, block, lds, st, ev0, ev1, 0, d, (const float*)actions, obs, reward, done);
 }
 
 hipError_t auv_step_fused_prepare(const AuvDev& d) {

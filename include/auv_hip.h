@@ -209,8 +209,10 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
  *                                    words stored and loaded coherently (csrc/k_step_fused.hip: k_step_roles,
  *                                    pair_finish_nav); waves that need a result poll for it, bounded -- if a
  *                                    poll ever runs out, every later auv_step / auv_graph_launch / auv_step_timed
- *                                    fails with AUV_ESTATE.  Needs the LiDAR on; without it, and inside a
- *                                    captured graph, the step falls back to the shapes below.
+ *                                    fails with AUV_ESTATE.  Needs the LiDAR on; without it the step falls back
+ *                                    to the shapes below.  Capturable (no launch argument changes from step to
+ *                                    step); a graph of SEVERAL steps uses the side-by-side shape with its fused
+ *                                    reward + dynamics launch all the same, because that replays faster.
  *   AUV_STEP_PAIRED                  K1 -> one launch whose workgroups do K2 for all envs and K3-nav for all envs
  *                                    side by side, the navigation wave also running K3-reward.  Two launches.
  *   AUV_STEP_SIDE_BY_SIDE            K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward; inside a
