@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     if (live && c == 0) d.stamps[(size_t)eg * 16 + 0] = wall_clock64();   // the state of this environment is out
 #endif
     return;   // (carrying on as the LiDAR wave of an environment instead of handing the slot to a fresh workgroup was
-              // tried: the merged code path costs more scalar-register spills than the later start of 512 sweeps: -2.5 %.
+              // tried: the merged code path costs more scalar-register spills than the later start of 512 sweeps: -2.5 %;
+              // with the dynamics in a function of its own (not inlined, arguments by value) they are 1 us slower: -4.5 %.
               // So was the scalar form of the integrator, lanes <-> environments, on 64 waves instead of 512: its
               // chain is 3 us longer and everybody waits for it, 97.2 M against 104.7 M env-steps/s.)
   }

@@ -32,3 +32,10 @@ f("nav durations from state (us)", n1 - ns)
 f("nav finish (reward) (us)", n2 - n1)
 f("nav end offsets (us)", n2 - base)
 print("navigation with the sweep's list: %d of %d" % (int(listed.sum()), n))
+late = np.arange(n) >= n - n // 8
+f("LiDAR sweep end, first 7/8 of the envs (us)", (l1 - base)[~late])
+f("LiDAR sweep end, last 1/8 (displaced by the dynamics waves) (us)", (l1 - base)[late])
+f("nav end, first 7/8 (us)", (n2 - base)[~late])
+f("nav end, last 1/8 (us)", (n2 - base)[late])
+f("sweep duration from state, first 7/8 (us)", (l1 - ls)[~late])
+f("sweep duration from state, last 1/8 (us)", (l1 - ls)[late])
