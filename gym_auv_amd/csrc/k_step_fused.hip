@@ -339,6 +339,10 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     // ---- _update + Vessel.perceive of one environment ----
     const int e = auv_uniform(b - nk);
     if (e >= d.n) return;
+    // (The SIMD's arbiter favours its oldest wave: at equal work the sweeps dispatched last take half as long again as
+    // the first, 17 against 12 us, and end the launch -- tools/phase_stamps3.py.  A priority graded by workgroup index
+    // evens that out and LOSES 1-2 % either way round: the early finishers make room for navigation waves, whose
+    // memory latency then hides behind the late sweeps' arithmetic.)
     // while the dynamics role integrates: everything of the sweep that does not need the vessel's new state --
     // descriptor and counters (written by earlier launches), the movers' kinematics, the obstacle records
 #ifdef AUV_STAMPS

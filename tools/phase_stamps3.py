@@ -35,3 +35,10 @@ if mode == "paired":
     print("last end of all waves (us): %.1f" % ((max(le.max(), ne.max()) - base) / 100))
 else:
     print("last end of all waves (us): %.1f" % ((max(t1.max(), n1.max()) - base) / 100))
+late = np.arange(n) >= n - n // 8
+seg = st[:, 5]
+print("active boundary segments per env: first 7/8 mean %.1f, last 1/8 mean %.1f" % (seg[~late].mean(), seg[late].mean()))
+print("sweep duration (us): first 7/8 p50 %.2f, last 1/8 p50 %.2f" % (np.median((t1 - t0)[~late]) / 100, np.median((t1 - t0)[late]) / 100))
+for k in range(8):
+    m = (np.arange(n) >= k * n // 8) & (np.arange(n) < (k + 1) * n // 8)
+    print("  envs [%4d, %4d): segs %.1f  sweep p50 %.2f us" % (k * n // 8, (k + 1) * n // 8, seg[m].mean(), np.median((t1 - t0)[m]) / 100))
