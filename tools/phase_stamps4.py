@@ -31,7 +31,6 @@ f("nav wait for state (us)", ns - n0)
 f("nav durations from state (us)", n1 - ns)
 f("nav finish (reward) (us)", n2 - n1)
 f("nav end offsets (us)", n2 - base)
-print("navigation with the sweep's list: %d of %d" % (int(listed.sum()), n))
 late = np.arange(n) >= n - n // 8
 f("LiDAR sweep end, first 7/8 of the envs (us)", (l1 - base)[~late])
 f("LiDAR sweep end, last 1/8 (displaced by the dynamics waves) (us)", (l1 - base)[late])
