@@ -244,7 +244,8 @@ def test_graph_replay_matches_eager():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_step_modes_agree_bitwise(dtype):
-    """two kernels (default) vs side-by-side launch vs whole step in one kernel vs two streams: bitwise the same."""
+    """every launch shape of the step (one launch with three roles -- the default --, paired, side-by-side, two kernels,
+    one kernel per wave, two streams): bitwise the same."""
     n = 64
     bank = _mixed_bank(32)
     cfg = effective_reference_config(use_lidar=True)
