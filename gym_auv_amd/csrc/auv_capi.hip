@@ -689,6 +689,8 @@ int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
     const char* v = getenv("AUV_PAIR_SKEW");
     const int k = v ? atoi(v) : 0;
     h->d.pair_skew = (k > 0 && k < 8) ? k : 0;
+    const char* f = getenv("AUV_PAIR_FAULT");                // test hook: one sweep withholds its word
+    h->d.pair_fault = (f && atoi(f) == 1) ? 1 : 0;
   }
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);

@@ -81,6 +81,7 @@ struct AuvDev {
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position
   int32_t pair_skew;   // paired step, test hook: idle workgroups between the two roles (puts them on different XCDs)
+  int32_t pair_fault;  // paired step, test hook: environment 0's sweep never publishes its word (the poll must run out)
   const struct AuvDev* self;  // this struct in device memory (as of the last bank load): the paired step's restore path
                               // reads its ~25 table pointers through it at the point of use -- as kernel arguments
                               // they would all be fetched (and spilled) at the entry of every wave of both roles

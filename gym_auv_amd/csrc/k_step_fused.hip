@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
 __device__ __forceinline__ void pair_publish_lidar(const AuvDev& d, const int e, const int lane, const int collision,
                                                    const double term) {
   auv_stores_done();                                       // of every lane of this wave (one counter per wave)
+  if (d.pair_fault && e == 0) return;                      // (test hook: tests/test_gpu_parity.py, the poll's time-out)
   if (lane == 0)
     __hip_atomic_store(d.pair_word + e, collision ? PAIR_COLLISION : (unsigned long long)__double_as_longlong(term),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -109,8 +110,9 @@ __device__ __forceinline__ void pair_finish_nav(const AuvDev& dk, const int e, c
                                                 float* __restrict__ obs_out, float* __restrict__ reward_out,
                                                 uint8_t* __restrict__ done_out) {
   unsigned long long word = pair_uniform(p.word);
+  const int limit = dk.pair_fault ? (1 << 12) : PAIR_POLL_LIMIT;
   for (int polls = 0; word == PAIR_EMPTY; polls++) {
-    if (polls == PAIR_POLL_LIMIT) {
+    if (polls == limit) {
       if (lane == 0) __hip_atomic_store(dk.pair_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }

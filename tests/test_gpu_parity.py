@@ -308,6 +308,37 @@ def test_paired_step_bitwise_with_many_resets(skew, mode, monkeypatch):
     assert ms[2] == 0.0 and len(par.timed_kernel_names()) == (2 if mode == "paired" else 1) and torch.equal(ref.obs, par.obs)
 
 
+@pytest.mark.parametrize("mode", ["paired", "one_launch"])
+def test_hand_over_timeout_fails_loudly_and_does_not_hang(mode, monkeypatch):
+    """The waits inside the one-launch / paired step are bounded.  With environment 0's sweep withholding its word
+    (test hook AUV_PAIR_FAULT) its navigation wave gives up after a bounded number of polls, the launch ends, and
+    every later step raises instead of returning half-finished results; loading a bank again clears the condition."""
+    n = 64
+    bank = _mixed_bank(32)
+    cfg = effective_reference_config(use_lidar=True)
+    monkeypatch.setenv("AUV_PAIR_FAULT", "1")
+    env = _env(cfg, bank, n)
+    env.set_step_mode(mode)
+    env.reset()
+    a = torch.zeros((n, 2), dtype=torch.float32, device="cuda:0")
+    env.step(a)                                  # the faulty launch itself is enqueued normally ...
+    torch.cuda.synchronize()                     # ... and ENDS (no hang)
+    with pytest.raises(RuntimeError, match="timed out"):
+        env.step(a)
+    monkeypatch.delenv("AUV_PAIR_FAULT")
+    env.set_step_mode(mode)                      # (re-reads the hook)
+    env.load_worlds(bank)                        # a fresh bank clears the condition
+    env.reset()
+    ref = _env(cfg, bank, n)
+    ref.set_step_mode("side_by_side")
+    ref.reset()
+    for _ in range(3):
+        o0, r0, d0, _ = ref.step(a)
+        o1, r1, d1, _ = env.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1)
+
+
 def test_action_ring_graph_and_eager_after_capture():
     """The action ring belongs to captured graphs: replay k consumes slot k % n.  An eager step() on
     an env whose ring is on (after capture_graph(slots > 1)) reads its [N, 2] tensor as a plain
