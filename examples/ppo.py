@@ -154,7 +154,9 @@ if __name__ == "__main__":
     ap.add_argument("--regen", type=int, default=5, help="regenerate the world bank on the device every this many updates")
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--task", default="colav", choices=["colav", "pathfollow"])
+    ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     from gym_auv_amd import distributed as D
     _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
-    train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, worlds=a.worlds, regen=a.regen, log_every=a.log_every, task=a.task)
+    train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, seed=a.seed, worlds=a.worlds, regen=a.regen, log_every=a.log_every,
+          task=a.task)
