@@ -43,7 +43,7 @@ class ActorCritic(nn.Module):
 
 
 def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=5, log_every=1,
-          task="colav"):
+          task="colav", step_mode=None):
     from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
@@ -62,6 +62,8 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
         bank = build_bank_parallel("moving_obstacles_world", range(5000 + 512 * rank, 5000 + 512 * rank + min(envs, 512)),
                                    procs=min(8, os.cpu_count() or 1), **({} if colav else dict(n_moving=0, n_static=0)))
     env = BatchedAuvEnv(cfg, bank, envs, device=device, auto_reset=True, rewarder="colav" if colav else "pathfollow")
+    if step_mode:
+        env.set_step_mode(step_mode)
     low = torch.as_tensor(env.action_space.low, device=device)
     high = torch.as_tensor(env.action_space.high, device=device)
     net = ActorCritic(env.obs_dim).to(device)
@@ -155,8 +157,9 @@ if __name__ == "__main__":
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--task", default="colav", choices=["colav", "pathfollow"])
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--step-mode", default=None, help="launch shape of a step (BatchedAuvEnv.STEP_MODES); default: the library's")
     a = ap.parse_args()
     from gym_auv_amd import distributed as D
     _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
     train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, seed=a.seed, worlds=a.worlds, regen=a.regen, log_every=a.log_every,
-          task=a.task)
+          task=a.task, step_mode=a.step_mode)
