@@ -39,11 +39,11 @@ class ActorCritic(nn.Module):
         self.log_std = nn.Parameter(torch.full((act_dim,), -0.5))
 
     def dist(self, obs):
-        return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
+        return torch.distributions.Normal(self.pi(obs), self.log_std.exp(), validate_args=False)   # (no host sync: graph-capturable)
 
 
 def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=5, log_every=1,
-          task="colav", step_mode=None):
+          task="colav", step_mode=None, graph_rollout=False):
     from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
@@ -74,6 +74,36 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     gamma, lam, clip, ent_coef, epochs, n_mb = 0.999, 0.98, 0.2, 0.01, 4, 32
     obs = env.reset().clone()
     history = []
+    # --graph-rollout: policy forward, sampling, the environment's step (one kernel launch, enqueued on torch's
+    # capture stream through the C ABI) and the value net as ONE captured device graph, replayed once per step
+    roll = None
+    if graph_rollout:
+        s_obs = obs.clone()
+        s_a = torch.zeros((envs, 2), device=device)
+        s_lp, s_v = torch.zeros(envs, device=device), torch.zeros(envs, device=device)
+        s_rew, s_done = torch.zeros(envs, device=device), torch.zeros(envs, device=device)
+
+        def one_step():
+            with torch.no_grad():
+                mu, log_std = net.pi(s_obs), net.log_std
+                a = mu + log_std.exp() * torch.randn_like(mu)        # (torch.normal with tensor arguments does not capture)
+                nobs, rew, done, _ = env.step(torch.max(torch.min(a, high), low))
+                lp = (-0.5 * ((a - mu) / log_std.exp()) ** 2 - log_std - 0.9189385332046727).sum(-1)
+                s_a.copy_(a), s_lp.copy_(lp), s_v.copy_(net.v(s_obs).squeeze(-1))
+                s_rew.copy_(rew), s_done.copy_(done.float())
+                return nobs
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):                      # (warm-up off the capture, as torch asks)
+            for _ in range(3):
+                one_step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize()
+        env.reset()
+        roll = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(roll):
+            s_next = one_step()
+        obs = env.reset().clone()
     for upd in range(updates):
         if worlds == "generated" and regen > 0 and upd and upd % regen == 0:
             # fresh scenarios for every environment, built on the device; all envs restart
@@ -82,13 +112,19 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
         t0 = time.time()
         O, A, LP, R, Dn, V = [], [], [], [], [], []
         with torch.no_grad():
-            for _ in range(rollout):
+            for _ in range(rollout if roll is None else 0):
                 dist = net.dist(obs)
                 a = dist.sample()
                 nobs, rew, done, _ = env.step(torch.max(torch.min(a, high), low))
                 O.append(obs), A.append(a), LP.append(dist.log_prob(a).sum(-1)), V.append(net.v(obs).squeeze(-1))
                 R.append(rew.clone() * 0.01), Dn.append(done.float())         # reward scale for the value net
                 obs = nobs.clone()
+            for _ in range(rollout if roll is not None else 0):
+                s_obs.copy_(obs)
+                roll.replay()
+                O.append(obs), A.append(s_a.clone()), LP.append(s_lp.clone()), V.append(s_v.clone())
+                R.append(s_rew * 0.01), Dn.append(s_done.clone())
+                obs = s_next.clone()
             last_v = net.v(obs).squeeze(-1)
             adv, gae = [None] * rollout, torch.zeros(envs, device=device)
             for t in reversed(range(rollout)):
@@ -157,9 +193,10 @@ if __name__ == "__main__":
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--task", default="colav", choices=["colav", "pathfollow"])
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--graph-rollout", type=int, default=0, help="1: one captured device graph per rollout step")
     ap.add_argument("--step-mode", default=None, help="launch shape of a step (BatchedAuvEnv.STEP_MODES); default: the library's")
     a = ap.parse_args()
     from gym_auv_amd import distributed as D
     _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
     train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, seed=a.seed, worlds=a.worlds, regen=a.regen, log_every=a.log_every,
-          task=a.task, step_mode=a.step_mode)
+          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout))
