@@ -43,7 +43,7 @@ class ActorCritic(nn.Module):
 
 
 def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=5, log_every=1,
-          task="colav", step_mode=None, graph_rollout=False):
+          task="colav", step_mode=None, graph_rollout=False, graph_update=False):
     from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
@@ -70,7 +70,9 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     if world > 1:   # data parallel over GPUs: same initial weights, gradients averaged over RCCL
         for prm in net.parameters():
             torch.distributed.broadcast(prm.data, 0)
-    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    graph_update = graph_update and world == 1            # (the gradient all-reduce of data parallelism stays eager)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, capturable=graph_update)
+    upd_graph, upd_in, upd_loss = None, None, None
     gamma, lam, clip, ent_coef, epochs, n_mb = 0.999, 0.98, 0.2, 0.01, 4, 32
     obs = env.reset().clone()
     history = []
@@ -139,22 +141,47 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
         RET = ADV + V
         ADV = (ADV - ADV.mean()) / (ADV.std() + 1e-8)
         n = O.shape[0]
+
+        def minibatch_step(o, a, lp, advn, ret):
+            dist = net.dist(o)
+            ratio = (dist.log_prob(a).sum(-1) - lp).exp()
+            pg = -torch.min(ratio * advn, ratio.clamp(1 - clip, 1 + clip) * advn).mean()
+            vf = 0.5 * (net.v(o).squeeze(-1) - ret).pow(2).mean()
+            loss = pg + 0.5 * vf - ent_coef * dist.entropy().sum(-1).mean()
+            opt.zero_grad(set_to_none=not graph_update)
+            loss.backward()
+            if world > 1:
+                for prm in net.parameters():
+                    torch.distributed.all_reduce(prm.grad)
+                    prm.grad /= world
+            nn.utils.clip_grad_norm_(net.parameters(), 0.5)
+            opt.step()
+            return loss
+
         for _ in range(epochs):
             perm = torch.randperm(n, device=device)
             for mb in perm.chunk(n_mb):
-                dist = net.dist(O[mb])
-                ratio = (dist.log_prob(A[mb]).sum(-1) - LP[mb]).exp()
-                pg = -torch.min(ratio * ADV[mb], ratio.clamp(1 - clip, 1 + clip) * ADV[mb]).mean()
-                vf = 0.5 * (net.v(O[mb]).squeeze(-1) - RET[mb]).pow(2).mean()
-                loss = pg + 0.5 * vf - ent_coef * dist.entropy().sum(-1).mean()
-                opt.zero_grad(set_to_none=True)
-                loss.backward()
-                if world > 1:
-                    for prm in net.parameters():
-                        torch.distributed.all_reduce(prm.grad)
-                        prm.grad /= world
-                nn.utils.clip_grad_norm_(net.parameters(), 0.5)
-                opt.step()
+                if not graph_update:
+                    loss = minibatch_step(O[mb], A[mb], LP[mb], ADV[mb], RET[mb])
+                    continue
+                # --graph-update: forward, backward, gradient clipping and the Adam step of one minibatch as ONE captured
+                # device graph (static input buffers, refilled by gathers before every replay)
+                if upd_in is None:
+                    upd_in = [O[mb].clone(), A[mb].clone(), LP[mb].clone(), ADV[mb].clone(), RET[mb].clone()]
+                    side = torch.cuda.Stream(device=device)
+                    side.wait_stream(torch.cuda.current_stream(device))
+                    with torch.cuda.stream(side):              # (warm-up off the capture: three real steps on this minibatch)
+                        for _w in range(3):
+                            minibatch_step(*upd_in)
+                    torch.cuda.current_stream(device).wait_stream(side)
+                    upd_graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(upd_graph):
+                        upd_loss = minibatch_step(*upd_in)
+                    continue
+                for buf, src in zip(upd_in, (O, A, LP, ADV, RET)):
+                    torch.index_select(src, 0, mb, out=buf)
+                upd_graph.replay()
+                loss = upd_loss
         torch.cuda.synchronize()
         mean_r = float(torch.stack(R).mean().item()) / 0.01
         sps = world * envs * rollout / (time.time() - t0)
@@ -194,9 +221,10 @@ if __name__ == "__main__":
     ap.add_argument("--task", default="colav", choices=["colav", "pathfollow"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph-rollout", type=int, default=0, help="1: one captured device graph per rollout step")
+    ap.add_argument("--graph-update", type=int, default=0, help="1: one captured device graph per minibatch step of the update")
     ap.add_argument("--step-mode", default=None, help="launch shape of a step (BatchedAuvEnv.STEP_MODES); default: the library's")
     a = ap.parse_args()
     from gym_auv_amd import distributed as D
     _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
     train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, seed=a.seed, worlds=a.worlds, regen=a.regen, log_every=a.log_every,
-          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout))
+          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout), graph_update=bool(a.graph_update))

@@ -38,7 +38,8 @@ def test_ppo_rollout_as_one_captured_graph_per_step():
     import ppo
     hist = ppo.train(envs=1024, updates=4, rollout=16, regen=0, log=lambda *_: None, graph_rollout=True)
     assert len(hist) == 4 and all(math.isfinite(h[0]) and math.isfinite(h[1]) for h in hist)
-    hist = ppo.train(envs=2048, updates=40, rollout=32, regen=0, task="pathfollow", log=lambda *_: None, graph_rollout=True)
+    hist = ppo.train(envs=2048, updates=40, rollout=32, regen=0, task="pathfollow", log=lambda *_: None, graph_rollout=True,
+                     graph_update=True)      # (... and forward + backward + clipping + Adam of a minibatch as one graph too)
     mean = lambda rows, i: sum(r[i] for r in rows) / len(rows)   # noqa: E731
     assert mean(hist[-5:], 3) > mean(hist[:5], 3) + 0.04, (mean(hist[:5], 3), mean(hist[-5:], 3))    # surge speed
     assert mean(hist[-5:], 0) > hist[0][0] + 0.3, (hist[0][0], mean(hist[-5:], 0))                    # step reward
