@@ -237,10 +237,12 @@ __device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const S
     // the usual shapes: all passes' table entries are requested before the sincos, so the passes
     // do not each wait for their own trip to memory
     double2 b[4];
+    if (!staged) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int i = q * AUV_WAVE + lane;
-      b[q] = staged ? L.rayv[i < S ? i : 0] : d.beam_cs[i < S ? i : 0];   // cos, sin of -pi + (i + 1) * dangle
+      for (int q = 0; q < 4; q++) {
+        const int i = q * AUV_WAVE + lane;
+        b[q] = d.beam_cs[i < S ? i : 0];                    // cos, sin of -pi + (i + 1) * dangle
+      }
     }
     cos_psi = L.hdr->cpsi, sin_psi = L.hdr->spsi;
 #pragma unroll
@@ -248,6 +250,7 @@ __device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const S
       if (q * AUV_WAVE >= S) break;                         // (uniform: 180 beams are three passes)
       const int i = q * AUV_WAVE + lane;
       if (i < S) {
+        if (staged) b[q] = L.rayv[i];                       // (already in this very slot: no need to hold all four)
         const double c = cos_psi * b[q].x - sin_psi * b[q].y, s = sin_psi * b[q].x + cos_psi * b[q].y;
         // end point minus origin, formed exactly as the reference forms the end point
         double ex = px + c * R, ey = py + s * R;
