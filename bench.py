@@ -211,6 +211,9 @@ def main():
     if ndev < world and not (args.rehearse or args.dry_run):
         raise SystemExit("WORLD_SIZE=%d but only %d GPU(s) visible (one rank per GPU; --rehearse 1 to share)" % (world, ndev))
     n_devices_used = len({r % max(1, ndev) for r in range(world)})   # ranks map to device LOCAL_RANK % ndev
+    if args.rehearse and ndev < world:
+        os.environ.setdefault("AUV_DIST_BACKEND", "gloo")            # (ranks sharing a device cannot use RCCL; also when an
+                                                                     # outside launcher -- torch.distributed.run -- started them)
 
     # ---- reset-time host work first, BEFORE anything initialises the GPU (worker processes
     # are forked here; no process that has touched HIP forks or execs)
