@@ -61,6 +61,9 @@ def parse():
                     help="uniform: i.i.d. U(action_space), resident in HBM (headline); pilot: closed loop, "
                          "a = (1, 0.15 * heading_error) computed on the device from the observation of the "
                          "previous step, so that episodes progress along the path (SURVEY 8(d), config 1)")
+    ap.add_argument("--sub-batches", type=int, default=1,
+                    help="K > 1: the rank's envs are stepped as K contiguous sub-batches, each a launch chain on a stream "
+                         "of its own (auv_step_slice); the chains overlap on the GPU.  Same envs, same results")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
     ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
@@ -287,6 +290,16 @@ def main():
             for _ in range(n):
                 torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
                 env.step(act)
+    elif args.sub_batches > 1:
+        env.set_sub_batches(args.sub_batches)
+
+        def run(i0, n):
+            # K independent launch chains: sub-batch s of step i goes to stream s; nothing orders the chains against
+            # each other (the actions are resident), the synchronize() around the timed region waits for all of them
+            for i in range(n):
+                a = pool[(i0 + i) % n_pool]
+                for s in range(env.sub_batches):
+                    env.step_slice(s, a)
     else:
         def run(i0, n):
             for i in range(n):
@@ -359,7 +372,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
                            parallelism="env-shard x%d (no step-path collective)" % world, ranks=world,
-                           hipgraph_steps=K, step_mode=args.step_mode, actions=args.actions,
+                           hipgraph_steps=K, sub_batches=max(1, args.sub_batches), step_mode=args.step_mode, actions=args.actions,
                            worlds_per_env=wpe, world_gen_s=round(t_gen, 1),
                            episodes_finished=int(stats["episodes"].sum().item())),
                roofline=roofline)

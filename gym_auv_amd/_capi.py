@@ -130,6 +130,7 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_load_worlds": (C.c_int, [vp, C.POINTER(AuvWorldBank)]),
         "auv_reset": (C.c_int, [vp, vp, vp, vp, vp]),
         "auv_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
+        "auv_step_slice": (C.c_int, [vp, i32, i32, vp, i32, vp, vp, vp, vp]),
         "auv_step_dynamics": (C.c_int, [vp, vp, i32, vp]),
         "auv_lidar": (C.c_int, [vp, i32, vp]),
         "auv_nav_reward": (C.c_int, [vp, i32, vp, vp, vp, vp]),
@@ -161,7 +162,7 @@ def load_library(path: str = None) -> C.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset", "auv_step",
+EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset", "auv_step", "auv_step_slice",
                     "auv_step_dynamics", "auv_lidar", "auv_nav_reward", "auv_read", "auv_write",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",

@@ -152,6 +152,64 @@ class BatchedAuvEnv:
                              self._stream()), "auv_step")
         return self.obs, self.reward, self.done, self._lazy_info()
 
+    # ------------------------------------------------------------------------------ sub-batches
+    def set_sub_batches(self, k: int):
+        """Split the batch into `k` contiguous sub-batches, each with a stream of its own.  `step_async` then steps
+        them as k independent launch chains that overlap on the GPU (one sub-batch's sweeps run under another's
+        dynamics chain and navigation tail); results are bit-identical to `step`.  k = 1 restores the single
+        launch on the caller's stream.  Slice boundaries are multiples of 64 environments."""
+        k = int(k)
+        if k < 1 or k > 64:
+            raise ValueError("sub-batches must be in [1, 64]")
+        n = self.n_envs
+        per = -(-n // k)
+        per = -(-per // 64) * 64
+        self._slices = [(lo, min(per, n - lo)) for lo in range(0, n, per)]
+        self.sub_batches = len(self._slices)
+        with torch.cuda.device(self.device):
+            self._sub_streams = [torch.cuda.Stream(device=self.device) for _ in self._slices]
+        self._async_pending = False
+        return self._slices
+
+    def step_slice(self, i: int, actions: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
+        """Enqueue one step of sub-batch `i` (see set_sub_batches) on `stream` (default: the sub-batch's own).
+        `actions` is the full [N, 2] tensor; only the slice's rows are read, and only the slice's rows of
+        obs / reward / done are written."""
+        a, dt = self._act(actions)
+        lo, cnt = self._slices[i]
+        st = self._sub_streams[i] if stream is None else stream
+        _check(_LIB.auv_step_slice(self._h, lo, cnt, C.c_void_p(a.data_ptr()), dt, C.c_void_p(self.obs.data_ptr()),
+                                   C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                                   C.c_void_p(st.cuda_stream)), "auv_step_slice")
+
+    def step_async(self, actions: torch.Tensor):
+        """VecEnv.step_async (what SubprocVecEnv does with its workers, scripts/run.py:293-296): enqueue the step of
+        every sub-batch on its own stream and return at once.  The sub-batch streams first wait for the caller's
+        current stream (the actions were produced there)."""
+        if getattr(self, "_slices", None) is None:
+            self.set_sub_batches(1)
+        a, dt = self._act(actions)
+        cur = torch.cuda.current_stream(self.device)
+        ap, op, rp, dp = (C.c_void_p(a.data_ptr()), C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
+                          C.c_void_p(self.done.data_ptr()))
+        for (lo, cnt), st in zip(self._slices, self._sub_streams):
+            st.wait_stream(cur)
+            _check(_LIB.auv_step_slice(self._h, lo, cnt, ap, dt, op, rp, dp, C.c_void_p(st.cuda_stream)), "auv_step_slice")
+        self._async_actions = a          # keep the buffer alive until step_wait
+        self._async_pending = True
+
+    def step_wait(self):
+        """VecEnv.step_wait: make the caller's current stream wait for every sub-batch's step and return
+        (obs, reward, done, info) -- device tensors, no host synchronisation."""
+        if not getattr(self, "_async_pending", False):
+            raise RuntimeError("step_wait() without step_async()")
+        cur = torch.cuda.current_stream(self.device)
+        for st in self._sub_streams:
+            cur.wait_stream(st)
+        self._async_pending = False
+        self._async_actions = None
+        return self.obs, self.reward, self.done, self._lazy_info()
+
     def _lazy_info(self):
         return _LazyInfo(self)
 

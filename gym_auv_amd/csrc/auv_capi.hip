@@ -289,6 +289,7 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   memset(&h->d, 0, sizeof(h->d));
   h->d.cfg = *cfg;
   h->d.n = n_envs;
+  h->d.e0 = 0, h->d.ne = n_envs;
   h->device = device_id;
   h->worlds_loaded = false;
   h->graph = nullptr;
@@ -662,6 +663,23 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
   PAIR_CHECK(h);
   int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream, false);
   if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_step_slice(auv_handle_t* h, int32_t e0, int32_t ne, const void* actions_dev, int32_t action_dtype, float* obs_dev,
+                   float* reward_dev, uint8_t* done_dev, void* stream) {
+  REQUIRE_READY(h);
+  if (!actions_dev) return fail(AUV_EINVAL, "auv_step_slice: null actions");
+  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_step_slice: bad action dtype");
+  if (e0 < 0 || ne < 1 || (int64_t)e0 + ne > h->d.n) return fail(AUV_EINVAL, "auv_step_slice: slice [%d, %d) outside [0, %d)", e0, e0 + ne, h->d.n);
+  PAIR_CHECK(h);
+  if (!(h->step_mode == AUV_STEP_ONE_LAUNCH && auv_roles_ok(h->d)))
+    return fail(AUV_ESTATE, "auv_step_slice: needs the one-launch step shape");
+  AuvDev d = h->d;
+  d.ring_slots = 1;
+  d.e0 = e0, d.ne = ne;
+  auv_launch_step_roles(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return AUV_OK;
 }

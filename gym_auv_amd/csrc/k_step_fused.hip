@@ -292,8 +292,9 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const int S = d.cfg.n_sensors;
-  const int nk = 8 * ((d.n + 63) / 64);                             // dynamics workgroups
-  const int nb = 8 * ((d.n + 7) / 8);                               // LiDAR workgroups
+  const int ne = d.ne;                                              // environments of this launch: [e0, e0 + ne)
+  const int nk = 8 * ((ne + 63) / 64);                              // dynamics workgroups
+  const int nb = 8 * ((ne + 7) / 8);                                // LiDAR workgroups
   const int b = (int)blockIdx.x;
   if (b < nk) {
     // ---- Vessel.step of eight environments ----
@@ -301,8 +302,8 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     __builtin_amdgcn_s_setprio(3);
     const int g = lane / K1_GROUP, c = lane % K1_GROUP;
     const int er = 8 * (8 * (b / 8) + g) + (b % 8);
-    const bool live = er < d.n;
-    const int eg = live ? er : d.n - 1;                             // idle groups compute along, store nothing
+    const bool live = er < ne;
+    const int eg = d.e0 + (live ? er : ne - 1);                     // idle groups compute along, store nothing
     const size_t n = (size_t)d.n;
     const int y = d.counters[eg].y + 1;                             // Vessel._step_counter (vessel.py:247); requested up front
     const double t = k1_group<AT>(d, actions, eg, lane);
@@ -339,8 +340,8 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
   EnvDesc ed;
   if (b < nk + nb) {
     // ---- _update + Vessel.perceive of one environment ----
-    const int e = auv_uniform(b - nk);
-    if (e >= d.n) return;
+    if (b - nk >= ne) return;
+    const int e = auv_uniform(d.e0 + b - nk);
     // (The SIMD's arbiter favours its oldest wave: at equal work the sweeps dispatched last take half as long again as
     // the first, 17 against 12 us, and end the launch -- tools/phase_stamps3.py.  A priority graded by workgroup index
     // evens that out and LOSES 1-2 % either way round: the early finishers make room for navigation waves, whose
@@ -379,8 +380,9 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #endif
   } else {
     // ---- Vessel.navigate of one environment, then its reward / done / auto-reset ----
-    const int e = auv_uniform(b - nk - nb - d.pair_skew);
-    if (e < 0 || e >= d.n) return;
+    const int el = b - nk - nb - d.pair_skew;
+    if (el < 0 || el >= ne) return;
+    const int e = auv_uniform(d.e0 + el);
     ed = d.env_desc[e];
     pre.cnt = d.counters[e];
     pre.ed = &ed;
@@ -629,7 +631,7 @@ bool auv_roles_ok(const AuvDev& d) { return auv_paired_ok(d); }
 void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
-  const int nk = 8 * ((d.n + 63) / 64), nb = 8 * ((d.n + 7) / 8);
+  const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
   const dim3 grid(nk + 2 * nb + d.pair_skew), block(AUV_WAVE);
   if (dtype == AUV_F64)
     hipExtLaunchKernelGGL(k_step_roles<double>, grid, block, lds, st, ev0, ev1, 0, d, (const double*)actions, obs, reward, done);

@@ -160,6 +160,17 @@ int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx
 int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
              float* reward_dev, uint8_t* done_dev, void* stream);
 
+/* step() of the environments [e0, e0 + ne) only, enqueued on `stream`; the buffers are the same full-batch
+ * [N][..] buffers auv_step takes (only the slice's rows are read / written).  Environments are independent
+ * (environment.py:86-89), so sub-batches of one handle may be stepped on DIFFERENT streams concurrently: one
+ * sub-batch's LiDAR sweeps then run under another's dynamics chain and navigation tail -- the batched analogue
+ * of the reference's SubprocVecEnv workers stepping at their own pace (scripts/run.py:293-296; VecEnv
+ * step_async / step_wait).  Results are bit-identical to auv_step over the same environments.  Ordering between
+ * sub-batches and with the consumer of obs / reward / done is the CALLER's (stream order, events).  Needs the
+ * one-launch or the three-launch shape; eager only (not capturable together with an action ring).          */
+int auv_step_slice(auv_handle_t* h, int32_t e0, int32_t ne, const void* actions_dev, int32_t action_dtype,
+                   float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+
 /* The three kernels of step(), individually launchable (per-kernel parity tests):        */
 /* K1  Vessel.step: clip -> RKF45 of the 3-DOF model -> wrap psi.  (vessel.py:226-247,561-578) */
 int auv_step_dynamics(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, void* stream);
