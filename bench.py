@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=0,
                     help="0 (default): eager launches; K > 0: K consecutive steps captured in ONE hipGraph over the action "
                          "ring, one replay per K steps (steps not a multiple of K are finished eagerly)")
-    ap.add_argument("--step-mode", default="one_launch", choices=["side_by_side", "paired", "one_launch", "two_kernels", "one_kernel", "two_streams"],
+    ap.add_argument("--step-mode", default="auto", choices=["auto", "side_by_side", "paired", "one_launch"],
                     help="how a step is launched (include/auv_hip.h, AUV_STEP_*)")
     ap.add_argument("--actions", default="uniform", choices=["uniform", "pilot"],
                     help="uniform: i.i.d. U(action_space), resident in HBM (headline); pilot: closed loop, "
@@ -297,9 +297,7 @@ def main():
             # K independent launch chains: sub-batch s of step i goes to stream s; nothing orders the chains against
             # each other (the actions are resident), the synchronize() around the timed region waits for all of them
             for i in range(n):
-                a = pool[(i0 + i) % n_pool]
-                for s in range(env.sub_batches):
-                    env.step_slice(s, a)
+                env.step_pipelined(pool[(i0 + i) % n_pool])
     else:
         def run(i0, n):
             for i in range(n):

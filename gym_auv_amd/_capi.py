@@ -14,7 +14,7 @@ from .config import Config
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libauv_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 AUV_REWARD_COLAV, AUV_REWARD_PATHFOLLOW = 0, 1
 AUV_CULL_REFERENCE, AUV_CULL_EXACT = 0, 1
@@ -107,9 +107,12 @@ def make_bank_struct(bank: Dict[str, np.ndarray]) -> Tuple[AuvWorldBank, list]:
 _lib = None
 
 
+HOOKS_LIB_PATH = os.path.join(_HERE, "csrc", "libauv_hip_hooks.so")   # `make -C gym_auv_amd/csrc hooks`: tests only
+
+
 def load_library(path: str = None) -> C.CDLL:
     """dlopen libauv_hip.so and declare every prototype of include/auv_hip.h.
-    AUV_HIP_LIB selects another build of the same library (A/B timing of kernel variants)."""
+    AUV_HIP_LIB selects another build of the same library (A/B timing of kernel variants; the test-hook build)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -131,6 +134,9 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_reset": (C.c_int, [vp, vp, vp, vp, vp]),
         "auv_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
         "auv_step_slice": (C.c_int, [vp, i32, i32, vp, i32, vp, vp, vp, vp]),
+        "auv_step_pipelined": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp]),
+        "auv_health": (C.c_int, [vp, C.POINTER(i32)]),
+        "auv_effective_step_mode": (C.c_int, [vp, i32]),
         "auv_step_dynamics": (C.c_int, [vp, vp, i32, vp]),
         "auv_lidar": (C.c_int, [vp, i32, vp]),
         "auv_nav_reward": (C.c_int, [vp, i32, vp, vp, vp, vp]),
@@ -158,11 +164,14 @@ def load_library(path: str = None) -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if lib.auv_abi_version() != ABI_VERSION:
         raise AuvLibraryError("ABI mismatch: library %d, binding %d" % (lib.auv_abi_version(), ABI_VERSION))
+    if hasattr(lib, "auv_test_hooks"):   # only the -DAUV_TEST_HOOKS build exports it
+        lib.auv_test_hooks.restype, lib.auv_test_hooks.argtypes = C.c_int, [vp, i32, i32]
     _lib = lib
     return lib
 
 
 EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset", "auv_step", "auv_step_slice",
+                    "auv_step_pipelined", "auv_health", "auv_effective_step_mode",
                     "auv_step_dynamics", "auv_lidar", "auv_nav_reward", "auv_read", "auv_write",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",

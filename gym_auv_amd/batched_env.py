@@ -1,4 +1,4 @@
-"""BatchedAuvEnv — N independent gym-auv environments advanced per call by three HIP launches.
+"""BatchedAuvEnv — N independent gym-auv environments advanced per call by one HIP launch (or one per sub-batch).
 
 VecEnv-shaped surface (what the reference's callers use through stable-baselines' VecEnv,
 /root/reference/scripts/run.py:293-296): `reset() -> obs[N, D]`,
@@ -84,7 +84,9 @@ class BatchedAuvEnv:
             self.reward = torch.zeros((self.n_envs,), dtype=torch.float32, device=self.device)
             self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
         self._graph_actions = None
-        self.step_mode = "one_launch"
+        self.step_mode = "auto"
+        self._slices = None
+        self.sub_batches = 1
 
     # ------------------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -168,6 +170,8 @@ class BatchedAuvEnv:
         self.sub_batches = len(self._slices)
         with torch.cuda.device(self.device):
             self._sub_streams = [torch.cuda.Stream(device=self.device) for _ in self._slices]
+        self._bounds_c = (C.c_int32 * (self.sub_batches + 1))(*([lo for lo, _ in self._slices] + [n]))
+        self._streams_c = (C.c_void_p * self.sub_batches)(*[st.cuda_stream for st in self._sub_streams])
         self._async_pending = False
         return self._slices
 
@@ -182,20 +186,26 @@ class BatchedAuvEnv:
                                    C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
                                    C.c_void_p(st.cuda_stream)), "auv_step_slice")
 
+    def step_pipelined(self, actions: torch.Tensor):
+        """One step of the whole batch as `sub_batches` independent launch chains, one C call (auv_step_pipelined):
+        sub-batch i goes to its own stream.  Nothing orders the chains against the caller's stream -- for open-loop
+        stretches (actions already resident); `step_async` / `step_wait` add that ordering."""
+        a, dt = self._act(actions)
+        _check(_LIB.auv_step_pipelined(self._h, self.sub_batches, self._bounds_c, self._streams_c, C.c_void_p(a.data_ptr()), dt,
+                                       C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
+                                       C.c_void_p(self.done.data_ptr())), "auv_step_pipelined")
+
     def step_async(self, actions: torch.Tensor):
         """VecEnv.step_async (what SubprocVecEnv does with its workers, scripts/run.py:293-296): enqueue the step of
         every sub-batch on its own stream and return at once.  The sub-batch streams first wait for the caller's
         current stream (the actions were produced there)."""
-        if getattr(self, "_slices", None) is None:
+        if self._slices is None:
             self.set_sub_batches(1)
-        a, dt = self._act(actions)
         cur = torch.cuda.current_stream(self.device)
-        ap, op, rp, dp = (C.c_void_p(a.data_ptr()), C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
-                          C.c_void_p(self.done.data_ptr()))
-        for (lo, cnt), st in zip(self._slices, self._sub_streams):
+        for st in self._sub_streams:
             st.wait_stream(cur)
-            _check(_LIB.auv_step_slice(self._h, lo, cnt, ap, dt, op, rp, dp, C.c_void_p(st.cuda_stream)), "auv_step_slice")
-        self._async_actions = a          # keep the buffer alive until step_wait
+        self.step_pipelined(actions)
+        self._async_actions = actions    # keep the buffer alive until step_wait
         self._async_pending = True
 
     def step_wait(self):
@@ -213,15 +223,31 @@ class BatchedAuvEnv:
     def _lazy_info(self):
         return _LazyInfo(self)
 
-    STEP_MODES = {"side_by_side": 0, "one_kernel": 1, "two_streams": 2, "two_kernels": 3, "paired": 4, "one_launch": 5}
+    STEP_MODES = {"side_by_side": 0, "paired": 4, "one_launch": 5, "auto": 6}
+    _MODE_NAMES = {v: k for k, v in STEP_MODES.items()}
 
     def set_step_mode(self, mode: str):
-        """"side_by_side": K1 -> [K2 + K3-nav in one launch] -> K3-reward; "paired": the same without the third
-        launch, the second of an environment's two waves runs K3-reward; "two_kernels": [K1 -> K3-nav]
-        -> [K2 -> K3-reward]; "one_kernel": the whole step in one kernel; "two_streams": K3-nav forked
-        beside K2.  All give the same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise)."""
+        """"auto" (default): "one_launch" below 16384 environments per launch, "side_by_side" from there on;
+        "one_launch": dynamics, LiDAR sweep and navigation + reward as three roles of ONE launch; "paired": K1 -> [K2 and
+        K3-nav side by side, the navigation wave also runs K3-reward]; "side_by_side": K1 -> [K2 + K3-nav in one
+        launch] -> K3-reward.  All give the same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise).
+        Where the in-launch hand-overs of the first two may not be used (see `health()`) the library steps in
+        "side_by_side" whatever is set: `effective_step_mode()` tells."""
         _check(_LIB.auv_set_step_mode(self._h, self.STEP_MODES[mode]), "auv_set_step_mode")
         self.step_mode = mode
+
+    def effective_step_mode(self, n_envs_per_launch: int = 0) -> str:
+        """The shape a launch of that many environments (0: the whole batch) is really stepped in."""
+        return self._MODE_NAMES[_LIB.auv_effective_step_mode(self._h, int(n_envs_per_launch))]
+
+    def health(self) -> Dict[str, int]:
+        """State of the in-launch hand-overs (auv_health; reads host memory only, no synchronisation): `handover_ok`,
+        `probe_failures` of the load-time dispatch-order probe, `timeouts` so far, `pending` = a time-out the next
+        step call will recover from (every environment reset, three-launch shape from then on, one RuntimeError).
+        A loop that replays a captured step (torch CUDAGraph around `step`) should look at `pending` once per rollout."""
+        out = (C.c_int32 * 4)()
+        _check(_LIB.auv_health(self._h, out), "auv_health")
+        return dict(handover_ok=int(out[0]), probe_failures=int(out[1]), timeouts=int(out[2]), pending=int(out[3]))
 
     # per-kernel entry points (parity tests)
     def step_dynamics(self, actions: torch.Tensor):
@@ -263,9 +289,10 @@ class BatchedAuvEnv:
         return self.obs, self.reward, self.done, self._lazy_info()
 
     def step_timed(self, actions: torch.Tensor):
-        """One step, every dispatch stamped with its own start/stop HIP event; returns ms: in the
-        two-kernel mode ([K1 + K3-nav], [K2 + K3-reward], 0, whole step first start..last stop), otherwise
-        the side-by-side shape (K1, K2+K3-nav, K3-reward, whole step).  `timed_kernel_names()` names them."""
+        """One step, every dispatch stamped with its own start/stop HIP event; returns four ms values: the launches
+        of the effective step mode in order (one_launch: the one launch; paired: K1, K2 + K3-nav + K3-reward;
+        side_by_side: K1, K2 + K3-nav, K3-reward), zeros, and last the whole step first start .. last stop.
+        `timed_kernel_names()` names them."""
         a, dt = self._act(actions)
         ms = (C.c_float * 4)()
         _check(_LIB.auv_step_timed(self._h, C.c_void_p(a.data_ptr()), dt, C.c_void_p(self.obs.data_ptr()),
@@ -274,11 +301,10 @@ class BatchedAuvEnv:
         return [float(x) for x in ms]
 
     def timed_kernel_names(self):
-        if self.step_mode == "two_kernels":
-            return ["k1n_dyn_nav", "k2r_lidar_reward"]
-        if self.step_mode == "one_launch" and self.config.vessel.use_lidar:
+        mode = self.effective_step_mode()
+        if mode == "one_launch":
             return ["k_step_roles"]
-        if self.step_mode == "paired" and self.config.vessel.use_lidar:
+        if mode == "paired":
             return ["k1_dynamics", "k23_lidar_nav_paired"]      # (the kernel trace calls it k23_lidar_nav<true>)
         return ["k1_dynamics", "k23_lidar_nav", "k3_reward"]
 

@@ -24,29 +24,22 @@ void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* d
                           hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, float* obs, hipStream_t st);
 void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
-void auv_launch_ring_advance(const AuvDev& d, hipStream_t st);
 void auv_launch_refresh_desc(const AuvDev& d, hipStream_t st);
 void auv_launch_derive(const AuvDev& d, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
 hipError_t auv_k2_prepare(const AuvDev& d);
-bool auv_step_fused_ok(const AuvDev& d);
 bool auv_k23_ok(const AuvDev& d);
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t auv_step_fused_prepare(const AuvDev& d);
-void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
-                           hipStream_t st);
-bool auv_two_kernel_ok(const AuvDev& d);
+uint32_t auv_step_lds_bytes(const AuvDev& d);
 bool auv_paired_ok(const AuvDev& d);
 bool auv_roles_ok(const AuvDev& d);
 void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
                            hipEvent_t ev1 = nullptr);
-void auv_launch_k1n(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr,
-                    hipEvent_t ev1 = nullptr);
-void auv_launch_k2r(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
-                    hipEvent_t ev1 = nullptr);
 void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st);
+hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
                    float* out_closeness, hipStream_t st);
 
@@ -73,24 +66,47 @@ struct auv_handle {
   bool worlds_loaded;
   std::vector<void*> env_allocs, bank_allocs;
   hipStream_t cap_stream;
-  hipStream_t aux_stream;        // second branch of the step: K3-nav runs beside K2
-  hipEvent_t ev_fork, ev_join;
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
-  int step_mode;                 // AUV_STEP_* (include/auv_hip.h)
-  int32_t* pair_error_host;      // pinned, mapped: set by a navigation wave of the paired step that gave up polling
+  int step_mode;                 // AUV_STEP_* as requested (include/auv_hip.h)
+  int32_t* pair_error_host;      // pinned, mapped: set by a wave of the one-launch / paired step that gave up polling
+  // in-launch hand-overs (one-launch and paired shapes): allowed only while the load-time probe of the dispatch
+  // order has passed and no poll has ever run out on this handle
+  bool handover_ok;
+  int probe_failures;            // of the last probe (0 = the dispatch order is what the hand-overs rely on)
+  int handover_timeouts;         // polls that ran out over the life of the handle (each one disables the hand-overs)
   hipEvent_t ev[6];
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
   GenOut gen;
 };
 
-// paired step: a navigation wave that gave up polling for its sweep's word has left the step unfinished
-#define PAIR_CHECK(h)                                                                                           \
-  do {                                                                                                          \
-    if ((h)->pair_error_host && *(volatile int32_t*)(h)->pair_error_host)                                       \
-      return fail(AUV_ESTATE, "paired step: a navigation wave timed out waiting for its LiDAR sweep; results " \
-                              "since then are incomplete (auv_set_step_mode(AUV_STEP_SIDE_BY_SIDE) avoids it)"); \
+// From how many environments per launch on the three-launch shape is used by AUV_STEP_AUTO: with eight rounds of
+// waves per slot nothing is gained by hiding a launch boundary, and the polling costs a little (DESIGN.md section 4:
+// 141 M against 139.6 M env-steps/s at 32768 environments)
+#define AUV_AUTO_THREE_LAUNCHES_FROM 16384
+
+// The shape a step of `ne` environments is actually launched in: the requested one, degraded to the fence-free
+// three-launch shape where the in-launch hand-overs may not be used (probe failed / a poll timed out / no LiDAR).
+static int effective_mode(const auv_handle* h, int ne) {
+  int m = h->step_mode;
+  if (m == AUV_STEP_AUTO) m = ne >= AUV_AUTO_THREE_LAUNCHES_FROM ? AUV_STEP_SIDE_BY_SIDE : AUV_STEP_ONE_LAUNCH;
+  if (m != AUV_STEP_SIDE_BY_SIDE && (!h->handover_ok || !auv_paired_ok(h->d))) m = AUV_STEP_SIDE_BY_SIDE;
+  return m;
+}
+
+static int recover_from_timeout(auv_handle* h);
+static int probe_dispatch_order(auv_handle* h);
+
+// A wave of the one-launch / paired step that gave up polling has left its environment's step unfinished.  The
+// next call on the handle notices (mapped host word), repairs the handle -- hand-over words cleared, EVERY
+// environment put back into its reset state, three-launch shape from now on -- and reports AUV_ESTATE once.
+#define PAIR_CHECK(h)                                                            \
+  do {                                                                           \
+    if ((h)->pair_error_host && *(volatile int32_t*)(h)->pair_error_host) {      \
+      int _rc = recover_from_timeout(h);                                         \
+      if (_rc) return _rc;                                                       \
+    }                                                                            \
   } while (0)
 
 template <typename T>
@@ -225,6 +241,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     *h->pair_error_host = 0;   // (a new bank starts with a clean slate; see PAIR_CHECK)
     HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d.k1_done, 0, sizeof(int32_t)));
+    if (((uintptr_t)d.k1_pkt & 63) != 0) return fail(AUV_EHIP, "state packets are not 64-byte aligned");
   }
   d.w_ready = 0;
   auv_launch_derive(d, nullptr);
@@ -232,6 +249,10 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
   HIP_TRY(auv_k2_prepare(d));
   HIP_TRY(auv_step_fused_prepare(d));
+  {
+    int rc_p = probe_dispatch_order(h);
+    if (rc_p) return rc_p;
+  }
   if ((size_t)AUV_ENVS_PER_BLOCK * (d.nch_max * 4 + 512) > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);
@@ -271,6 +292,52 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   return AUV_OK;
 }
 
+// One launch with the step's structure and LDS footprint and several times more one-wave workgroups than the chip has
+// slots (k_step_fused.hip: k_probe_order): do consumers always find their lower-indexed producers?  Sets
+// handover_ok; a failure is not an error -- the handle then simply steps in the three-launch shape.
+static int probe_dispatch_order(auv_handle* h) {
+  const int np = 512, nc = 8192;
+  unsigned int* words = nullptr;
+  HIP_TRY(hipMalloc((void**)&words, (size_t)(np + nc + 1) * sizeof(unsigned int)));
+  HIP_TRY(hipMemset(words, 0, (size_t)(np + nc + 1) * sizeof(unsigned int)));
+  unsigned int* failures = words + np + nc;
+  unsigned int nf = 0;
+  hipError_t e = auv_launch_probe(words, np, nc, 0xA5A5u, failures, auv_step_lds_bytes(h->d), nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(&nf, failures, sizeof(nf), hipMemcpyDeviceToHost);
+  (void)hipFree(words);
+  if (e != hipSuccess) return fail(AUV_EHIP, "dispatch-order probe: %s", hipGetErrorString(e));
+  h->probe_failures = (int)nf;
+  h->handover_ok = nf == 0 && h->handover_timeouts == 0;
+  return AUV_OK;
+}
+
+static int recover_from_timeout(auv_handle* h) {
+  AuvDev& d = h->d;
+  const int code = *(volatile int32_t*)h->pair_error_host;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  h->handover_timeouts += 1;
+  h->handover_ok = false;
+  if (h->graph_exec) {
+    (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+  }
+  const size_t n = (size_t)d.n;
+  std::vector<unsigned long long> empty(n ? n : 1, AUV_PAIR_EMPTY);
+  HIP_TRY(hipMemcpy(d.pair_word, empty.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d.k1_done, 0, sizeof(int32_t)));
+  auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  *h->pair_error_host = 0;
+  return fail(AUV_ESTATE, "in-launch hand-over timed out (%s): steps since then were incomplete, so EVERY environment has been put "
+                          "back into its reset state; the handle steps in the three-launch shape from now on (no in-launch "
+                          "hand-over) and this error is reported once -- carry on with reset observations",
+              code == 2 ? "a wave waited in vain for the dynamics role's state" : "a navigation wave waited in vain for its sweep");
+}
+
 extern "C" {
 
 int32_t auv_abi_version(void) { return AUV_ABI_VERSION; }
@@ -295,17 +362,13 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->graph = nullptr;
   h->graph_exec = nullptr;
   h->cap_stream = nullptr;
-  h->step_mode = AUV_STEP_ONE_LAUNCH;
+  h->step_mode = AUV_STEP_AUTO;
   h->gen_worlds = 0;
-  h->aux_stream = nullptr;
-  h->ev_fork = h->ev_join = nullptr;
+  h->pair_error_host = nullptr;
+  h->handover_ok = false;
+  h->probe_failures = -1;
+  h->handover_timeouts = 0;
   for (auto& e : h->ev) e = nullptr;
-  if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
-    delete h;
-    return fail(AUV_EHIP, "auv_create: cannot create the auxiliary stream / events");
-  }
   *out = h;
   return AUV_OK;
 }
@@ -317,9 +380,6 @@ int auv_destroy(auv_handle_t* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   free_pool(h->env_allocs);
@@ -597,71 +657,58 @@ int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx
   return AUV_OK;
 }
 
-// One step: K1, then K2 (LiDAR) on the caller's stream with K3-nav forked onto the auxiliary
-// stream (they are independent given the new state), joined before K3-reward.  Works the same
-// eagerly and under stream capture (the fork/join events become graph edges).
+// One step of the environments [e0, e0 + ne) on `st`, in the shape effective_mode() names.  Works the same eagerly
+// and under stream capture.
 // `skip_k1`: the dynamics of this step were done by the previous step's fused kernel; `fuse_next`: this step's
 // reward phase also runs the dynamics of the NEXT step (both only inside a captured graph of several steps)
-static int enqueue_step(auv_handle_t* h, const void* actions, int32_t dtype, float* obs, float* reward, uint8_t* done,
-                        hipStream_t st, bool capturing, bool skip_k1 = false, bool fuse_next = false) {
+static int enqueue_step(auv_handle_t* h, int mode, int e0, int ne, const void* actions, int32_t dtype, float* obs, float* reward,
+                        uint8_t* done, hipStream_t st, bool capturing, bool skip_k1 = false, bool fuse_next = false) {
   // The action ring belongs to captured graphs only: an eager step reads `actions` as ONE plain
   // [N][2] buffer and neither reads nor advances the ring position (a caller that launches
   // eagerly can pass a different pointer every step).
   AuvDev d = h->d;
   if (!capturing) d.ring_slots = 1;
-  if (h->step_mode == AUV_STEP_ONE_KERNEL && auv_step_fused_ok(d)) {
-    // the whole step in one kernel (csrc/k_step_fused.hip).  A captured graph cannot change
-    // arguments, so it reads the device-side ring position and advances it with a tiny follow-up node.
-    auv_launch_step_fused(d, actions, dtype, obs, reward, done, st);
-    if (d.ring_slots > 1) auv_launch_ring_advance(d, st);
-    return AUV_OK;
-  }
-  if (h->step_mode == AUV_STEP_TWO_KERNELS && auv_two_kernel_ok(d)) {
-    // [K1 -> K3-nav] -> [K2 -> K3-reward], two launches on one stream (csrc/k_step_fused.hip)
-    auv_launch_k1n(d, actions, dtype, obs, st);
-    auv_launch_k2r(d, obs, reward, done, st);
-    return AUV_OK;
-  }
-  if (h->step_mode == AUV_STEP_ONE_LAUNCH && auv_roles_ok(d)) {
+  d.e0 = e0, d.ne = ne;
+  if (mode == AUV_STEP_ONE_LAUNCH) {
     // dynamics, LiDAR and navigation + reward as three roles of ONE launch (csrc/k_step_fused.hip: k_step_roles;
     // inside a captured graph its dynamics role advances the action ring)
     auv_launch_step_roles(d, actions, dtype, obs, reward, done, st);
     return AUV_OK;
   }
-  if ((h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) && auv_paired_ok(d)) {
+  if (mode == AUV_STEP_PAIRED) {
     // K1 -> [K2 and K3-nav side by side, the second of an environment's two waves runs K3-reward]: two launches
     auv_launch_k1(d, actions, dtype, st);
     auv_launch_k23_paired(d, obs, reward, done, st);   // (advances a captured graph's action ring)
     return AUV_OK;
   }
-  if (h->step_mode != AUV_STEP_TWO_STREAMS && auv_k23_ok(d)) {
-    // default: K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward, one stream
-    if (!skip_k1) auv_launch_k1(d, actions, dtype, st);
-    auv_launch_k23(d, obs, st);                       // (advances a captured graph's action ring)
-    AuvDev dr = d;
-    if (d.ring_slots > 1) dr.ring_slot_host = -2;     // ... so the reward phase does not
-    if (fuse_next) auv_launch_k31(dr, actions, dtype, obs, reward, done, st);
-    else auv_launch_k3_reward(dr, obs, reward, done, d.cfg.use_lidar ? 0 : 1, st);
-    return AUV_OK;
-  }
-  auv_launch_k1(d, actions, dtype, st);
-  HIP_TRY(hipEventRecord(h->ev_fork, st));
-  HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-  auv_launch_k3_nav(d, obs, h->aux_stream);
-  HIP_TRY(hipEventRecord(h->ev_join, h->aux_stream));
-  auv_launch_k2(d, 1, st);
-  HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-  auv_launch_k3_reward(d, obs, reward, done, 1, st);   // a done env with auto-reset copies its next world's reset rows
+  // K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward: no hand-over inside a launch
+  if (!auv_k23_ok(d)) return fail(AUV_EINVAL, "path too long for the navigation's chunk list (%d chunks)", d.nch_max);
+  if (!skip_k1) auv_launch_k1(d, actions, dtype, st);
+  auv_launch_k23(d, obs, st);                         // (advances a captured graph's action ring)
+  AuvDev dr = d;
+  if (d.ring_slots > 1) dr.ring_slot_host = -2;       // ... so the reward phase does not
+  if (fuse_next) auv_launch_k31(dr, actions, dtype, obs, reward, done, st);
+  else auv_launch_k3_reward(dr, obs, reward, done, d.cfg.use_lidar ? 0 : 1, st);
+  return AUV_OK;
+}
+
+static int check_actions(const void* actions_dev, int32_t action_dtype, const char* who) {
+  if (!actions_dev) return fail(AUV_EINVAL, "%s: null actions", who);
+  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "%s: bad action dtype", who);
+  // the kernels fetch an environment's (thrust, rudder) pair with one load
+  if ((uintptr_t)actions_dev & (action_dtype == AUV_F64 ? 15 : 7))
+    return fail(AUV_EINVAL, "%s: the action buffer must be %d-byte aligned", who, action_dtype == AUV_F64 ? 16 : 8);
   return AUV_OK;
 }
 
 int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
              uint8_t* done_dev, void* stream) {
   REQUIRE_READY(h);
-  if (!actions_dev) return fail(AUV_EINVAL, "auv_step: null actions");
-  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_step: bad action dtype");
+  int rc = check_actions(actions_dev, action_dtype, "auv_step");
+  if (rc) return rc;
   PAIR_CHECK(h);
-  int rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream, false);
+  rc = enqueue_step(h, effective_mode(h, h->d.n), 0, h->d.n, actions_dev, action_dtype, obs_dev, reward_dev, done_dev,
+                    (hipStream_t)stream, false);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return AUV_OK;
@@ -670,18 +717,46 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
 int auv_step_slice(auv_handle_t* h, int32_t e0, int32_t ne, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                    float* reward_dev, uint8_t* done_dev, void* stream) {
   REQUIRE_READY(h);
-  if (!actions_dev) return fail(AUV_EINVAL, "auv_step_slice: null actions");
-  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_step_slice: bad action dtype");
+  int rc = check_actions(actions_dev, action_dtype, "auv_step_slice");
+  if (rc) return rc;
   if (e0 < 0 || ne < 1 || (int64_t)e0 + ne > h->d.n) return fail(AUV_EINVAL, "auv_step_slice: slice [%d, %d) outside [0, %d)", e0, e0 + ne, h->d.n);
   PAIR_CHECK(h);
-  if (!(h->step_mode == AUV_STEP_ONE_LAUNCH && auv_roles_ok(h->d)))
-    return fail(AUV_ESTATE, "auv_step_slice: needs the one-launch step shape");
-  AuvDev d = h->d;
-  d.ring_slots = 1;
-  d.e0 = e0, d.ne = ne;
-  auv_launch_step_roles(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream);
+  rc = enqueue_step(h, effective_mode(h, ne), e0, ne, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream, false);
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return AUV_OK;
+}
+
+int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, const void* actions_dev,
+                       int32_t action_dtype, float* obs_dev, float* reward_dev, uint8_t* done_dev) {
+  REQUIRE_READY(h);
+  int rc = check_actions(actions_dev, action_dtype, "auv_step_pipelined");
+  if (rc) return rc;
+  if (n_slices < 1 || !bounds || !streams) return fail(AUV_EINVAL, "auv_step_pipelined: bad arguments");
+  if (bounds[0] != 0 || bounds[n_slices] != h->d.n) return fail(AUV_EINVAL, "auv_step_pipelined: bounds must run from 0 to %d", h->d.n);
+  for (int i = 0; i < n_slices; i++)
+    if (bounds[i + 1] <= bounds[i]) return fail(AUV_EINVAL, "auv_step_pipelined: empty or reversed slice %d", i);
+  PAIR_CHECK(h);
+  for (int i = 0; i < n_slices && rc == AUV_OK; i++)
+    rc = enqueue_step(h, effective_mode(h, bounds[i + 1] - bounds[i]), bounds[i], bounds[i + 1] - bounds[i], actions_dev, action_dtype,
+                      obs_dev, reward_dev, done_dev, (hipStream_t)streams[i], false);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_health(auv_handle_t* h, int32_t* out4) {
+  if (!h || !out4) return fail(AUV_EINVAL, "auv_health: bad arguments");
+  out4[0] = h->handover_ok ? 1 : 0;
+  out4[1] = h->probe_failures;
+  out4[2] = h->handover_timeouts;
+  out4[3] = (h->pair_error_host && *(volatile int32_t*)h->pair_error_host) ? 1 : 0;   // a time-out not yet recovered from
+  return AUV_OK;
+}
+
+int auv_effective_step_mode(auv_handle_t* h, int32_t n_envs_per_launch) {
+  if (!h) return fail(AUV_EINVAL, "null handle");
+  return effective_mode(h, n_envs_per_launch > 0 ? n_envs_per_launch : h->d.n);
 }
 
 int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
@@ -699,17 +774,9 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
 
 int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   if (!h) return fail(AUV_EINVAL, "null handle");
-  if (mode < 0 || mode > 5) return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
+  if (mode != AUV_STEP_SIDE_BY_SIDE && mode != AUV_STEP_PAIRED && mode != AUV_STEP_ONE_LAUNCH && mode != AUV_STEP_AUTO)
+    return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
   h->step_mode = mode;
-  {
-    // test hook of the paired step: AUV_PAIR_SKEW=k leaves k idle workgroups between the two roles, which puts an
-    // environment's two waves on different XCDs (read here, not cached, so that a test can switch it)
-    const char* v = getenv("AUV_PAIR_SKEW");
-    const int k = v ? atoi(v) : 0;
-    h->d.pair_skew = (k > 0 && k < 8) ? k : 0;
-    const char* f = getenv("AUV_PAIR_FAULT");                // test hook: one sweep withholds its word
-    h->d.pair_fault = (f && atoi(f) == 1) ? 1 : 0;
-  }
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;
@@ -717,10 +784,25 @@ int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   return AUV_OK;
 }
 
+#ifdef AUV_TEST_HOOKS
+// Only in libauv_hip_hooks.so (make hooks): skew = idle workgroups between the roles of the one-launch / paired
+// shapes (an environment's waves then sit on different XCDs); fault = 1: the sweep of the first environment of every
+// launch never publishes its word, so the navigation wave's poll runs out.
+int auv_test_hooks(auv_handle_t* h, int32_t skew, int32_t fault) {
+  if (!h) return fail(AUV_EINVAL, "null handle");
+  h->d.pair_skew = (skew > 0 && skew < 8) ? skew : 0;
+  h->d.pair_fault = fault == 1 ? 1 : 0;
+  if (h->d.self) HIP_TRY(hipMemcpy((void*)h->d.self, &h->d, sizeof(AuvDev), hipMemcpyHostToDevice));
+  return AUV_OK;
+}
+#endif
+
 int auv_step_dynamics(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, void* stream) {
   REQUIRE_READY(h);
-  if (!actions_dev) return fail(AUV_EINVAL, "auv_step_dynamics: null actions");
-  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "bad action dtype");
+  {
+    int rc_a = check_actions(actions_dev, action_dtype, "auv_step_dynamics");
+    if (rc_a) return rc_a;
+  }
   auv_launch_k1(h->d, actions_dev, action_dtype, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return AUV_OK;
@@ -810,9 +892,12 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
                             float* reward_dev, uint8_t* done_dev, int32_t n_steps, void* stream) {
   REQUIRE_READY(h);
   (void)stream;
-  if (!actions_dev) return fail(AUV_EINVAL, "auv_graph_capture: null actions");
   if (n_steps < 1 || n_steps > 4096) return fail(AUV_EINVAL, "auv_graph_capture_steps: n_steps must be in [1, 4096]");
-  if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "auv_graph_capture: bad action dtype");
+  {
+    int rc_a = check_actions(actions_dev, action_dtype, "auv_graph_capture");
+    if (rc_a) return rc_a;
+  }
+  PAIR_CHECK(h);
   if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
   if (h->graph_exec) {
     HIP_TRY(hipGraphExecDestroy(h->graph_exec));
@@ -830,15 +915,11 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
   // inside a graph of several steps the fused reward + dynamics launch makes up for more of that than they do --
   // 97.6 M against 95.5 M (paired) and 96.6 M (one launch) env-steps/s at 16 steps per graph, 95.3 against 90.6 M at
   // 8192 x 256 -- and the bits are the same.  A graph of ONE step keeps the handle's own shape.)
-  const bool fuse = n_steps > 1 &&
-                    (h->step_mode == AUV_STEP_SIDE_BY_SIDE || h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) &&
-                    auv_k23_ok(h->d) && h->d.cfg.use_lidar;
-  const int mode_was = h->step_mode;
-  if (fuse) h->step_mode = AUV_STEP_SIDE_BY_SIDE;
+  const bool fuse = n_steps > 1 && auv_k23_ok(h->d) && h->d.cfg.use_lidar;
+  const int mode = fuse ? AUV_STEP_SIDE_BY_SIDE : effective_mode(h, h->d.n);
   for (int32_t k = 0; k < n_steps && rc == AUV_OK; k++)
-    rc = enqueue_step(h, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream, true,
+    rc = enqueue_step(h, mode, 0, h->d.n, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream, true,
                       fuse && k > 0, fuse && k + 1 < n_steps);
-  h->step_mode = mode_was;
   hipError_t ce = hipStreamEndCapture(h->cap_stream, &h->graph);
   if (rc) return rc;
   HIP_TRY(ce);
@@ -857,7 +938,11 @@ int auv_graph_launch(auv_handle_t* h, void* stream) {
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
                    uint8_t* done_dev, void* stream, float* out_ms4) {
   REQUIRE_READY(h);
-  if (!actions_dev || !out_ms4) return fail(AUV_EINVAL, "auv_step_timed: null argument");
+  if (!out_ms4) return fail(AUV_EINVAL, "auv_step_timed: null argument");
+  {
+    int rc_a = check_actions(actions_dev, action_dtype, "auv_step_timed");
+    if (rc_a) return rc_a;
+  }
   PAIR_CHECK(h);
   hipStream_t st = (hipStream_t)stream;
   for (auto& e : h->ev)
@@ -867,14 +952,11 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   // every dispatch of the step is stamped with its own start and stop event (hipExtLaunchKernel): the
   // elapsed times are the kernels' own durations, as a kernel trace reports them, without the gaps
   int nk;
-  if (h->step_mode == AUV_STEP_TWO_KERNELS && auv_two_kernel_ok(d)) {
-    auv_launch_k1n(d, actions_dev, action_dtype, obs_dev, st, h->ev[0], h->ev[1]);
-    auv_launch_k2r(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
-    nk = 2;
-  } else if (h->step_mode == AUV_STEP_ONE_LAUNCH && auv_roles_ok(d)) {
+  const int mode = effective_mode(h, d.n);
+  if (mode == AUV_STEP_ONE_LAUNCH) {
     auv_launch_step_roles(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, st, h->ev[0], h->ev[1]);
     nk = 1;
-  } else if ((h->step_mode == AUV_STEP_PAIRED || h->step_mode == AUV_STEP_ONE_LAUNCH) && auv_paired_ok(d)) {
+  } else if (mode == AUV_STEP_PAIRED) {
     auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
     auv_launch_k23_paired(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
     nk = 2;

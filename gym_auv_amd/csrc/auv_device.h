@@ -31,6 +31,7 @@ struct AuvDev {
   int32_t n;        // environments
   int32_t e0, ne;   // the slice [e0, e0 + ne) of environments a step launch covers (the whole batch: 0, n) -- sub-batches
                     // of one handle stepped on different streams (auv_step_slice) overlap each other's head and tail
+  int32_t act_f64;  // the action buffer of this launch holds doubles (else floats)
   int32_t n_worlds;
   int32_t k_max, m_max;
   // ---- world bank (HBM, read-only during step).  Every table is addressed by a start offset

@@ -95,15 +95,28 @@ __device__ __forceinline__ Vec6 state_dot(const Vec6& y, double tau_u, double ta
   return o;
 }
 
+// The action (thrust, rudder) of environment e: `actions` is [N][2] of float or double (d.act_f64; one kernel serves
+// both -- the branch is uniform over the launch), inside a captured graph the current slot of the action ring.
+__device__ __forceinline__ void k1_action(const AuvDev& d, const void* __restrict__ actions, const int e, double* a0, double* a1) {
+  size_t i = 2 * (size_t)e;
+  if (d.ring_slots > 1)   // action ring: slot of this step
+    i += (size_t)(d.ring_slot_host >= 0 ? d.ring_slot_host : *d.ring_pos) * 2 * (size_t)d.n;
+  if (d.act_f64) {
+    const double2 a = *(const double2*)((const double*)actions + i);
+    *a0 = a.x, *a1 = a.y;
+  } else {
+    const float2 a = *(const float2*)((const float*)actions + i);
+    *a0 = (double)a.x, *a1 = (double)a.y;
+  }
+}
+
 // Vessel.step for environment e.  Every calling lane computes the same thing; `store` selects
 // who writes the new state / step counter back.  Returns them for the phases that follow in
-// the single-kernel step.
-template <typename AT>
-__device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const AT* __restrict__ actions, const bool store) {
+// the same kernel.
+__device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const void* __restrict__ actions, const bool store) {
   const size_t n = (size_t)d.n;
-  if (d.ring_slots > 1)   // action ring: slot of this step
-    actions += (size_t)(d.ring_slot_host >= 0 ? d.ring_slot_host : *d.ring_pos) * 2 * n;
-  double a0 = (double)actions[2 * (size_t)e], a1 = (double)actions[2 * (size_t)e + 1];
+  double a0, a1;
+  k1_action(d, actions, e, &a0, &a1);
   if (isnan(a0) || isnan(a1)) a0 = a1 = 0.0;
   const double tu = auv_clip(a0, 0.0, 1.0) * d.cfg.thrust_max;
   const double tr = auv_clip(a1, -1.0, 1.0) * d.cfg.moment_max;
@@ -161,14 +174,12 @@ __device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const AT*
 // components.  Returns component c of the new state (lanes c >= 6: unspecified).  Lanes whose group
 // is idle (`e` clamped by the caller) compute along.
 #define K1_GROUP 8
-template <typename AT>
-__device__ __forceinline__ double k1_group(const AuvDev& d, const AT* __restrict__ actions, const int e, const int lane) {
+__device__ __forceinline__ double k1_group(const AuvDev& d, const void* __restrict__ actions, const int e, const int lane) {
   const int c = lane % K1_GROUP, gbase = lane - c;
   const size_t n = (size_t)d.n;
   const bool own = c < 6;
-  if (d.ring_slots > 1)   // action ring: slot of this step
-    actions += (size_t)(d.ring_slot_host >= 0 ? d.ring_slot_host : *d.ring_pos) * 2 * n;
-  double a0 = (double)actions[2 * (size_t)e], a1 = (double)actions[2 * (size_t)e + 1];
+  double a0, a1;
+  k1_action(d, actions, e, &a0, &a1);
   if (isnan(a0) || isnan(a1)) a0 = a1 = 0.0;
   const double tu = auv_clip(a0, 0.0, 1.0) * d.cfg.thrust_max;
   const double tr = auv_clip(a1, -1.0, 1.0) * d.cfg.moment_max;
@@ -206,15 +217,14 @@ __device__ __forceinline__ double k1_group(const AuvDev& d, const AT* __restrict
 }
 
 #ifndef AUV_DEVICE_FUNCS_ONLY
-template <typename AT>
-__global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const AT* __restrict__ actions) {
+__global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const void* __restrict__ actions) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x % AUV_WAVE;
   const int c = lane % K1_GROUP;
   const size_t n = (size_t)d.n;
-  const bool live = tid / K1_GROUP < d.n;
-  const int e = live ? tid / K1_GROUP : d.n - 1;          // idle groups compute along, store nothing
-  const double t = k1_group<AT>(d, actions, e, lane);
+  const bool live = tid / K1_GROUP < d.ne;
+  const int e = d.e0 + (live ? tid / K1_GROUP : d.ne - 1);          // idle groups compute along, store nothing
+  const double t = k1_group(d, actions, e, lane);
   if (live && c < 6) d.state[(size_t)c * n + e] = t;
   if (live && c == 0) d.counters[e].y += 1;                // Vessel._step_counter (vessel.py:247)
   // (cos / sin of the new heading are NOT formed here for the launch that follows: measured, the extra sincos on
@@ -227,12 +237,11 @@ __global__ void __launch_bounds__(AUV_BLOCK) k1_dynamics(AuvDev d, const AT* __r
 #ifndef AUV_DEVICE_FUNCS_ONLY
 // ev0 / ev1 (both or neither): the dispatch itself is stamped (hipExtLaunchKernel), so the elapsed
 // time between them is the kernel's own duration without the gaps around it
-void auv_launch_k1(const AuvDev& d, const void* actions, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+void auv_launch_k1(const AuvDev& d0, const void* actions, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  AuvDev d = d0;
+  d.act_f64 = dtype == AUV_F64;
   const int per_block = AUV_BLOCK / K1_GROUP;
-  dim3 grid((d.n + per_block - 1) / per_block), block(AUV_BLOCK);
-  if (dtype == AUV_F64)
-    hipExtLaunchKernelGGL(k1_dynamics<double>, grid, block, 0, st, ev0, ev1, 0, d, (const double*)actions);
-  else
-    hipExtLaunchKernelGGL(k1_dynamics<float>, grid, block, 0, st, ev0, ev1, 0, d, (const float*)actions);
+  dim3 grid((d.ne + per_block - 1) / per_block), block(AUV_BLOCK);
+  hipExtLaunchKernelGGL(k1_dynamics, grid, block, 0, st, ev0, ev1, 0, d, actions);
 }
 #endif

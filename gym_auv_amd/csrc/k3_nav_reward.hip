@@ -845,8 +845,9 @@ __global__ void __launch_bounds__(AUV_BLOCK) k3_reward(AuvDev d, float* __restri
                                                        float* __restrict__ reward_out,
                                                        uint8_t* __restrict__ done_out, int lidar_obs) {
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
-  if (e >= d.n) return;
+  const int el = blockIdx.x * AUV_ENVS_PER_BLOCK + wave;
+  if (el >= d.ne) return;
+  const int e = auv_uniform(d.e0 + el);
   k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, nullptr, -1, false, lidar_obs != 0);
 }
 
@@ -858,10 +859,11 @@ __global__ void __launch_bounds__(AUV_WAVE) k3_reward_lanes(AuvDev d, float* __r
                                                             float* __restrict__ reward_out,
                                                             uint8_t* __restrict__ done_out) {
   const int lane = threadIdx.x;
-  const int e = blockIdx.x * AUV_WAVE + lane;
+  const int el = blockIdx.x * AUV_WAVE + lane;
+  const int e = d.e0 + el;
   int do_reset = 0, w = 0;
   int4 cnt = make_int4(0, 0, 0, 0);
-  if (e < d.n) {
+  if (el < d.ne) {
     cnt = d.counters[e];
     w = d.world_idx[e];
     const int collision = d.collision[e];
@@ -944,9 +946,9 @@ void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st) {
 void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st,
                           hipEvent_t ev0, hipEvent_t ev1) {
   if (d.cfg.use_lidar && !lidar_obs)   // the step path behind a LiDAR launch that wrote the float32 closeness itself
-    hipExtLaunchKernelGGL(k3_reward_lanes, dim3((d.n + AUV_WAVE - 1) / AUV_WAVE), dim3(AUV_WAVE), 0, st, ev0, ev1, 0, d, obs, reward, done);
+    hipExtLaunchKernelGGL(k3_reward_lanes, dim3((d.ne + AUV_WAVE - 1) / AUV_WAVE), dim3(AUV_WAVE), 0, st, ev0, ev1, 0, d, obs, reward, done);
   else
-    hipExtLaunchKernelGGL(k3_reward, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, ev0, ev1, 0, d, obs, reward, done, lidar_obs);
+    hipExtLaunchKernelGGL(k3_reward, dim3((d.ne + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK), dim3(AUV_BLOCK), 0, st, ev0, ev1, 0, d, obs, reward, done, lidar_obs);
 }
 
 void auv_launch_k3_fresh(const AuvDev& d, float* obs, hipStream_t st) {

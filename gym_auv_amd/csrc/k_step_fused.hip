@@ -1,14 +1,13 @@
-// k_step — the whole step() of one environment in ONE kernel, one wave per environment:
-//   Vessel.step (K1)  ->  Vessel.navigate (K3-nav)  ->  _update + Vessel.perceive (K2)  ->
-//   reward / done / bookkeeping / auto-reset (K3-reward),
-// built from the very same device functions as the individually launchable kernels
-// (k1_dynamics / k2_lidar / k3_nav / k3_reward), so the per-kernel parity tests cover its
-// arithmetic and tests/test_gpu_parity.py::test_fused_step_equals_kernel_sequence pins the
-// composition.  At 4096 environments the step is a chain of latency-bound phases; a single launch
-// removes three kernel boundaries (~2 us each on one stream, ~8 us across streams) and lets the
-// tail of one environment's LiDAR sweep overlap the other phases of its neighbours.
-// The new state and counters are handed from phase to phase in registers (EnvPre), so no lane
-// re-reads global memory that another lane of the wave has just written.
+// k_step_fused.hip -- the launch shapes of step() that put more than one phase into a launch, built from the very
+// same device functions as the individually launchable kernels (k1_dynamics / k2_lidar / k3_nav / k3_reward), so the
+// per-kernel parity tests cover their arithmetic and tests/test_gpu_parity.py pins the compositions bit for bit:
+//   k_step_roles            ONE launch per step: dynamics, LiDAR sweep, navigation + reward as three roles
+//   k23_lidar_nav<PAIRED>   K2 and K3-nav side by side in one launch (PAIRED: the navigation wave also finishes the step)
+//   k31_reward_dyn          inside a captured graph of several steps: reward phase of step t + dynamics of step t + 1
+// Every launch covers the slice [e0, e0 + ne) of the handle's environments (AuvDev::e0 / ne; the whole batch by
+// default): sub-batches of one handle stepped on different streams overlap each other's head and tail.
+// (Measured and removed in round 3, numbers in DESIGN.md: the whole step as one wave per environment, 66.9 M
+// env-steps/s; [K1 + navigation] -> [LiDAR + reward], 73.6 M; navigation forked onto a second stream, 64.5 M.)
 #include <cstdlib>
 #include <hip/hip_ext.h>
 
@@ -21,33 +20,18 @@
 #define AUV_K23_MIN_WAVES 4   // waves per SIMD the LiDAR launches are compiled for (128 VGPRs)
 #endif
 
-namespace {
+// Test hooks (tests/test_gpu_parity.py) exist only in the library built with -DAUV_TEST_HOOKS (make hooks ->
+// libauv_hip_hooks.so): idle workgroups between the roles (puts an environment's waves on different XCDs) and a
+// sweep that never publishes its word (the poll must run out and fail loudly).  The shipped library has neither.
+#ifdef AUV_TEST_HOOKS
+#define AUV_HOOK_SKEW(d) ((d).pair_skew)
+#define AUV_HOOK_FAULT(d) ((d).pair_fault)
+#else
+#define AUV_HOOK_SKEW(d) 0
+#define AUV_HOOK_FAULT(d) 0
+#endif
 
-template <typename AT>
-__global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __restrict__ actions,
-                                                       float* __restrict__ obs_out, float* __restrict__ reward_out,
-                                                       uint8_t* __restrict__ done_out) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int S = d.cfg.n_sensors;
-  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
-  if (e >= d.n) return;
-  const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
-  // K1: every lane advances the (same) vessel; lane 0 writes it back
-  const EnvPre pre = k1_env<AT>(d, e, actions, lane == 0);
-  // K3-nav: its chunk list borrows the (not yet used) segment stage of the LiDAR slice
-  k3_nav_env(d, e, lane, (unsigned char*)L.stage, obs_out, &pre);
-  auv_wave_lds_sync();
-  // K2
-  int collision = 0;
-  const int n_act = k2_front(d, e, lane, L, 1, &pre);
-  if (d.cfg.use_lidar) {
-    k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
-    collision = k2_back(d, e, lane, L, n_act, obs_out);
-  }
-  // K3-reward (lidar_d / closeness rows are re-read by the lanes that wrote them)
-  k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, &pre, collision, false, !d.cfg.use_lidar);
-}
+namespace {
 
 // ---- the paired finish: reward / done / auto-reset inside the side-by-side launch -------------------
 // An environment's LiDAR wave and its navigation wave are two one-wave workgroups of the same launch; the
@@ -78,7 +62,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, 3) k_step(AuvDev d, const AT* __res
 __device__ __forceinline__ void pair_publish_lidar(const AuvDev& d, const int e, const int lane, const int collision,
                                                    const double term) {
   auv_stores_done();                                       // of every lane of this wave (one counter per wave)
-  if (d.pair_fault && e == 0) return;                      // (test hook: tests/test_gpu_parity.py, the poll's time-out)
+  if (AUV_HOOK_FAULT(d) && e == d.e0) return;              // (test hook: the poll's time-out)
   if (lane == 0)
     __hip_atomic_store(d.pair_word + e, collision ? PAIR_COLLISION : (unsigned long long)__double_as_longlong(term),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -110,7 +94,7 @@ __device__ __forceinline__ void pair_finish_nav(const AuvDev& dk, const int e, c
                                                 float* __restrict__ obs_out, float* __restrict__ reward_out,
                                                 uint8_t* __restrict__ done_out) {
   unsigned long long word = pair_uniform(p.word);
-  const int limit = dk.pair_fault ? (1 << 12) : PAIR_POLL_LIMIT;
+  const int limit = AUV_HOOK_FAULT(dk) ? (1 << 12) : PAIR_POLL_LIMIT;
   for (int polls = 0; word == PAIR_EMPTY; polls++) {
     if (polls == limit) {
       if (lane == 0) __hip_atomic_store(dk.pair_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -148,13 +132,12 @@ __device__ __forceinline__ void pair_finish_nav(const AuvDev& dk, const int e, c
   }
 }
 
-// K2 and K3-nav of ALL environments in one launch: workgroups [0, nb) sweep the LiDAR of their
-// environments, workgroups [nb, 2 nb) navigate theirs.  The two are independent given the
-// new vessel state, so they run side by side (the LiDAR workgroups are dispatched first and fill
-// the chip; navigation workgroups move in as those retire) -- the concurrency of two streams
-// without the ~8 us a cross-stream event wait costs on each side.
-// PAIRED: the navigation wave also runs the reward phase (pair_finish_nav above); one-wave workgroups, nb a
-// multiple of 8 (+ pair_skew idle workgroups between the roles in the coherence tests).
+// K2 and K3-nav of the launch's environments in one launch of one-wave workgroups: workgroups [0, nb) sweep the LiDAR
+// of their environments, workgroups [nb, 2 nb) navigate theirs.  The two are independent given the new vessel state,
+// so they run side by side (the LiDAR workgroups are dispatched first and fill the chip; navigation workgroups move
+// in as those retire; a wave slot is handed on the moment an environment's sweep ends) -- the concurrency of two
+// streams without the ~8 us a cross-stream event wait costs on each side.
+// PAIRED: the navigation wave also runs the reward phase (pair_finish_nav above); nb a multiple of 8.
 #ifndef AUV_PAIR_WT
 #define AUV_PAIR_WT 1   // (0: plain stores in the paired launch -- a measurement build only, see pair_finish)
 #endif
@@ -166,17 +149,18 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
   // spilled any more -- was tried for the whole kernel: the loads then sit on the dependent chains, 36.3 -> 42.2 us)
   const AuvDev& d = dk;
   extern __shared__ __align__(16) unsigned char smem[];
-  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int lane = threadIdx.x;
   const int S = d.cfg.n_sensors;
-  const int wpb = blockDim.x / AUV_WAVE;                            // waves per workgroup
-  const int nb = PAIRED ? 8 * ((d.n + 7) / 8) : (d.n + wpb - 1) / wpb;   // LiDAR workgroups: one env per wave
-  const int nav0 = PAIRED ? nb + dk.pair_skew : nb;                 // first navigation workgroup
+  const int ne = d.ne;
+  const int nb = PAIRED ? 8 * ((ne + 7) / 8) : ne;                  // LiDAR workgroups: one environment each
+  const int nav0 = PAIRED ? nb + AUV_HOOK_SKEW(dk) : nb;            // first navigation workgroup
   const bool nav_role = (int)blockIdx.x >= nb;                      // workgroup-uniform
   constexpr bool WT = PAIRED && AUV_PAIR_WT;
-  unsigned char* slice = smem + wave * k2_slice_bytes(S, d.k_max, d.m_max);
+  unsigned char* slice = smem;
   if (nav_role) {
-    const int e = auv_uniform(((int)blockIdx.x - nav0) * wpb + wave);
-    if (e < 0 || e >= d.n) return;
+    const int el = (int)blockIdx.x - nav0;
+    if (el < 0 || el >= ne) return;
+    const int e = auv_uniform(d.e0 + el);
 #ifdef AUV_STAMPS
     const unsigned long long t_nav0 = wall_clock64();
 #endif
@@ -193,10 +177,10 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
     if (PAIRED && lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();     // end of the navigation wave incl. its finish
 #endif
   } else {
-    const int e = auv_uniform((int)blockIdx.x * wpb + wave);
-    if (e >= d.n) return;
+    if ((int)blockIdx.x >= ne) return;
+    const int e = auv_uniform(d.e0 + (int)blockIdx.x);
     // next action slot of a captured graph's ring: the dynamics kernel of this step has read the position, the
-    // one of the next step has not been launched yet
+    // one of the next step has not been launched yet (a captured step covers the whole batch: e0 = 0)
     if (e == 0 && lane == 0 && dk.ring_slots > 1 && dk.ring_slot_host == -1) *dk.ring_pos = (*dk.ring_pos + 1) % dk.ring_slots;
     const Slice L = carve(slice, S, d.k_max, d.m_max);
     AUV_STAMP_DECL
@@ -257,10 +241,30 @@ __device__ __forceinline__ double pair_lane_value(const unsigned long long v, co
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-#define ROLES_READY 1ull
+// The packet's eighth word is its "ready" mark AND a checksum of the other seven: (xor of words 0..6, xor a constant)
+// with bit 0 set; "down" is 0.  A reader accepts the payload only if the mark it loaded WITH it matches the payload,
+// so a request served in pieces (new mark, old state) can never pass -- the hand-over does not rest on the 64-byte
+// request being served atomically, and costs the reader a few scalar instructions, no second trip.
+#define ROLES_MAGIC 0x9e3779b97f4a7c15ull
+__device__ __forceinline__ unsigned long long roles_mark(const unsigned long long x) { return (x ^ ROLES_MAGIC) | 1ull; }
+
+// xor of `w` over the eight lanes of the caller's group (lanes 8 g .. 8 g + 7), by DPP moves: quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror -- no LDS, a dozen VALU instructions at the end of the dynamics' chain
+__device__ __forceinline__ unsigned long long roles_group_xor(const unsigned long long w) {
+  int lo = (int)(unsigned)w, hi = (int)(unsigned)(w >> 32);
+  lo ^= __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true), hi ^= __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+  lo ^= __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true), hi ^= __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+  lo ^= __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true), hi ^= __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+__device__ __forceinline__ unsigned long long roles_lane_word(const unsigned long long v, const int src) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src) << 32) |
+         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+}
+
 // the state the dynamics role left for environment e in this launch; false: gave up polling
 __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, const int lane, EnvPre& pre) {
-  const unsigned long long seq = ROLES_READY;
   const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
   // (polling harder does not pay: with two requests in flight per wave the packet is noticed sooner, but the
   // traffic of 3500 polling waves slows the dynamics role down by more -- 102.3 M against 104.7 M env-steps/s;
@@ -268,9 +272,13 @@ __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, c
   unsigned long long v = 0;
   for (int polls = 0;; polls++) {
     v = __hip_atomic_load(pk + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one 64-byte request per wave
-    const unsigned long long got = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 7) << 32) |
-                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 7);
-    if (got == seq) break;
+    const unsigned long long got = roles_lane_word(v, 7);
+    if (got != 0ull) {
+      unsigned long long x = roles_lane_word(v, 0);
+#pragma unroll
+      for (int i = 1; i < 7; i++) x ^= roles_lane_word(v, i);
+      if (roles_mark(x) == got) break;                       // mark and payload belong together
+    }
     if (polls == PAIR_POLL_LIMIT) {
       if (lane == 0) __hip_atomic_store(d.pair_error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return false;
@@ -283,8 +291,7 @@ __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, c
   return true;
 }
 
-template <typename AT>
-__global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvDev dk, const AT* __restrict__ actions,
+__global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvDev dk, const void* __restrict__ actions,
                                                                            float* __restrict__ obs_out,
                                                                            float* __restrict__ reward_out,
                                                                            uint8_t* __restrict__ done_out) {
@@ -306,18 +313,15 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     const int eg = d.e0 + (live ? er : ne - 1);                     // idle groups compute along, store nothing
     const size_t n = (size_t)d.n;
     const int y = d.counters[eg].y + 1;                             // Vessel._step_counter (vessel.py:247); requested up front
-    const double t = k1_group<AT>(d, actions, eg, lane);
+    const double t = k1_group(d, actions, eg, lane);
     unsigned long long* pk = d.k1_pkt + 8 * (size_t)eg;
-    if (live && c < 6) {
-      auv_st<true>(&d.state[(size_t)c * n + eg], t);
-      __hip_atomic_store(pk + c, (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (live && c == 6) {
-      __hip_atomic_store(&d.counters[eg].y, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(pk + 6, (unsigned long long)(unsigned)y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const unsigned long long word = c < 6 ? (unsigned long long)__double_as_longlong(t) : (c == 6 ? (unsigned long long)(unsigned)y : 0ull);
+    const unsigned long long mark = roles_mark(roles_group_xor(word));
+    if (live && c < 6) auv_st<true>(&d.state[(size_t)c * n + eg], t);
+    if (live && c < 7) __hip_atomic_store(pk + c, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (live && c == 6) __hip_atomic_store(&d.counters[eg].y, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     auv_stores_done();
-    if (live && c == 7) __hip_atomic_store(pk + 7, ROLES_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (live && c == 7) __hip_atomic_store(pk + 7, mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // a captured graph's action ring: every dynamics wave has read the position before it counts itself off, so
     // the last one to do so may move it on
     if (d.ring_slots > 1 && d.ring_slot_host == -1 && lane == 0) {
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #endif
   } else {
     // ---- Vessel.navigate of one environment, then its reward / done / auto-reset ----
-    const int el = b - nk - nb - d.pair_skew;
+    const int el = b - nk - nb - AUV_HOOK_SKEW(d);
     if (el < 0 || el >= ne) return;
     const int e = auv_uniform(d.e0 + el);
     ed = d.env_desc[e];
@@ -410,115 +414,11 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
   }
 }
 
-// ---- the default step: TWO launches --------------------------------------------------------------
-// k1n_dyn_nav      Vessel.step for eight environments by ONE wave (eight lanes per environment), then
-//                  Vessel.navigate of those eight by the workgroup's eight waves.  While the
-//                  dynamics are being integrated every wave runs its navigation's nearest-point
-//                  search against the pose BEFORE the step and fetches what it finds (nav_speculate);
-//                  behind the barrier only arithmetic on registers is left (nav_finish).
-// k2r_lidar_reward _update + Vessel.perceive of one environment per one-wave workgroup and, in the
-//                  same wave, reward / done / bookkeeping / auto-reset: the navigation's results
-//                  are a kernel boundary old by then, the sweep's are in registers.
-// Same device functions, hence the same bits, as the other launch shapes.
-#ifndef K1N_ENVS
-#define K1N_ENVS 8
-#endif
-#define K1N_THREADS ((K1N_ENVS + 1) * AUV_WAVE)   // eight navigation waves + the dynamics wave
-template <typename AT>
-__global__ void __launch_bounds__(K1N_THREADS, 5) k1n_dyn_nav(AuvDev d, const AT* __restrict__ actions,
-                                                            float* __restrict__ obs_out) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  double* sh = (double*)smem;                                       // [K1N_ENVS][8]: the new state
-  double* wins = sh + K1N_ENVS * 8;                                 // [K1N_ENVS][3][20]: parked spline windows
-  int* lists = (int*)(wins + K1N_ENVS * 3 * 20);                    // [K1N_ENVS][nch_max] surviving chunks
-  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const size_t n = (size_t)d.n;
-  const int e0 = (int)blockIdx.x * K1N_ENVS;
-  if (wave == K1N_ENVS) {
-    // ---- the dynamics wave: Vessel.step of the workgroup's eight environments, eight lanes each.  (Its own
-    // branch, so that the navigation's prefetched registers are not live across the integrator.)
-    const int g = lane / K1_GROUP, c = lane % K1_GROUP;
-    const bool live = g < K1N_ENVS && e0 + g < d.n;
-    const int eg = live ? e0 + g : d.n - 1;                         // idle groups compute along, store nothing
-    const double t = k1_group<AT>(d, actions, eg, lane);
-    if (live && c < 6) d.state[(size_t)c * n + eg] = t, sh[g * 8 + c] = t;
-    if (live && c == 0) d.counters[eg].y += 1;                      // Vessel._step_counter (vessel.py:247)
-    // cos / sin of the new heading, for the reward's cos(heading error) and for the LiDAR sweep of this
-    // step (k2_front): here they cost one sincos per eight environments instead of one per environment
-    double sn, co;
-    sincos(__shfl(t, lane - c + 2, AUV_WAVE), &sn, &co);
-    if (live && c == 6) sh[g * 8 + 6] = co, sh[g * 8 + 7] = sn, d.pose_cs[eg] = make_double2(co, sn);
-    __syncthreads();
-    return;
-  }
-  const int e = auv_uniform(e0 + wave);
-  const bool valid = e < d.n;
-#ifdef AUV_STAMPS
-  const unsigned long long t_wg0 = wall_clock64();
-#endif
-  // the navigation's search against the pose BEFORE the step, with every load it needs (chunk circles,
-  // the surviving chunks' segments, spline windows): all of it overlaps the dynamics.  (A wave that
-  // reads the state after the dynamics wave has already stored the new one merely gets a better guess.)
-  NavSpec sp;
-  if (valid) sp = nav_speculate(d, e, lane, lists + (size_t)wave * d.nch_max, d.state[0 * n + e], d.state[1 * n + e],
-                                2.0 * NAV_DELTA, wins + wave * 3 * 20);
-  __syncthreads();
-  if (!valid) return;
-  EnvPre pre;
-#pragma unroll
-  for (int i = 0; i < 6; i++) pre.s[i] = sh[wave * 8 + i];
-  pre.cnt = make_int4(0, 0, 0, 0);                                  // (the navigation does not look at the counters)
-#ifdef AUV_STAMPS
-  const unsigned long long t_nav0 = wall_clock64();
-#endif
-  const double2 cs = make_double2(sh[wave * 8 + 6], sh[wave * 8 + 7]);
-  nav_finish(d, e, lane, lists + (size_t)wave * d.nch_max, obs_out, &pre, sp, true, wins + wave * 3 * 20, &cs);
-#ifdef AUV_STAMPS
-  if (lane == 0) d.stamps[(size_t)e * 16 + 12] = t_nav0, d.stamps[(size_t)e * 16 + 13] = wall_clock64(), d.stamps[(size_t)e * 16 + 14] = t_wg0;
-#endif
-}
-
-__global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k2r_lidar_reward(AuvDev d, float* __restrict__ obs_out,
-                                                                 float* __restrict__ reward_out,
-                                                                 uint8_t* __restrict__ done_out) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x % AUV_WAVE;
-  const int S = d.cfg.n_sensors;
-  const int e = auv_uniform((int)blockIdx.x);
-  if (e >= d.n) return;
-  const Slice L = carve(smem, S, d.k_max, d.m_max);
-  AUV_STAMP_DECL
-#ifdef AUV_STAMPS
-  const unsigned long long t_real0 = wall_clock64();
-#endif
-  int collision = -1;
-  double term = 0.0;
-  const int n_act = k2_front(d, e, lane, L, 1, nullptr, d.pose_cs);
-  if (d.cfg.use_lidar) {
-    AUV_STAMP()
-    k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
-    AUV_STAMP()
-    collision = k2_back(d, e, lane, L, n_act, obs_out, &term);
-    AUV_STAMP()
-    AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
-#ifdef AUV_STAMPS
-    if (lane == 0) d.stamps[(size_t)e * 16 + 3] = t_real0, d.stamps[(size_t)e * 16 + 4] = wall_clock64();
-    if (lane == 0) d.stamps[(size_t)e * 16 + 5] = (unsigned long long)L.sbase[n_act];
-#endif
-  }
-  k3_reward_env(d, e, lane, true, obs_out, reward_out, done_out, nullptr, collision, false, !d.cfg.use_lidar,
-                d.cfg.use_lidar ? &term : nullptr);
-#ifdef AUV_STAMPS
-  if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();   // end of the reward phase
-#endif
-}
-
 // ---- inside a captured graph of several steps: reward / done / auto-reset of step t and Vessel.step of step t + 1
 // in ONE launch (the actions of an open-loop stretch are in the ring already, so nothing sits between the two).
 // Lanes <-> environments for both: the scalar form of the dynamics (k1_env: the same operations in the same order
 // as the eight-lane kernel, bit-identical) has the same dependent chain, and 64 of them share a wave.
-template <typename AT>
-__global__ void __launch_bounds__(AUV_WAVE) k31_reward_dyn(AuvDev d, const AT* __restrict__ actions, float* __restrict__ obs_out,
+__global__ void __launch_bounds__(AUV_WAVE) k31_reward_dyn(AuvDev d, const void* __restrict__ actions, float* __restrict__ obs_out,
                                                            float* __restrict__ reward_out, uint8_t* __restrict__ done_out) {
   const int lane = threadIdx.x;
   const int e = blockIdx.x * AUV_WAVE + lane;
@@ -542,53 +442,68 @@ __global__ void __launch_bounds__(AUV_WAVE) k31_reward_dyn(AuvDev d, const AT* _
   }
   // a restored environment's state was written by lane 0, its dynamics below read it from another lane
   if (any_reset) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  if (e < d.n) k1_env<AT>(d, e, actions, true);
+  if (e < d.n) k1_env(d, e, actions, true);
+}
+
+// ---- load-time probe of what the in-launch hand-overs rely on ----------------------------------------------------
+// The one-launch and paired shapes let a wave poll for a word that a workgroup with a SMALLER index of the same
+// launch stores.  That terminates if workgroups are dispatched in index order (a poller's producer is resident or
+// done by the time the poller gets a slot) -- what gfx950 does, but HIP does not promise it.  k_probe_order has the
+// step's structure without its arithmetic: `np` producers (a short wait, then an sc1 word each), behind them
+// consumers that poll their producer's word, publish a word of their own and are in turn polled by a second
+// generation -- three generations like dynamics / sweep / navigation, every workgroup one wave with the step's LDS
+// footprint, and several times more workgroups than the chip has slots.  Any poll that runs out (bounded: ~20 ms)
+// counts a failure; the host then keeps the handle on the three-launch shape (auv_capi.hip: probe_dispatch_order).
+__global__ void __launch_bounds__(AUV_WAVE) k_probe_order(unsigned int* __restrict__ words, int np, int nc, unsigned int tag,
+                                                          unsigned int* __restrict__ failures) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = (int)blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) smem[0] = 1;   // (touch the allocation so that it is not optimised away)
+  unsigned int* mine = words + b;
+  const unsigned int* src = nullptr;
+  if (b >= np + nc) src = words + np + (b - np - nc);          // third generation: its own second-generation wave
+  else if (b >= np) src = words + (b - np) % np;               // second generation: one of the producers
+  if (src) {
+    int polls = 0;
+    while (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      if (++polls == (1 << 14)) {
+        if (lane == 0) atomicAdd(failures, 1u);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+  } else {
+    __builtin_amdgcn_s_sleep(40), __builtin_amdgcn_s_sleep(40);   // ~2 us, like the dynamics' chain
+  }
+  if (lane == 0 && b < np + nc) __hip_atomic_store(mine, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
 
-void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st) {
-  const dim3 grid((d.n + AUV_WAVE - 1) / AUV_WAVE), block(AUV_WAVE);
-  if (dtype == AUV_F64)
-    hipLaunchKernelGGL(k31_reward_dyn<double>, grid, block, 0, st, d, (const double*)actions, obs, reward, done);
-  else
-    hipLaunchKernelGGL(k31_reward_dyn<float>, grid, block, 0, st, d, (const float*)actions, obs, reward, done);
+hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_probe_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_probe_order, dim3(np + 2 * nc), dim3(AUV_WAVE), lds, st, words, np, nc, tag, failures);
+  return hipGetLastError();
 }
 
-// the nav chunk list must fit the segment stage it borrows
-bool auv_step_fused_ok(const AuvDev& d) { return NAV_SCRATCH_BYTES(d.nch_max) <= (size_t)K2_SEG_CAP * 32; }
-
-void auv_launch_step_fused(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
-                           hipStream_t st) {
-  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
-  const dim3 grid((d.n + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK), block(AUV_BLOCK);
-  if (dtype == AUV_F64)
-    hipLaunchKernelGGL(k_step<double>, grid, block, lds, st, d, (const double*)actions, obs, reward, done);
-  else
-    hipLaunchKernelGGL(k_step<float>, grid, block, lds, st, d, (const float*)actions, obs, reward, done);
+void auv_launch_k31(const AuvDev& d0, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st) {
+  AuvDev d = d0;
+  d.act_f64 = dtype == AUV_F64;
+  const dim3 grid((d.n + AUV_WAVE - 1) / AUV_WAVE), block(AUV_WAVE);
+  hipLaunchKernelGGL(k31_reward_dyn, grid, block, 0, st, d, actions, obs, reward, done);
 }
 
 // the navigation role keeps its chunk list at the start of the wave's slice
 bool auv_k23_ok(const AuvDev& d) { return NAV_SCRATCH_BYTES(d.nch_max) <= k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
 
-// Workgroup shape of the side-by-side launch: ONE wave per workgroup, so a wave slot is handed on
-// the moment an environment's sweep ends instead of when the slowest of four does -- the
-// navigation workgroups queued behind the LiDAR ones start (and end) earlier.
-static int k23_wpb() {
-  static int wpb = 0;
-  if (!wpb) {
-    const char* v = getenv("AUV_K23_WPB");
-    wpb = v ? atoi(v) : 1;
-    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = 1;
-  }
-  return wpb;
-}
-
+// K2 + K3-nav side by side: ONE wave per workgroup, so a wave slot is handed on the moment an environment's sweep
+// ends -- the navigation workgroups queued behind the LiDAR ones start (and end) earlier.
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-  const int wpb = k23_wpb();
-  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * wpb;
-  const int nb = (d.n + wpb - 1) / wpb;
-  hipExtLaunchKernelGGL(k23_lidar_nav<false>, dim3(2 * nb), dim3(AUV_WAVE * wpb), (uint32_t)lds, st, ev0, ev1, 0, d, obs,
+  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  hipExtLaunchKernelGGL(k23_lidar_nav<false>, dim3(2 * d.ne), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs,
                         (float*)nullptr, (uint8_t*)nullptr);
 }
 
@@ -598,66 +513,32 @@ bool auv_paired_ok(const AuvDev& d) { return auv_k23_ok(d) && d.cfg.use_lidar; }
 void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0,
                            hipEvent_t ev1) {
   const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
-  const int nb = 8 * ((d.n + 7) / 8);
-  hipExtLaunchKernelGGL(k23_lidar_nav<true>, dim3(2 * nb + d.pair_skew), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs,
+  const int nb = 8 * ((d.ne + 7) / 8);
+  hipExtLaunchKernelGGL(k23_lidar_nav<true>, dim3(2 * nb + AUV_HOOK_SKEW(d)), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs,
                         reward, done);
-}
-
-// ---- launches of the two-kernel step ----
-static size_t k1n_lds_bytes(const AuvDev& d) {
-  return K1N_ENVS * 8 * sizeof(double) + K1N_ENVS * 3 * 20 * sizeof(double) + (size_t)K1N_ENVS * d.nch_max * sizeof(int);
-}
-bool auv_two_kernel_ok(const AuvDev& d) { return k1n_lds_bytes(d) <= 64 * 1024; }
-
-void auv_launch_k1n(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0,
-                    hipEvent_t ev1) {
-  const dim3 grid((d.n + K1N_ENVS - 1) / K1N_ENVS), block(K1N_THREADS);
-  const uint32_t lds = (uint32_t)k1n_lds_bytes(d);
-  if (dtype == AUV_F64)
-    hipExtLaunchKernelGGL(k1n_dyn_nav<double>, grid, block, lds, st, ev0, ev1, 0, d, (const double*)actions, obs);
-  else
-    hipExtLaunchKernelGGL(k1n_dyn_nav<float>, grid, block, lds, st, ev0, ev1, 0, d, (const float*)actions, obs);
-}
-
-void auv_launch_k2r(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0,
-                    hipEvent_t ev1) {
-  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
-  hipExtLaunchKernelGGL(k2r_lidar_reward, dim3(d.n), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs, reward, done);
 }
 
 // ---- the one-launch step ----
 bool auv_roles_ok(const AuvDev& d) { return auv_paired_ok(d); }
 
-void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
+void auv_launch_step_roles(const AuvDev& d0, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  AuvDev d = d0;
+  d.act_f64 = dtype == AUV_F64;
   const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
   const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
-  const dim3 grid(nk + 2 * nb + d.pair_skew), block(AUV_WAVE);
-  if (dtype == AUV_F64)
-    hipExtLaunchKernelGGL(k_step_roles<double>, grid, block, lds, st, ev0, ev1, 0, d, (const double*)actions, obs, reward, done);
-  else
-    hipExtLaunchKernelGGL(k_step_roles<float>, grid, block, lds, st, ev0, ev1, 0, d, (const float*)actions, obs, reward, done);
+  const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d)), block(AUV_WAVE);
+  hipExtLaunchKernelGGL(k_step_roles, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
 }
 
+uint32_t auv_step_lds_bytes(const AuvDev& d) { return (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
+
 hipError_t auv_step_fused_prepare(const AuvDev& d) {
-  {
-    const size_t b1 = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
-    if (b1 > 64 * 1024) {
-      hipError_t e1 = hipFuncSetAttribute((const void*)k2r_lidar_reward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b1);
-      if (e1 != hipSuccess) return e1;
-    }
-  }
-  const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
+  const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
   if (b <= 64 * 1024) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k23_lidar_nav<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_step_roles<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_step_roles<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)k_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  return hipFuncSetAttribute((const void*)k_step_roles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
 }

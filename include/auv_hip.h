@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AUV_ABI_VERSION 1
+#define AUV_ABI_VERSION 2
 
 enum {
   AUV_OK = 0,
@@ -155,7 +155,7 @@ int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx
               float* obs_dev, void* stream);
 
 /* step(): _update -> vessel.step -> observe -> reward -> done, for all N envs.
- * actions_dev: [N][2] (thrust, rudder) of action_dtype AUV_F32/AUV_F64.
+ * actions_dev: [N][2] (thrust, rudder) of action_dtype AUV_F32/AUV_F64, 8- / 16-byte aligned.
  * obs_dev [N][6+S] f32, reward_dev [N] f32, done_dev [N] u8.             (environment.py:292-366) */
 int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
              float* reward_dev, uint8_t* done_dev, void* stream);
@@ -166,10 +166,16 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
  * sub-batch's LiDAR sweeps then run under another's dynamics chain and navigation tail -- the batched analogue
  * of the reference's SubprocVecEnv workers stepping at their own pace (scripts/run.py:293-296; VecEnv
  * step_async / step_wait).  Results are bit-identical to auv_step over the same environments.  Ordering between
- * sub-batches and with the consumer of obs / reward / done is the CALLER's (stream order, events).  Needs the
- * one-launch or the three-launch shape; eager only (not capturable together with an action ring).          */
+ * sub-batches and with the consumer of obs / reward / done is the CALLER's (stream order, events).  Eager only
+ * (a captured graph steps the whole batch).                                                                  */
 int auv_step_slice(auv_handle_t* h, int32_t e0, int32_t ne, const void* actions_dev, int32_t action_dtype,
                    float* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+/* The same for ALL sub-batches with one call: slice i = [bounds[i], bounds[i + 1]) goes to streams[i]
+ * (bounds[0] = 0, bounds[n_slices] = N; HOST arrays).  One step of the whole batch as n_slices independent
+ * launch chains -- what a VecEnv.step_async() of this handle enqueues.                                        */
+int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams,
+                       const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
+                       uint8_t* done_dev);
 
 /* The three kernels of step(), individually launchable (per-kernel parity tests):        */
 /* K1  Vessel.step: clip -> RKF45 of the 3-DOF model -> wrap psi.  (vessel.py:226-247,561-578) */
@@ -211,42 +217,47 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
  * resets the ring to one slot.                                                                */
 int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 
-/* How auv_step / auv_graph_capture run a step (same results, bit for bit):
- *   AUV_STEP_ONE_LAUNCH (default)    the whole step in ONE launch of one-wave workgroups with three roles: the
+/* How auv_step / auv_step_slice / auv_graph_capture run a step (same results, bit for bit):
+ *   AUV_STEP_AUTO (default)          AUV_STEP_ONE_LAUNCH for launches of fewer than 16384 environments,
+ *                                    AUV_STEP_SIDE_BY_SIDE from there on (where it is the faster one).
+ *   AUV_STEP_ONE_LAUNCH              the whole step in ONE launch of one-wave workgroups with three roles: the
  *                                    first n / 8 integrate the dynamics (K1, eight environments per wave), the
  *                                    next n sweep the LiDAR of one environment each (K2), the last n navigate one
  *                                    environment each (K3-nav) and run its reward / done / auto-reset (K3-reward).
  *                                    The roles hand their results on inside the launch through per-environment
  *                                    words stored and loaded coherently (csrc/k_step_fused.hip: k_step_roles,
- *                                    pair_finish_nav); waves that need a result poll for it, bounded -- if a
- *                                    poll ever runs out, every later auv_step / auv_graph_launch / auv_step_timed
- *                                    fails with AUV_ESTATE.  Needs the LiDAR on; without it the step falls back
- *                                    to the shapes below.  Capturable (no launch argument changes from step to
- *                                    step); a graph of SEVERAL steps uses the side-by-side shape with its fused
- *                                    reward + dynamics launch all the same, because that replays faster.
+ *                                    pair_finish_nav); waves that need a result poll for it, bounded.
  *   AUV_STEP_PAIRED                  K1 -> one launch whose workgroups do K2 for all envs and K3-nav for all envs
  *                                    side by side, the navigation wave also running K3-reward.  Two launches.
- *   AUV_STEP_SIDE_BY_SIDE            K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward; inside a
- *                                    captured graph of several steps K3-reward of step t and K1 of step t + 1
- *                                    share a launch (also what a graph captured in the two modes above uses).
- *   AUV_STEP_TWO_KERNELS             [K1 -> K3-nav] -> [K2 -> K3-reward]: Vessel.step of eight
- *                                    environments by one wave while the workgroup's other eight run
- *                                    their navigation's search against the pose before the step;
- *                                    then one wave per environment sweeps the LiDAR and finishes
- *                                    the step (reward, done, auto-reset).  Two launches.
- *   AUV_STEP_ONE_KERNEL              the whole step in one kernel, one wave per env running
- *                                    K1 -> K3-nav -> K2 -> K3-reward back to back.
- *   AUV_STEP_TWO_STREAMS             K1 -> { K2 || K3-nav on an auxiliary stream } -> K3-reward. */
-enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_KERNEL = 1, AUV_STEP_TWO_STREAMS = 2, AUV_STEP_TWO_KERNELS = 3, AUV_STEP_PAIRED = 4,
-       AUV_STEP_ONE_LAUNCH = 5 };
+ *   AUV_STEP_SIDE_BY_SIDE            K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward: nothing is
+ *                                    handed over inside a launch.  Inside a captured graph of several steps
+ *                                    K3-reward of step t and K1 of step t + 1 share a launch (also what a graph
+ *                                    of several steps captured in the modes above uses: it replays faster).
+ * The in-launch hand-overs of ONE_LAUNCH and PAIRED assume that the workgroups of a launch are dispatched in index
+ * order (a polling wave's producer has a smaller index; true on gfx950, not promised by HIP).  Every bank load
+ * therefore runs a probe launch of the same structure (more one-wave workgroups than the chip has slots, three
+ * generations polling each other); if any of its polls runs out, and whenever the LiDAR is off, the handle steps in
+ * AUV_STEP_SIDE_BY_SIDE whatever mode is set.  Should a poll of a real step ever run out (bounded: seconds), the
+ * NEXT call on the handle returns AUV_ESTATE once, having cleared the hand-over words, put EVERY environment back
+ * into its reset state and switched the handle to AUV_STEP_SIDE_BY_SIDE for good; later calls succeed.  A step
+ * replayed from a captured graph (hipGraphLaunch, or a torch CUDAGraph around auv_step) is not checked per replay:
+ * poll auv_health() once per rollout there.
+ * (Removed in round 3, measured slower: the whole step as one kernel, [K1 + K3-nav] -> [K2 + K3-reward], and
+ * K3-nav forked onto a second stream; their enum values 1, 2, 3 are rejected.)                                */
+enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_PAIRED = 4, AUV_STEP_ONE_LAUNCH = 5, AUV_STEP_AUTO = 6 };
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
+/* The shape a launch of n_envs_per_launch environments (<= 0: the whole batch) is really stepped in: AUV_STEP_*. */
+int auv_effective_step_mode(auv_handle_t* h, int32_t n_envs_per_launch);
+/* out4: [0] 1 = in-launch hand-overs in use, [1] polls of the load-time probe that ran out (-1: no bank yet),
+ *       [2] hand-over time-outs over the life of the handle, [3] 1 = a time-out is pending (the next step call
+ *       will recover and return AUV_ESTATE).  Reads host memory only: no synchronisation.                       */
+int auv_health(auv_handle_t* h, int32_t* out4);
 
 /* One step with every dispatch stamped with its own start / stop HIP event on `stream` (the kernel's
- * own duration, as a kernel trace reports it).  out_ms[0..3] by mode:
- *   AUV_STEP_ONE_LAUNCH   the one launch, 0, 0, whole step
- *   AUV_STEP_PAIRED       K1, [K2 + K3-nav + K3-reward], 0, whole step (first start .. last stop)
- *   AUV_STEP_TWO_KERNELS  [K1 + K3-nav], [K2 + K3-reward], 0, whole step
- *   any other mode        the side-by-side shape is timed: K1, [K2 + K3-nav], K3-reward, whole step. */
+ * own duration, as a kernel trace reports it).  out_ms[0..3] by effective mode:
+ *   AUV_STEP_ONE_LAUNCH    the one launch, 0, 0, whole step
+ *   AUV_STEP_PAIRED        K1, [K2 + K3-nav + K3-reward], 0, whole step (first start .. last stop)
+ *   AUV_STEP_SIDE_BY_SIDE  K1, [K2 + K3-nav], K3-reward, whole step. */
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                    float* reward_dev, uint8_t* done_dev, void* stream, float* out_ms4);
 

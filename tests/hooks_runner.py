@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Cases that need the TEST-HOOK build of the library (gym_auv_amd/csrc/libauv_hip_hooks.so, `make hooks`): roles skewed
+onto different XCDs, and a sweep that withholds its word so that a poll runs out.  The shipped library has no such
+hooks, and one process can only hold one build of it, so tests/test_gpu_parity.py runs this file in a child process
+with AUV_HIP_LIB pointing at the hook build and reads one JSON line per case.
+
+    AUV_HIP_LIB=gym_auv_amd/csrc/libauv_hip_hooks.so python tests/hooks_runner.py
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FIELDS = ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO",
+          "WORLD_IDX", "CULL_LIMITS", "COLLISION", "REWARD64")
+
+
+def mixed_bank(n):
+    from gym_auv_amd.scenarios import moving_obstacles_world, polygon_world, static_circles_world
+    from gym_auv_amd.world import build_world, pack_bank
+    specs = []
+    for i in range(n):
+        if i % 3 == 0:
+            specs.append(moving_obstacles_world(1000 + i))
+        elif i % 3 == 1:
+            specs.append(static_circles_world(1000 + i, 20))
+        else:
+            specs.append(polygon_world(1000 + i, 12, n_circles=4, n_moving=3))
+    return pack_bank([build_world(s) for s in specs])
+
+
+def main():
+    from gym_auv_amd import _capi
+    from gym_auv_amd.batched_env import _LIB, BatchedAuvEnv, _check
+    from gym_auv_amd.config import effective_reference_config
+    assert hasattr(_LIB, "auv_test_hooks"), "not the hook build: %s" % os.environ.get("AUV_HIP_LIB")
+    bank = mixed_bank(32)
+
+    def env_(cfg, n, mode, skew=0, fault=0):
+        e = BatchedAuvEnv(cfg, bank, n, device="cuda:0", auto_reset=True)
+        e.set_step_mode(mode)
+        _check(_LIB.auv_test_hooks(e._h, skew, fault), "auv_test_hooks")
+        e.reset()
+        return e
+
+    # ---- the hand-overs with an environment's waves on DIFFERENT XCDs (three idle workgroups between the roles):
+    # bit for bit the three-launch shape over short episodes (every environment restored >= 10 times)
+    for mode in ("paired", "one_launch"):
+        n = 1024
+        cfg = effective_reference_config(use_lidar=True)
+        cfg.episode.max_timesteps = 5
+        ref, par = env_(cfg, n, "side_by_side"), env_(cfg, n, mode, skew=3)
+        rs = np.random.RandomState(20)
+        ok, n_done = True, 0
+        for k in range(60):
+            a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=torch.float32, device="cuda:0")
+            o0, r0, d0, _ = ref.step(a)
+            o1, r1, d1, _ = par.step(a)
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1)
+            n_done += int(d0.sum())
+            if k % 7 == 0 or k == 59:
+                ok = ok and all(torch.equal(ref.read(f), par.read(f)) for f in FIELDS)
+        print(json.dumps(dict(case="skew", mode=mode, bitwise=bool(ok), n_done=n_done, n=n, effective=par.effective_step_mode())), flush=True)
+        ref.close(), par.close()
+
+    # ---- a poll that runs out: the launch ENDS, the next call reports it once, every environment is back in its
+    # reset state, the handle goes on in the three-launch shape -- bit for bit what a fresh handle does from reset
+    for mode in ("paired", "one_launch"):
+        n = 64
+        cfg = effective_reference_config(use_lidar=True)
+        env = env_(cfg, n, mode, fault=1)
+        a = torch.zeros((n, 2), dtype=torch.float32, device="cuda:0")
+        h0 = env.health()
+        env.step(a)                                  # the faulty launch itself is enqueued normally ...
+        torch.cuda.synchronize()                     # ... and ENDS (no hang)
+        h1 = env.health()
+        msg = ""
+        try:
+            env.step(a)
+        except RuntimeError as exc:
+            msg = str(exc)
+        h2 = env.health()
+        ref = env_(cfg, n, "side_by_side")
+        same_reset = all(torch.equal(ref.read(f), env.read(f)) for f in FIELDS if f not in ("EPISODE", "COUNTERS", "STEP_INFO", "REWARD64"))
+        ok = True
+        for _ in range(5):
+            o0, r0, d0, _ = ref.step(a)
+            o1, r1, d1, _ = env.step(a)              # (fault hook still on: the three-launch shape has no hand-over to fail)
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1)
+        ok = ok and all(torch.equal(ref.read(f), env.read(f)) for f in ("STATE", "LIDAR_D", "OBS64", "NAV64", "MOVER_STATE", "NEARBY", "CULL_LIMITS"))
+        print(json.dumps(dict(case="fault", mode=mode, before=h0, after_launch=h1, after_recovery=h2, message=msg,
+                              reset_state_equal=bool(same_reset), continues_bitwise=bool(ok),
+                              effective=env.effective_step_mode())), flush=True)
+        ref.close(), env.close()
+
+
+if __name__ == "__main__":
+    main()

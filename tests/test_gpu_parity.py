@@ -244,16 +244,17 @@ def test_graph_replay_matches_eager():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_step_modes_agree_bitwise(dtype):
-    """every launch shape of the step (one launch with three roles -- the default --, paired, side-by-side, two kernels,
-    one kernel per wave, two streams): bitwise the same."""
+    """every launch shape of the step (one launch with three roles, paired, side-by-side, and the default that picks
+    between them by size): bitwise the same."""
     n = 64
     bank = _mixed_bank(32)
     cfg = effective_reference_config(use_lidar=True)
     cfg.episode.max_timesteps = 9
     envs = []
-    for mode in ("two_kernels", "side_by_side", "one_kernel", "two_streams", "paired", "one_launch"):
+    for mode in ("side_by_side", "paired", "one_launch", "auto"):
         e = _env(cfg, bank, n)
         e.set_step_mode(mode)
+        assert e.effective_step_mode() == ("one_launch" if mode == "auto" else mode)
         e.reset()
         envs.append(e)
     rs = np.random.RandomState(5)
@@ -261,7 +262,7 @@ def test_step_modes_agree_bitwise(dtype):
         a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=dtype, device="cuda:0")
         outs = [e.step(a)[:3] for e in envs]
         torch.cuda.synchronize()
-        for other in (1, 2, 3, 4, 5):
+        for other in (1, 2, 3):
             for x, y in zip(outs[0], outs[other]):
                 assert torch.equal(x, y)
             for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO"):
@@ -269,13 +270,12 @@ def test_step_modes_agree_bitwise(dtype):
 
 
 @pytest.mark.parametrize("mode", ["paired", "one_launch"])
-@pytest.mark.parametrize("skew", [0, 3])
-def test_paired_step_bitwise_with_many_resets(skew, mode, monkeypatch):
-    """The paired step (the second of an environment's two waves runs the reward phase inside the side-by-side
-    launch) against the three-launch default, bit for bit, over short episodes: every environment is restored many
-    times, by whichever of its two waves ends last.  skew = 3 puts the two roles of an environment on DIFFERENT
-    XCDs (three idle workgroups between them), so the hand-over and the restore rows cross L2s; skew = 0 is the
-    production placement (same XCD)."""
+def test_paired_step_bitwise_with_many_resets(mode):
+    """The in-launch hand-overs (paired: the second of an environment's two waves runs the reward phase inside the
+    side-by-side launch; one_launch: the dynamics role too) against the three-launch shape, bit for bit, over short
+    episodes: every environment is restored many times, by whichever of its waves ends last.  Production placement
+    (an environment's waves share an XCD); the same with the roles skewed onto different XCDs needs the hook build:
+    test_hook_build_cases."""
     n = 1024
     bank = _mixed_bank(32)
     cfg = effective_reference_config(use_lidar=True)
@@ -283,11 +283,10 @@ def test_paired_step_bitwise_with_many_resets(skew, mode, monkeypatch):
     ref = _env(cfg, bank, n)
     ref.set_step_mode("side_by_side")
     ref.reset()
-    monkeypatch.setenv("AUV_PAIR_SKEW", str(skew))
     par = _env(cfg, bank, n)
     par.set_step_mode(mode)
     par.reset()
-    rs = np.random.RandomState(17 + skew)
+    rs = np.random.RandomState(17)
     fields = ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO",
               "WORLD_IDX", "CULL_LIMITS", "COLLISION", "REWARD64")
     n_done = 0
@@ -308,35 +307,124 @@ def test_paired_step_bitwise_with_many_resets(skew, mode, monkeypatch):
     assert ms[2] == 0.0 and len(par.timed_kernel_names()) == (2 if mode == "paired" else 1) and torch.equal(ref.obs, par.obs)
 
 
-@pytest.mark.parametrize("mode", ["paired", "one_launch"])
-def test_hand_over_timeout_fails_loudly_and_does_not_hang(mode, monkeypatch):
-    """The waits inside the one-launch / paired step are bounded.  With environment 0's sweep withholding its word
-    (test hook AUV_PAIR_FAULT) its navigation wave gives up after a bounded number of polls, the launch ends, and
-    every later step raises instead of returning half-finished results; loading a bank again clears the condition."""
+@pytest.fixture(scope="module")
+def hook_cases():
+    """tests/hooks_runner.py in a child process that loads the TEST-HOOK build of the library (the shipped one has no
+    hooks; a process holds one build): one JSON line per case."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from gym_auv_amd import _capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(_capi.HOOKS_LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(root, "gym_auv_amd", "csrc"), "-j4", "hooks"])
+    env = dict(os.environ, AUV_HIP_LIB=_capi.HOOKS_LIB_PATH)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "hooks_runner.py")], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_hook_build_cases(hook_cases):
+    """(a) hand-overs across XCDs: with three idle workgroups between the roles an environment's waves sit on
+    different XCDs, so the packet, the word and the restore rows cross L2s -- still bit for bit the three-launch shape.
+    (b) the waits inside the one-launch / paired step are bounded: with one sweep withholding its word its navigation
+    wave gives up, the launch ENDS, the next call raises once ("timed out") having put every environment back into
+    its reset state, and the handle carries on in the three-launch shape, bit for bit what a fresh handle does."""
+    skew = [c for c in hook_cases if c["case"] == "skew"]
+    fault = [c for c in hook_cases if c["case"] == "fault"]
+    assert {c["mode"] for c in skew} == {"paired", "one_launch"} and {c["mode"] for c in fault} == {"paired", "one_launch"}
+    for c in skew:
+        assert c["bitwise"] and c["n_done"] >= 10 * c["n"] and c["effective"] == c["mode"], c
+    for c in fault:
+        assert c["before"] == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0), c
+        assert c["after_launch"]["pending"] == 1, c
+        assert "timed out" in c["message"] and "reset" in c["message"], c
+        assert c["after_recovery"] == dict(handover_ok=0, probe_failures=0, timeouts=1, pending=0), c
+        assert c["reset_state_equal"] and c["continues_bitwise"] and c["effective"] == "side_by_side", c
+
+
+def test_shipped_library_has_no_test_hooks(monkeypatch):
+    """The product library neither exports the hook entry point nor reads the environment variables older builds did:
+    with all of them set a step is what it is without them."""
+    from gym_auv_amd.batched_env import _LIB
+    assert not hasattr(_LIB, "auv_test_hooks")
+    for k in ("AUV_PAIR_FAULT", "AUV_PAIR_SKEW", "AUV_K23_WPB"):
+        monkeypatch.setenv(k, "1")
     n = 64
+    bank = _mixed_bank(8)
+    cfg = effective_reference_config(use_lidar=True)
+    env, ref = _env(cfg, bank, n), _env(cfg, bank, n)
+    env.set_step_mode("one_launch"), ref.set_step_mode("side_by_side")
+    env.reset(), ref.reset()
+    a = torch.zeros((n, 2), dtype=torch.float32, device="cuda:0")
+    for _ in range(3):
+        o1, r1, d1, _ = env.step(a)
+        o0, r0, d0, _ = ref.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(r0, r1) and env.health()["pending"] == 0
+
+
+def test_probe_health_and_mode_selection():
+    """Every bank load probes the dispatch order the in-launch hand-overs rely on; on this hardware it passes, the
+    default mode then is the one-launch shape below 16384 environments per launch and the three-launch shape from
+    there on; the removed shapes are rejected."""
+    import ctypes as C
+    from gym_auv_amd.batched_env import _LIB
+    bank = _mixed_bank(4)
+    env = _env(effective_reference_config(use_lidar=True), bank, 16)
+    assert env.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0)
+    assert env.step_mode == "auto" and env.effective_step_mode() == "one_launch"
+    assert env.effective_step_mode(16383) == "one_launch" and env.effective_step_mode(16384) == "side_by_side"
+    for removed in (1, 2, 3, 7, -1):
+        assert _LIB.auv_set_step_mode(env._h, removed) != 0
+    nol = _env(effective_reference_config(use_lidar=False), bank, 16)      # no sweep, nothing to hand over
+    assert nol.effective_step_mode() == "side_by_side"
+    # a misaligned action buffer is refused (the kernels fetch a pair with one load)
+    buf = torch.zeros(16 * 2 + 1, dtype=torch.float32, device="cuda:0")
+    rc = _LIB.auv_step(env._h, C.c_void_p(buf.data_ptr() + 4), 0, C.c_void_p(env.obs.data_ptr()), C.c_void_p(env.reward.data_ptr()),
+                       C.c_void_p(env.done.data_ptr()), env._stream())
+    assert rc != 0 and b"aligned" in _LIB.auv_last_error()
+
+
+@pytest.mark.parametrize("mode", ["auto", "paired", "side_by_side"])
+@pytest.mark.parametrize("n,k", [(1000, 3), (192, 2), (70, 4)])
+def test_sub_batches_bitwise(mode, n, k):
+    """The batch stepped as k sub-batches on k streams (auv_step_slice / auv_step_pipelined; VecEnv step_async /
+    step_wait) against one launch over all environments: bit for bit, over short episodes with auto-reset, ragged
+    sizes included (the last slice is shorter; boundaries are multiples of 64)."""
     bank = _mixed_bank(32)
     cfg = effective_reference_config(use_lidar=True)
-    monkeypatch.setenv("AUV_PAIR_FAULT", "1")
-    env = _env(cfg, bank, n)
-    env.set_step_mode(mode)
-    env.reset()
-    a = torch.zeros((n, 2), dtype=torch.float32, device="cuda:0")
-    env.step(a)                                  # the faulty launch itself is enqueued normally ...
-    torch.cuda.synchronize()                     # ... and ENDS (no hang)
-    with pytest.raises(RuntimeError, match="timed out"):
-        env.step(a)
-    monkeypatch.delenv("AUV_PAIR_FAULT")
-    env.set_step_mode(mode)                      # (re-reads the hook)
-    env.load_worlds(bank)                        # a fresh bank clears the condition
-    env.reset()
-    ref = _env(cfg, bank, n)
-    ref.set_step_mode("side_by_side")
-    ref.reset()
-    for _ in range(3):
+    cfg.episode.max_timesteps = 7
+    ref, sub, asy = _env(cfg, bank, n), _env(cfg, bank, n), _env(cfg, bank, n)
+    for e in (ref, sub, asy):
+        e.set_step_mode(mode)
+        e.reset()
+    slices = sub.set_sub_batches(k)
+    asy.set_sub_batches(k)
+    assert slices[0][0] == 0 and sum(c for _, c in slices) == n and all(lo % 64 == 0 for lo, _ in slices)
+    rs = np.random.RandomState(3)
+    fields = ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO",
+              "WORLD_IDX", "CULL_LIMITS", "COLLISION", "REWARD64")
+    for t in range(40):
+        a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=torch.float32, device="cuda:0")
         o0, r0, d0, _ = ref.step(a)
-        o1, r1, d1, _ = env.step(a)
-    torch.cuda.synchronize()
-    assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1)
+        if t % 2:
+            for i in range(sub.sub_batches):
+                sub.step_slice(i, a)
+        else:
+            sub.step_pipelined(a)
+        asy.step_async(a)
+        o2, r2, d2, _ = asy.step_wait()
+        torch.cuda.synchronize()
+        assert torch.equal(o0, sub.obs) and torch.equal(r0, sub.reward) and torch.equal(d0, sub.done), t
+        assert torch.equal(o0, o2) and torch.equal(r0, r2) and torch.equal(d0, d2), t
+        if t % 9 == 0 or t == 39:
+            for f in fields:
+                assert torch.equal(ref.read(f), sub.read(f)) and torch.equal(ref.read(f), asy.read(f)), (t, f)
+    with pytest.raises(RuntimeError):
+        asy.step_wait()                                        # nothing pending
 
 
 def test_action_ring_graph_and_eager_after_capture():
@@ -437,11 +525,11 @@ def test_long_soak_vs_oracle():
     assert n_done >= 3 * n
 
 
-def test_two_kernel_mode_vs_oracle_incl_speculation_miss():
-    """The two-kernel step searches the path against the pose BEFORE the step and finishes with the new one.  With
-    dt = 0.5 s the vessel moves a fraction of a metre and the guess always covers it; with dt = 8 s it moves several
-    metres per step, the guess is rejected (|p - q| > NAV_DELTA) and the search is redone for the real pose.  Both
-    regimes against the oracle, every field, plus bitwise agreement with the default launch shape."""
+def test_large_time_step_vs_oracle():
+    """dt = 0.5 s (the reference's effective step: the vessel moves a fraction of a metre per step, the navigation's
+    hint chunk from last step almost always still holds the nearest point) and dt = 8 s (several metres per step: the
+    hint is stale, the upper bound loose, more chunks survive).  Both regimes against the oracle, every field, plus
+    bitwise agreement between the one-launch and the three-launch shapes."""
     n = 96
     bank = _mixed_bank(32)
     for dt in (0.5, 8.0):
@@ -449,8 +537,8 @@ def test_two_kernel_mode_vs_oracle_incl_speculation_miss():
         cfg.simulation.t_step_size = dt
         cfg.episode.max_timesteps = 40
         env = _env(cfg, bank, n, auto_reset=True)
-        env.set_step_mode("two_kernels")
         ref = _env(cfg, bank, n, auto_reset=True)
+        ref.set_step_mode("side_by_side")
         ora = _oracle(cfg, bank, n, auto_reset=True)
         env.reset(), ref.reset(), ora.reset()
         rs = np.random.RandomState(17)
@@ -473,5 +561,5 @@ def test_two_kernel_mode_vs_oracle_incl_speculation_miss():
                 np.testing.assert_allclose(_np(env.read(f)), ora.read(f), rtol=0, atol=ATOL if dt < 1 else 1e-7,
                                            err_msg="%s dt=%g step %d" % (f, dt, t))
             np.testing.assert_array_equal(_np(env.read("CULL_LIMITS")), ora.read("CULL_LIMITS"))
-        assert (moved < 1.0) if dt < 1 else (moved > 1.5), (dt, moved)   # the second regime really leaves the guess behind
+        assert (moved < 1.0) if dt < 1 else (moved > 1.5), (dt, moved)   # the second regime really leaves the hint behind
         env.close(), ref.close()

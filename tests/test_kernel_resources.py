@@ -39,11 +39,12 @@ def test_side_by_side_kernel_fits_its_register_budget():
                  int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", b).group(1))) for b in blk]
 
     # (k_step_roles: the one-launch step -- dynamics, LiDAR and navigation + reward roles share its allocation)
-    for vgpr, spill, lds_static in usage("k_step_roles") + usage("k23_lidar_nav") + usage("k2r_lidar_reward"):
+    for vgpr, spill, lds_static in usage("k_step_roles") + usage("k23_lidar_nav"):
         assert vgpr <= 128, "LiDAR kernel needs %d VGPRs: fewer than 4 waves per SIMD" % vgpr
         assert spill <= 4, "LiDAR kernel spills %d VGPRs to scratch" % spill
         assert lds_static == 0          # the per-wave slice is dynamic LDS, sized by the host
-    # dynamics + navigation: two 9-wave workgroups per CU (all 512 of the headline batch resident) need
-    # 18 wave slots, i.e. 5 waves per SIMD: <= 96 VGPRs (a handful of spilled registers is the lesser evil)
-    for vgpr, spill, lds_static in usage("k1n_dyn_nav"):
-        assert vgpr <= 96 and spill <= 16, (vgpr, spill)
+    # the one-launch step keeps nothing in scratch memory (scalar registers spill to VGPR lanes only)
+    blk = [b for b in blocks if re.search(r"\.name:\s+\S*k_step_roles", b)]
+    assert all(int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", b).group(1)) == 0 for b in blk)
+    # one instantiation per kernel: the action dtype is a launch-time flag, not a template parameter (build time)
+    assert len(usage("k_step_roles")) == 1

@@ -69,9 +69,7 @@ def main():
                         env.step(pool[(i0 + i) % 64])
                 else:
                     for i in range(cnt):
-                        a = pool[(i0 + i) % 64]
-                        for s in range(env.sub_batches):
-                            env.step_slice(s, a)
+                        env.step_pipelined(pool[(i0 + i) % 64])
             run(0, args.warmup)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
