@@ -784,6 +784,16 @@ int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   return AUV_OK;
 }
 
+#ifdef AUV_CUTS
+// Only in the diagnostic build (tools/build_variant.sh cuts "-DAUV_CUTS"; tools/valu_budget.py): switch off the
+// LiDAR role's phases from `cut_lidar` on and the navigation role's from `cut_nav` on (0 = run everything).
+int auv_diag_cuts(auv_handle_t* h, int32_t cut_lidar, int32_t cut_nav) {
+  if (!h) return fail(AUV_EINVAL, "null handle");
+  h->d.cut_lidar = cut_lidar, h->d.cut_nav = cut_nav;
+  return AUV_OK;
+}
+#endif
+
 #ifdef AUV_TEST_HOOKS
 // Only in libauv_hip_hooks.so (make hooks): skew = idle workgroups between the roles of the one-launch / paired
 // shapes (an environment's waves then sit on different XCDs); fault = 1: the sweep of the first environment of every

@@ -83,6 +83,7 @@ struct AuvDev {
   int32_t* pair_error; // [1] paired step: set when a navigation wave gave up waiting for its sweep
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position
+  int32_t cut_lidar, cut_nav;  // diagnostic build only (-DAUV_CUTS, tools/valu_budget.py): phases from this number on are skipped
   int32_t pair_skew;   // paired step, test hook: idle workgroups between the two roles (puts them on different XCDs)
   int32_t pair_fault;  // paired step, test hook: environment 0's sweep never publishes its word (the poll must run out)
   const struct AuvDev* self;  // this struct in device memory (as of the last bank load): the paired step's restore path
@@ -119,6 +120,18 @@ struct EnvPre {
   int4 cnt;        // t_step, vessel step counter (already incremented), episodes, -
   const EnvDesc* ed = nullptr;   // the environment's descriptor where the caller has fetched it already
 };
+
+// Cumulative phase cuts (diagnostic build only, -DAUV_CUTS): AUV_RUN_L(d, n) is false when the LiDAR role's phases
+// from n on are switched off (cut_lidar = n), likewise AUV_RUN_N for the navigation role.  Differences of the SQ
+// counters between consecutive cut levels are the phases' dynamic instruction budgets (tools/valu_budget.py).
+// The product build compiles them to `true`.
+#ifdef AUV_CUTS
+#define AUV_RUN_L(d, n) ((d).cut_lidar == 0 || (d).cut_lidar > (n))
+#define AUV_RUN_N(d, n) ((d).cut_nav == 0 || (d).cut_nav > (n))
+#else
+#define AUV_RUN_L(d, n) true
+#define AUV_RUN_N(d, n) true
+#endif
 
 // In-kernel phase stamps (diagnostic build only: make STAMPS=1).  The stamp values leave the
 // kernel through `stamps` alone; no output is computed from them.

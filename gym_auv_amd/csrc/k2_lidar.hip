@@ -619,6 +619,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     if (lane == 0) L.sbase[0] = 0;
   }
   if (n_act == 0) return 0;                                  // nothing in sight: no rays, no sweep (k2_back writes the free row)
+  if (!AUV_RUN_L(d, 2)) return 0;
   k2_rays(d, lane, L, beams_staged);                         // phase C
   return n_act;
 }
@@ -756,6 +757,10 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
     if (T > K2_SEG_CAP) T = K2_SEG_CAP;
     auv_wave_lds_sync();
     SUB_ADD(c_stage)
+    if (!AUV_RUN_L(d, 4)) {
+      a0 = a1;
+      continue;
+    }
 
     // ---- phase D (i): obstacles containing p0 -> distance 0 on every ray of their window ----
     for (int ab = a0; ab < a1; ab += AUV_WAVE) {            // lanes <-> obstacles of the batch
@@ -794,6 +799,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 #ifdef AUV_STAMPS
     n_it += n_items;
 #endif
+    if (!AUV_RUN_L(d, 5)) n_items = 0;
     for (int it = lane; it < n_items; it += AUV_WAVE) {
       int lo = 0, hi = T;                                  // largest t with ioff[t] <= it
       while (hi - lo > 1) {
@@ -896,6 +902,7 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
       n_hit += __popcll(m);
     }
     auv_wave_lds_sync();
+    if (!AUV_RUN_L(d, 6)) n_hit = 0;
     // ---- the returns ----
     for (int h0 = 0; h0 < n_hit; h0 += AUV_WAVE) {
       const int h = h0 + lane;

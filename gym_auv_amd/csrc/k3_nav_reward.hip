@@ -584,6 +584,7 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
     wmask = __ballot(best.d == dmin && best.j == jm);
   }
   AUV_STAMP()
+  if (!AUV_RUN_N(d, 3)) return;
   // the winning lane hands over its segment (no second trip to memory)
   const int src = wmask ? __ffsll((long long)wmask) - 1 : 0;
   double2 A, B;
@@ -685,6 +686,7 @@ __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const i
   (void)wins;
   const NavSpec sp = nav_speculate(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
                                    0.0, nullptr, pre ? pre->ed : nullptr);
+  if (!AUV_RUN_N(d, 2)) return;
   nav_finish<WT>(d, e, lane, list, obs_out, pre, sp, true, nullptr, pose_cs ? pose_cs + e : nullptr, out);
 }
 
