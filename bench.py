@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=0,
                     help="0 (default): eager launches; K > 0: K consecutive steps captured in ONE hipGraph over the action "
                          "ring, one replay per K steps (steps not a multiple of K are finished eagerly)")
-    ap.add_argument("--step-mode", default="auto", choices=["auto", "side_by_side", "paired", "one_launch"],
+    ap.add_argument("--step-mode", default="auto", choices=["auto", "side_by_side", "paired", "one_launch", "two_launch", "four_roles"],
                     help="how a step is launched (include/auv_hip.h, AUV_STEP_*)")
     ap.add_argument("--actions", default="uniform", choices=["uniform", "pilot"],
                     help="uniform: i.i.d. U(action_space), resident in HBM (headline); pilot: closed loop, "
@@ -127,8 +127,8 @@ def algorithmic_bytes(bank, S, world_of_env, nearby):
 
 KERNEL_PHASES = {   # which phases of the step a launch performs (for its algorithmic byte count)
     "k1_dynamics": ("k1",), "k23_lidar_nav": ("lidar", "nav"), "k3_reward": ("reward",),
-    "k1n_dyn_nav": ("k1", "nav"), "k2r_lidar_reward": ("lidar", "reward"),
     "k23_lidar_nav_paired": ("lidar", "nav", "reward"), "k_step_roles": ("k1", "lidar", "nav", "reward"),
+    "k_step_search": ("k1", "lidar", "nav"), "k_tail_reward_lanes": ("reward",),
 }
 
 

@@ -223,7 +223,7 @@ class BatchedAuvEnv:
     def _lazy_info(self):
         return _LazyInfo(self)
 
-    STEP_MODES = {"side_by_side": 0, "paired": 4, "one_launch": 5, "auto": 6}
+    STEP_MODES = {"side_by_side": 0, "paired": 4, "one_launch": 5, "auto": 6, "two_launch": 7, "four_roles": 8}
     _MODE_NAMES = {v: k for k, v in STEP_MODES.items()}
 
     def set_step_mode(self, mode: str):
@@ -302,8 +302,10 @@ class BatchedAuvEnv:
 
     def timed_kernel_names(self):
         mode = self.effective_step_mode()
-        if mode == "one_launch":
+        if mode in ("one_launch", "four_roles"):
             return ["k_step_roles"]
+        if mode == "two_launch":
+            return ["k_step_search", "k_tail_reward_lanes"]     # (the kernel trace calls the first k_step_roles<false>)
         if mode == "paired":
             return ["k1_dynamics", "k23_lidar_nav_paired"]      # (the kernel trace calls it k23_lidar_nav<true>)
         return ["k1_dynamics", "k23_lidar_nav", "k3_reward"]

@@ -38,6 +38,12 @@ void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, floa
                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
                            hipEvent_t ev1 = nullptr);
+void auv_launch_step_roles4(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
+                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+void auv_launch_step_search(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr,
+                            hipEvent_t ev1 = nullptr);
+void auv_launch_tail_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
+                            hipEvent_t ev1 = nullptr);
 void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st);
 hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
@@ -198,6 +204,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.pose_cs, n);
   rc |= dev_alloc(ep, &d.pair_word, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
+  rc |= dev_alloc(ep, &d.nav_hand, 8 * n);
   rc |= dev_alloc(ep, &d.k1_done, 4);
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
@@ -675,6 +682,16 @@ static int enqueue_step(auv_handle_t* h, int mode, int e0, int ne, const void* a
     auv_launch_step_roles(d, actions, dtype, obs, reward, done, st);
     return AUV_OK;
   }
+  if (mode == AUV_STEP_FOUR_ROLES) {
+    auv_launch_step_roles4(d, actions, dtype, obs, reward, done, st);
+    return AUV_OK;
+  }
+  if (mode == AUV_STEP_TWO_LAUNCH) {
+    // [dynamics | sweep | path search as three roles of one launch] -> [navigation tail + reward, lanes <-> environments]
+    auv_launch_step_search(d, actions, dtype, obs, st);
+    auv_launch_tail_reward(d, obs, reward, done, st);
+    return AUV_OK;
+  }
   if (mode == AUV_STEP_PAIRED) {
     // K1 -> [K2 and K3-nav side by side, the second of an environment's two waves runs K3-reward]: two launches
     auv_launch_k1(d, actions, dtype, st);
@@ -774,7 +791,8 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
 
 int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   if (!h) return fail(AUV_EINVAL, "null handle");
-  if (mode != AUV_STEP_SIDE_BY_SIDE && mode != AUV_STEP_PAIRED && mode != AUV_STEP_ONE_LAUNCH && mode != AUV_STEP_AUTO)
+  if (mode != AUV_STEP_SIDE_BY_SIDE && mode != AUV_STEP_PAIRED && mode != AUV_STEP_ONE_LAUNCH && mode != AUV_STEP_AUTO &&
+      mode != AUV_STEP_TWO_LAUNCH && mode != AUV_STEP_FOUR_ROLES)
     return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
   h->step_mode = mode;
   if (h->graph_exec) {
@@ -966,6 +984,13 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   if (mode == AUV_STEP_ONE_LAUNCH) {
     auv_launch_step_roles(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, st, h->ev[0], h->ev[1]);
     nk = 1;
+  } else if (mode == AUV_STEP_FOUR_ROLES) {
+    auv_launch_step_roles4(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, st, h->ev[0], h->ev[1]);
+    nk = 1;
+  } else if (mode == AUV_STEP_TWO_LAUNCH) {
+    auv_launch_step_search(d, actions_dev, action_dtype, obs_dev, st, h->ev[0], h->ev[1]);
+    auv_launch_tail_reward(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
+    nk = 2;
   } else if (mode == AUV_STEP_PAIRED) {
     auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
     auv_launch_k23_paired(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);

@@ -81,6 +81,8 @@ struct AuvDev {
   double2* pose_cs;    // [N] cos, sin of the heading K1 has just produced (K1 -> LiDAR within one step only)
   unsigned long long* pair_word; // [N] paired step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
   int32_t* pair_error; // [1] paired step: set when a navigation wave gave up waiting for its sweep
+  double* nav_hand;            // [N][8] two-launch step: what the path search leaves for the navigation's tail (nav_tail_lane):
+                               //        end points of the nearest segment, arclength at its first vertex
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position
   int32_t cut_lidar, cut_nav;  // diagnostic build only (-DAUV_CUTS, tools/valu_budget.py): phases from this number on are skipped

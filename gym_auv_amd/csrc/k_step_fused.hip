@@ -291,6 +291,20 @@ __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, c
   return true;
 }
 
+// FINISH = false (the two-launch step): the navigation role only SEARCHES (nearest segment of the path -> NAV_HAND)
+// and nobody finishes the step here -- the sweep needs no write-through stores and publishes no word, nothing polls
+// for one; the second launch, k_tail_reward_lanes, evaluates the navigation's scalar tail and the reward phase with
+// lanes <-> environments: 64 environments per wave instead of three busy lanes per environment (the tail is 19 % of
+// the one-launch step's VALU issue cycles, profiles/r03/valu_budget_polygons50.json).
+// SHAPE 2 (the one-launch step with FOUR roles): as SHAPE 0 the navigation role only searches, but the tail and the
+// reward phase follow in this very launch -- a fourth role of ne / 64 waves behind the others, lanes <-> environments.
+// A lane waits (bounded poll, sc1 loads) for its environment's state packet, its sweep's word and the search's
+// NAV_HAND mark, evaluates the tail and the reward phase, takes the three marks down; environments that ended are
+// then restored by the whole wave, one after the other.
+#define SHAPE_SEARCH 0
+#define SHAPE_WAVE_FINISH 1
+#define SHAPE_TAIL_ROLE 2
+template <int SHAPE>
 __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvDev dk, const void* __restrict__ actions,
                                                                            float* __restrict__ obs_out,
                                                                            float* __restrict__ reward_out,
@@ -359,7 +373,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     pre.cnt = d.counters[e];                               // t_step, episodes; the step counter comes with the state
     pre.ed = &ed;
     const Slice L = carve(smem, S, d.k_max, d.m_max);
-    k2_movers<true>(d, e, lane, L, ed, 1);
+    k2_movers<SHAPE != SHAPE_SEARCH>(d, e, lane, L, ed, 1);
     const K2Pre kp = k2_prefetch(d, e, lane, ed);
     k2_stage_beams(d, lane, L);
     // (also tried here: warming the caches with the nearby obstacles' boundary segments -- it has to wait for the
@@ -372,19 +386,19 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     if (lane == 0) d.stamps[(size_t)e * 16 + 2] = wall_clock64();
 #endif
     int n_act = 0;
-    if (AUV_RUN_L(d, 1)) n_act = k2_front<true>(d, e, lane, L, 1, &pre, nullptr, 1, &kp, true);
+    if (AUV_RUN_L(d, 1)) n_act = k2_front<SHAPE != SHAPE_SEARCH>(d, e, lane, L, 1, &pre, nullptr, 1, &kp, true);
     if (AUV_RUN_L(d, 3)) k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
     double term = 0.0;
-    const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term);
+    const int collision = k2_back<SHAPE != SHAPE_SEARCH>(d, e, lane, L, n_act, obs_out, &term);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 4] = wall_clock64();
 #endif
-    pair_publish_lidar(d, e, lane, collision, term);
+    if constexpr (SHAPE != SHAPE_SEARCH) pair_publish_lidar(d, e, lane, collision, term);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 14] = wall_clock64();
 #endif
-  } else {
-    // ---- Vessel.navigate of one environment, then its reward / done / auto-reset ----
+  } else if (b < nk + 2 * nb + AUV_HOOK_SKEW(d)) {
+    // ---- Vessel.navigate of one environment (SHAPE_WAVE_FINISH: then its reward / done / auto-reset) ----
     const int el = b - nk - nb - AUV_HOOK_SKEW(d);
     if (el < 0 || el >= ne) return;
     const int e = auv_uniform(d.e0 + el);
@@ -398,20 +412,95 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 5] = wall_clock64();
 #endif
-    PairPre pp = pair_prefetch(d, e);
-    pp.cnt = pre.cnt;
-    NavOut no;
-    no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
-    if (AUV_RUN_N(d, 1)) k3_nav_env(d, e, lane, smem, obs_out, &pre, nullptr, &no);
+    if constexpr (SHAPE != SHAPE_WAVE_FINISH) {
+      if (AUV_RUN_N(d, 1)) k3_nav_env<SHAPE == SHAPE_TAIL_ROLE, true>(d, e, lane, smem, obs_out, &pre, nullptr, nullptr);
 #ifdef AUV_STAMPS
-    if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
+      if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif
-    pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
-    // the environment's step is complete (and its sweep wave gone): the packet's mark comes down for the next launch
-    if (lane == 0) __hip_atomic_store(d.k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    } else {
+      PairPre pp = pair_prefetch(d, e);
+      pp.cnt = pre.cnt;
+      NavOut no;
+      no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
+      if (AUV_RUN_N(d, 1)) k3_nav_env(d, e, lane, smem, obs_out, &pre, nullptr, &no);
 #ifdef AUV_STAMPS
-    if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();
+      if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif
+      pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
+      // the environment's step is complete (and its sweep wave gone): the packet's mark comes down for the next launch
+      if (lane == 0) __hip_atomic_store(d.k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef AUV_STAMPS
+      if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();
+#endif
+    }
+  } else if constexpr (SHAPE == SHAPE_TAIL_ROLE) {
+    // ---- navigation tail + reward / done / auto-reset of 64 environments, lanes <-> environments ----
+    const int el = (b - nk - 2 * nb - AUV_HOOK_SKEW(d)) * AUV_WAVE + lane;
+    const bool valid = el < ne;
+    const int e = d.e0 + (valid ? el : ne - 1);                     // (idle lanes look at the last environment, store nothing)
+    // what earlier launches left
+    int4 cnt = d.counters[e];
+    const int w = d.world_idx[e];
+    const double cum_in = d.info64[8 * (size_t)e + 4];
+    const EnvDesc edl = d.env_desc[e];
+    const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
+    unsigned long long* hmark = (unsigned long long*)(d.nav_hand + 8 * (size_t)e + 5);
+    unsigned long long pw[7];
+    unsigned long long word = PAIR_EMPTY;
+    for (int polls = 0;; polls++) {
+      bool ready = !valid;
+      if (valid) {
+        unsigned long long x = 0ull;
+#pragma unroll
+        for (int i = 0; i < 7; i++) pw[i] = __hip_atomic_load(pk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x ^= pw[i];
+        const unsigned long long mark = __hip_atomic_load(pk + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        word = __hip_atomic_load(d.pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hm = __hip_atomic_load(hmark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ready = mark != 0ull && roles_mark(x) == mark && word != PAIR_EMPTY && hm == 1ull;
+      }
+      if (!__any(!ready)) break;
+      if (polls == (AUV_HOOK_FAULT(d) ? (1 << 12) : PAIR_POLL_LIMIT)) {
+        if (lane == 0) __hip_atomic_store(d.pair_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    int do_reset = 0;
+    if (valid) {
+      // the search's result: stored write-through and completed before its mark (which this lane has seen)
+      const double* h = d.nav_hand + 8 * (size_t)e;
+      const double2 A = make_double2(auv_ld<true>(h + 0), auv_ld<true>(h + 1)), B = make_double2(auv_ld<true>(h + 2), auv_ld<true>(h + 3));
+      const double cum = auv_ld<true>(h + 4);
+      const NavOut no = nav_tail_core(d, e, edl, A, B, cum, __longlong_as_double((long long)pw[0]), __longlong_as_double((long long)pw[1]),
+                                      __longlong_as_double((long long)pw[2]), __longlong_as_double((long long)pw[3]),
+                                      __longlong_as_double((long long)pw[4]), __longlong_as_double((long long)pw[5]), obs_out);
+      cnt.y = (int)(unsigned)pw[6];                                 // the vessel's step counter of this launch
+      // the three marks come down for the next launch
+      __hip_atomic_store(d.pair_word + e, PAIR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(d.k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(hmark, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      RewardIn in;
+      const int collision = word == PAIR_COLLISION;
+      in.closeness_reward = collision ? 0.0 : __longlong_as_double((long long)word);
+      in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
+      in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
+      in.cum = cum_in;
+      d.info64[8 * (size_t)e] = collision;
+      do_reset = reward_apply(d, e, collision, cnt, in, reward_out, done_out, false);
+    }
+    unsigned long long m = __ballot(do_reset);
+    if (m) {
+      // (rare) tables of the copy through the device-side copy of `d`, see pair_finish_nav
+      const AuvDev& dc = *(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)d.self;
+      while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int er = auv_uniform(__shfl(e, src, AUV_WAVE));
+        const int wr = __shfl(w, src, AUV_WAVE), ep = __shfl(cnt.z, src, AUV_WAVE);
+        restore_env(dc, er, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
+      }
+    }
   }
 }
 
@@ -444,6 +533,42 @@ __global__ void __launch_bounds__(AUV_WAVE) k31_reward_dyn(AuvDev d, const void*
   // a restored environment's state was written by lane 0, its dynamics below read it from another lane
   if (any_reset) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   if (e < d.n) k1_env(d, e, actions, true);
+}
+
+// ---- second launch of the two-launch step: navigation tail + reward / done / auto-reset, lanes <-> environments ----
+// (rewarder.py:78-140, :167-241; environment.py:333-347, :375-384; vessel.py:471-541.)  Everything it reads was stored by
+// the launch before it.  It also takes the state packets' marks down for the next step's first launch.
+__global__ void __launch_bounds__(AUV_WAVE) k_tail_reward_lanes(AuvDev d, float* __restrict__ obs_out, float* __restrict__ reward_out,
+                                                                uint8_t* __restrict__ done_out) {
+  const int lane = threadIdx.x;
+  const int el = blockIdx.x * AUV_WAVE + lane;
+  const int e = d.e0 + el;
+  int do_reset = 0, w = 0;
+  int4 cnt = make_int4(0, 0, 0, 0);
+  if (el < d.ne) {
+    cnt = d.counters[e];
+    w = d.world_idx[e];
+    const int collision = d.collision[e];
+    const double rew_lidar = d.rew_lidar[e];
+    const double cum = d.info64[8 * (size_t)e + 4];
+    const NavOut no = nav_tail_lane(d, e, obs_out);
+    d.k1_pkt[8 * (size_t)e + 7] = 0ull;                      // (visible to the next launch's polls: kernel boundary)
+    RewardIn in;
+    in.closeness_reward = collision ? 0.0 : rew_lidar;
+    in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
+    in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
+    in.cum = cum;
+    d.info64[8 * (size_t)e] = collision;
+    do_reset = reward_apply(d, e, collision, cnt, in, reward_out, done_out, false);
+  }
+  unsigned long long m = __ballot(do_reset);
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int er = auv_uniform(__shfl(e, src, AUV_WAVE));
+    const int wr = __shfl(w, src, AUV_WAVE), ep = __shfl(cnt.z, src, AUV_WAVE);
+    restore_env(d, er, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
+  }
 }
 
 // ---- load-time probe of what the in-launch hand-overs rely on ----------------------------------------------------
@@ -529,7 +654,33 @@ void auv_launch_step_roles(const AuvDev& d0, const void* actions, int dtype, flo
   const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
   const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
   const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d)), block(AUV_WAVE);
-  hipExtLaunchKernelGGL(k_step_roles, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
+  hipExtLaunchKernelGGL(k_step_roles<SHAPE_WAVE_FINISH>, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
+}
+
+// ... with the navigation tail + reward phase as a FOURTH role (lanes <-> environments)
+void auv_launch_step_roles4(const AuvDev& d0, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
+                            hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  AuvDev d = d0;
+  d.act_f64 = dtype == AUV_F64;
+  const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8), nt = (d.ne + AUV_WAVE - 1) / AUV_WAVE;
+  const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d) + nt), block(AUV_WAVE);
+  hipExtLaunchKernelGGL(k_step_roles<SHAPE_TAIL_ROLE>, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
+}
+
+// ---- the two-launch step: [dynamics | sweep | path search] -> [navigation tail + reward, lanes <-> environments] ----
+void auv_launch_step_search(const AuvDev& d0, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0,
+                            hipEvent_t ev1) {
+  AuvDev d = d0;
+  d.act_f64 = dtype == AUV_F64;
+  const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
+  const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d)), block(AUV_WAVE);
+  hipExtLaunchKernelGGL(k_step_roles<SHAPE_SEARCH>, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, (float*)nullptr, (uint8_t*)nullptr);
+}
+
+void auv_launch_tail_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  hipExtLaunchKernelGGL(k_tail_reward_lanes, dim3((d.ne + AUV_WAVE - 1) / AUV_WAVE), dim3(AUV_WAVE), 0, st, ev0, ev1, 0, d, obs, reward, done);
 }
 
 uint32_t auv_step_lds_bytes(const AuvDev& d) { return (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
@@ -541,5 +692,9 @@ hipError_t auv_step_fused_prepare(const AuvDev& d) {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)k23_lidar_nav<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)k_step_roles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  e = hipFuncSetAttribute((const void*)k_step_roles<SHAPE_SEARCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_step_roles<SHAPE_TAIL_ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)k_step_roles<SHAPE_WAVE_FINISH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
 }

@@ -244,7 +244,7 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
  * poll auv_health() once per rollout there.
  * (Removed in round 3, measured slower: the whole step as one kernel, [K1 + K3-nav] -> [K2 + K3-reward], and
  * K3-nav forked onto a second stream; their enum values 1, 2, 3 are rejected.)                                */
-enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_PAIRED = 4, AUV_STEP_ONE_LAUNCH = 5, AUV_STEP_AUTO = 6 };
+enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_PAIRED = 4, AUV_STEP_ONE_LAUNCH = 5, AUV_STEP_AUTO = 6, AUV_STEP_TWO_LAUNCH = 7, AUV_STEP_FOUR_ROLES = 8 };
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
 /* The shape a launch of n_envs_per_launch environments (<= 0: the whole batch) is really stepped in: AUV_STEP_*. */
 int auv_effective_step_mode(auv_handle_t* h, int32_t n_envs_per_launch);

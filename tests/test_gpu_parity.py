@@ -18,6 +18,7 @@ from helpers import cfg_from_scalars, load, scene_order, scene_world
 pytestmark = pytest.mark.gpu
 
 ATOL = 1e-9
+AUTO_SMALL = "one_launch"    # what AUV_STEP_AUTO picks below 16384 environments per launch
 
 
 def _env(cfg, bank, n, **kw):
@@ -251,10 +252,10 @@ def test_step_modes_agree_bitwise(dtype):
     cfg = effective_reference_config(use_lidar=True)
     cfg.episode.max_timesteps = 9
     envs = []
-    for mode in ("side_by_side", "paired", "one_launch", "auto"):
+    for mode in ("side_by_side", "paired", "one_launch", "auto", "two_launch", "four_roles"):
         e = _env(cfg, bank, n)
         e.set_step_mode(mode)
-        assert e.effective_step_mode() == ("one_launch" if mode == "auto" else mode)
+        assert e.effective_step_mode() == (AUTO_SMALL if mode == "auto" else mode)
         e.reset()
         envs.append(e)
     rs = np.random.RandomState(5)
@@ -262,14 +263,14 @@ def test_step_modes_agree_bitwise(dtype):
         a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=dtype, device="cuda:0")
         outs = [e.step(a)[:3] for e in envs]
         torch.cuda.synchronize()
-        for other in (1, 2, 3):
+        for other in (1, 2, 3, 4, 5):
             for x, y in zip(outs[0], outs[other]):
                 assert torch.equal(x, y)
             for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO"):
                 assert torch.equal(envs[0].read(f), envs[other].read(f)), f
 
 
-@pytest.mark.parametrize("mode", ["paired", "one_launch"])
+@pytest.mark.parametrize("mode", ["paired", "one_launch", "two_launch", "four_roles"])
 def test_paired_step_bitwise_with_many_resets(mode):
     """The in-launch hand-overs (paired: the second of an environment's two waves runs the reward phase inside the
     side-by-side launch; one_launch: the dynamics role too) against the three-launch shape, bit for bit, over short
@@ -304,7 +305,7 @@ def test_paired_step_bitwise_with_many_resets(mode):
     ms = par.step_timed(a)
     ref.step(a)
     torch.cuda.synchronize()
-    assert ms[2] == 0.0 and len(par.timed_kernel_names()) == (2 if mode == "paired" else 1) and torch.equal(ref.obs, par.obs)
+    assert ms[2] == 0.0 and len(par.timed_kernel_names()) == (1 if mode in ("one_launch", "four_roles") else 2) and torch.equal(ref.obs, par.obs)
 
 
 @pytest.fixture(scope="module")
@@ -375,9 +376,9 @@ def test_probe_health_and_mode_selection():
     bank = _mixed_bank(4)
     env = _env(effective_reference_config(use_lidar=True), bank, 16)
     assert env.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0)
-    assert env.step_mode == "auto" and env.effective_step_mode() == "one_launch"
-    assert env.effective_step_mode(16383) == "one_launch" and env.effective_step_mode(16384) == "side_by_side"
-    for removed in (1, 2, 3, 7, -1):
+    assert env.step_mode == "auto" and env.effective_step_mode() == AUTO_SMALL
+    assert env.effective_step_mode(16383) == AUTO_SMALL and env.effective_step_mode(16384) == "side_by_side"
+    for removed in (1, 2, 3, 9, -1):
         assert _LIB.auv_set_step_mode(env._h, removed) != 0
     nol = _env(effective_reference_config(use_lidar=False), bank, 16)      # no sweep, nothing to hand over
     assert nol.effective_step_mode() == "side_by_side"
@@ -388,7 +389,7 @@ def test_probe_health_and_mode_selection():
     assert rc != 0 and b"aligned" in _LIB.auv_last_error()
 
 
-@pytest.mark.parametrize("mode", ["auto", "paired", "side_by_side"])
+@pytest.mark.parametrize("mode", ["one_launch", "two_launch", "four_roles", "paired", "side_by_side"])
 @pytest.mark.parametrize("n,k", [(1000, 3), (192, 2), (70, 4)])
 def test_sub_batches_bitwise(mode, n, k):
     """The batch stepped as k sub-batches on k streams (auv_step_slice / auv_step_pipelined; VecEnv step_async /

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--worlds-per-env", type=int, default=2)
     ap.add_argument("--bank-cache", default="")
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--modes", default="auto")
     args = ap.parse_args()
     import bench
     from gym_auv_amd.config import effective_reference_config
@@ -56,7 +57,8 @@ def main():
     w0 = torch.arange(n, device=dev, dtype=torch.int32)
     ref = None
     fields = ("STATE", "OBS64", "REWARD64", "LIDAR_D", "WORLD_IDX", "INFO64", "NAV64", "EPISODE")
-    for k in [int(x) for x in args.ks.split(",")]:
+    for mode, k in [(m, int(x)) for m in args.modes.split(",") for x in args.ks.split(",")]:
+        env.set_step_mode(mode)
         env.set_sub_batches(k)
         rates = []
         for rep in range(args.repeat):
@@ -86,7 +88,7 @@ def main():
         else:
             same = all(np.array_equal(ref[f], snap[f], equal_nan=True) if snap[f].dtype.kind == "f" else np.array_equal(ref[f], snap[f])
                        for f in snap)
-        print(json.dumps(dict(sub_batches=env.sub_batches, slices=env._slices[:2], env_steps_per_s=[round(r / 1e6, 2) for r in rates],
+        print(json.dumps(dict(mode=mode, sub_batches=env.sub_batches, slices=env._slices[:2], env_steps_per_s=[round(r / 1e6, 2) for r in rates],
                               ms_per_step=round(1e3 * n / max(rates), 5), bitwise_equal_to_first=bool(same))), flush=True)
     env.close()
 
