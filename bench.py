@@ -16,15 +16,25 @@ episode, cyclically), as the reference regenerates the scenario on every reset
 (envs/movingobstacles.py:28-95).  One "step" = one batched env.step() over all envs of the rank.
 Weak scaling: per-GPU work is fixed as N grows.
 
+The rank's envs are stepped as --sub-batches K sub-batches (default 4 at >= 2048 envs per rank): K independent launch
+chains on K streams, no ordering between them inside the timed region (the actions are resident); they overlap on the
+GPU -- one chain's sweeps run under another's dynamics chain and navigation tail.  Same envs, same results as K = 1,
+bit for bit (tests/test_gpu_parity.py::test_sub_batches_bitwise).
+
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline      dominant kernel (HIP-event timed on the launch stream in this process): the HBM leg
-                (`achieved` = algorithmic bytes per launch / duration; algorithmic = what the
-                implemented algorithm must touch, LiDAR segments counted for NEARBY obstacles only)
-                and the VALU leg (`valu`: wave-instructions and issue cycles per launch from the
-                committed rocprofv3 SQ-counter pass, profiles/pmc_sq.json); `bound` names the larger;
-  cpu_baseline  the CPU oracle (a C port of the reference algorithm) timed on this box's host cores
-                on a bounded sample of the same workload, plus the reference's own Python step()
-                as measured in the build container (a stated constant, never run here).
+  roofline      the step's dominant kernel, k_step_roles.  `kernels[...]`: its launch duration by HIP events on its own
+                stream in this process (with sub-batches: while the other chains run beside it; what a kernel trace's
+                average shows) and algorithmic bytes / that duration.  HBM leg (`achieved`, `frac`): with ONE chain exactly
+                that figure; with K concurrent chains the K launches of a step run at the same time, so the leg is the
+                algorithmic bytes of a whole step / the measured time per step of the timed region.  Algorithmic = what the
+                implemented algorithm must touch, LiDAR segments counted for NEARBY obstacles only.  `traffic`: HBM bytes
+                per step from the committed FETCH_SIZE / WRITE_SIZE passes; `valu`: VALU issue cycles per step from the
+                committed SQ pass / (1024 SIMDs x clock x measured time per step), `wait_frac` = SQ_WAIT_ANY /
+                SQ_WAVE_CYCLES; both carry the sha256 of the library they were measured on and `stale: true` when this
+                process runs another one.  `bound`: the larger leg, or "latency" when neither reaches 0.6.
+  cpu_baseline  the CPU oracle (a C port of the reference algorithm) timed on this box's host cores on a bounded sample of
+                the same workload (median of 5 repeats of 500 steps), plus the reference's own
+                Python step() as measured in the build container (a stated constant, never run here).
 """
 import argparse
 import json
@@ -55,15 +65,17 @@ def parse():
     ap.add_argument("--graph", type=int, default=0,
                     help="0 (default): eager launches; K > 0: K consecutive steps captured in ONE hipGraph over the action "
                          "ring, one replay per K steps (steps not a multiple of K are finished eagerly)")
-    ap.add_argument("--step-mode", default="auto", choices=["auto", "side_by_side", "paired", "one_launch", "two_launch", "four_roles"],
+    ap.add_argument("--step-mode", default="auto", choices=["auto", "side_by_side", "one_launch"],
                     help="how a step is launched (include/auv_hip.h, AUV_STEP_*)")
     ap.add_argument("--actions", default="uniform", choices=["uniform", "pilot"],
                     help="uniform: i.i.d. U(action_space), resident in HBM (headline); pilot: closed loop, "
                          "a = (1, 0.15 * heading_error) computed on the device from the observation of the "
                          "previous step, so that episodes progress along the path (SURVEY 8(d), config 1)")
-    ap.add_argument("--sub-batches", type=int, default=1,
-                    help="K > 1: the rank's envs are stepped as K contiguous sub-batches, each a launch chain on a stream "
-                         "of its own (auv_step_slice); the chains overlap on the GPU.  Same envs, same results")
+    ap.add_argument("--sub-batches", type=int, default=0,
+                    help="K: the rank's envs are stepped as K contiguous sub-batches, each a launch chain on a stream of its "
+                         "own (auv_step_pipelined); the chains overlap on the GPU -- same envs, same results, bit for bit.  "
+                         "0 (default): 4 (the four compute pipes of the chip) when the rank has >= 2048 envs and the step "
+                         "is launched eagerly from resident actions, else 1")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
     ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
@@ -127,9 +139,16 @@ def algorithmic_bytes(bank, S, world_of_env, nearby):
 
 KERNEL_PHASES = {   # which phases of the step a launch performs (for its algorithmic byte count)
     "k1_dynamics": ("k1",), "k23_lidar_nav": ("lidar", "nav"), "k3_reward": ("reward",),
-    "k23_lidar_nav_paired": ("lidar", "nav", "reward"), "k_step_roles": ("k1", "lidar", "nav", "reward"),
-    "k_step_search": ("k1", "lidar", "nav"), "k_tail_reward_lanes": ("reward",),
+    "k_step_roles": ("k1", "lidar", "nav", "reward"),
 }
+
+
+def library_sha256():
+    """sha256 of the HIP library this process runs (ties the committed counter passes to a binary)"""
+    import hashlib
+    from gym_auv_amd import _capi
+    path = os.environ.get("AUV_HIP_LIB") or _capi.LIB_PATH
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
 
 
 def host_cores():
@@ -267,6 +286,11 @@ def main():
 
     env.reset()
     K = max(0, args.graph)
+    sub = args.sub_batches
+    if sub <= 0:
+        sub = 4 if (n_local >= 2048 and not K and env.effective_step_mode(n_local // 4) == "one_launch") else 1
+    if K:
+        sub = 1
     if K:
         # the 64 pre-generated action batches become the action ring of the captured steps: a replay consumes
         # the next K slots, nothing is copied or re-bound in the timed loop.  Steps beyond a multiple of K are
@@ -284,14 +308,22 @@ def main():
     elif args.actions == "pilot":
         act = torch.ones((n_local, 2), dtype=torch.float32, device=dev)
 
+        if sub > 1:
+            env.set_sub_batches(sub)
+
         def run(i0, n):
             # look-ahead pilot: full thrust, rudder proportional to the heading error (observation
-            # column 4, already clipped to +-1 rad): two tiny torch kernels per step, all on the device
+            # column 4, already clipped to +-1 rad): two tiny torch kernels per step, all on the device.  With
+            # sub-batches: VecEnv step_async / step_wait (the chains wait for the action, the caller's stream for them)
             for _ in range(n):
                 torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
-                env.step(act)
-    elif args.sub_batches > 1:
-        env.set_sub_batches(args.sub_batches)
+                if sub > 1:
+                    env.step_async(act)
+                    env.step_wait()
+                else:
+                    env.step(act)
+    elif sub > 1:
+        env.set_sub_batches(sub)
 
         def run(i0, n):
             # K independent launch chains: sub-batch s of step i goes to stream s; nothing orders the chains against
@@ -320,57 +352,97 @@ def main():
     world_of_env = env.read("WORLD_IDX").cpu().numpy()
     nearby = env.read("NEARBY").cpu().numpy()
 
-    # ---- per-kernel timing with HIP events on the launch stream (same workload, same process)
-    kms = np.zeros(4)
+    # ---- per-kernel timing with HIP events on the launch stream(s) (same workload, same process)
     n_prof = min(max(args.steps, 20), 100)
-    for i in range(n_prof):
-        kms += np.array(env.step_timed(pool[i % n_pool]))
-    kms /= n_prof
     alg = algorithmic_bytes(bank, S, world_of_env, nearby)
-    names = env.timed_kernel_names()
-    per_kernel = {}
-    for j, nm in enumerate(names):
-        b = sum(alg[ph] for ph in KERNEL_PHASES[nm])
-        gbs = b / (kms[j] * 1e-3) / 1e9 if kms[j] > 0 else 0.0
-        per_kernel[nm] = dict(avg_ms=round(float(kms[j]), 5), algorithmic_bytes=int(b),
-                              achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+    step_bytes = sum(alg[ph] for ph in ("k1", "lidar", "nav", "reward"))
+    pipelined = sub > 1 and args.actions == "uniform"
+    if pipelined:
+        # every sub-batch launch stamped on its own stream while the other chains run beside it
+        lms = np.zeros(env.sub_batches)
+        for i in range(n_prof):
+            lms += np.array(env.step_pipelined_timed(pool[i % n_pool]))
+        lms /= n_prof
+        names = ["k_step_roles"]
+        kms = np.array([lms.mean(), 0.0, 0.0, lms.max()])
+        launch_bytes = step_bytes / env.sub_batches
+        per_kernel = {"k_step_roles": dict(avg_ms=round(float(lms.mean()), 5), launches_per_step=env.sub_batches,
+                                           algorithmic_bytes=int(launch_bytes),
+                                           achieved_GBs=round(launch_bytes / (lms.mean() * 1e-3) / 1e9, 1),
+                                           frac=round(launch_bytes / (lms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           per_slice_ms=[round(float(x), 5) for x in lms])}
+    else:
+        kms = np.zeros(4)
+        for i in range(n_prof):
+            kms += np.array(env.step_timed(pool[i % n_pool]))
+        kms /= n_prof
+        names = env.timed_kernel_names()
+        per_kernel = {}
+        for j, nm in enumerate(names):
+            b = sum(alg[ph] for ph in KERNEL_PHASES[nm])
+            gbs = b / (kms[j] * 1e-3) / 1e9 if kms[j] > 0 else 0.0
+            per_kernel[nm] = dict(avg_ms=round(float(kms[j]), 5), launches_per_step=1, algorithmic_bytes=int(b),
+                                  achieved_GBs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
     dom = max(names, key=lambda nm: per_kernel[nm]["avg_ms"])
     per_kernel[dom].update(lidar_bytes=int(alg["lidar"]), nav_bytes=int(alg["nav"]),
                            nearby_segments_per_env=round(alg["nearby_segments_per_env"], 1),
                            all_segments_per_env=round(alg["all_segments_per_env"], 1),
                            nav_bruteforce_bytes=int(alg["nav_bruteforce"]))
+    # HBM leg.  One chain: algorithmic bytes of the dominant launch / its HIP-event duration.  Sub-batch chains: the
+    # launches of a step run CONCURRENTLY, so one launch's bytes / duration is a quarter of what the chip moves; the
+    # leg is then all launches' bytes of a step / the measured time per step of the timed region (gaps included).
+    ms_step = 1e3 * elapsed / args.steps
+    if pipelined:
+        achieved = step_bytes / (ms_step * 1e-3) / 1e9
+    else:
+        achieved = per_kernel[dom]["achieved_GBs"]
+    hbm_frac = round(achieved / HBM_PEAK_GBS, 4)
+
+    lib_sha = library_sha256()
+    cfg_key = "%s/sub%d" % (args.workload, sub)
 
     def committed(name):
-        """per-launch counters of the dominant kernel from the committed rocprofv3 passes (4096 envs per GPU)"""
+        """per-STEP counters of the step's launches from the committed rocprofv3 passes (4096 envs per GPU, this
+        workload and sub-batch count), with the sha256 of the library they were measured on"""
         path = os.path.join(ROOT, "profiles", name)
         if n_local != 4096 or not os.path.exists(path):
             return None
         try:
-            return json.load(open(path)).get(args.workload, {}).get(dom)
+            return json.load(open(path)).get(cfg_key)
         except Exception:
             return None
 
     traffic = committed("pmc_traffic.json")
     sq = committed("pmc_sq.json")
     valu = None
+    if traffic is not None:
+        traffic = dict(traffic, stale=traffic.get("lib_sha256") != lib_sha)
     if sq:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) in which a wave executes a VALU instruction, summed
-        # over waves; SQ_BUSY_CYCLES is summed over the 32 shader engines.  frac = issue cycles / (SIMDs x busy cycles).
+        # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) in which a wave executes a VALU instruction, summed over
+        # waves and (here) over the launches of one step.  Issue capacity of a step = 1024 SIMDs x shader clock x time per
+        # step; the clock is the counter pass's own SQ_BUSY_CYCLES / 32 shader engines / kernel duration.
         issue = 4.0 * sq["SQ_ACTIVE_INST_VALU"]
-        busy = sq["SQ_BUSY_CYCLES"] / 32.0
-        valu = dict(insts=int(sq["SQ_INSTS_VALU"]), issue_cycles=int(issue), kernel_cycles=int(busy),
-                    frac=round(issue / (N_SIMD * busy), 4), source="profiles/pmc_sq.json")
-    hbm_frac = per_kernel[dom]["frac"]
-    bound = "valu" if (valu and valu["frac"] > hbm_frac) else "hbm"
-    roofline = dict(bound=bound, kernel=dom, achieved=per_kernel[dom]["achieved_GBs"], peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=hbm_frac, traffic=traffic, valu=valu, kernels=per_kernel)
+        cyc_step = sq["clock_ghz"] * 1e9 * ms_step * 1e-3
+        valu = dict(insts=int(sq["SQ_INSTS_VALU"]), issue_cycles=int(issue), step_cycles=int(cyc_step), clock_ghz=sq["clock_ghz"],
+                    frac=round(issue / (N_SIMD * cyc_step), 4),
+                    wait_frac=round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 4) if sq.get("SQ_WAVE_CYCLES") else None,
+                    source="profiles/pmc_sq.json [%s]" % cfg_key, lib_sha256=sq.get("lib_sha256"),
+                    stale=sq.get("lib_sha256") != lib_sha)
+    legs = dict(hbm=hbm_frac, valu=valu["frac"] if valu else 0.0)
+    bound = max(legs, key=legs.get)
+    if max(legs.values()) < 0.6:
+        bound = "latency"      # neither leg saturated: the step is bound by dependent chains / occupancy, not by a pipe
+    roofline = dict(bound=bound, kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac,
+                    traffic=traffic, valu=valu, wait_frac=valu["wait_frac"] if valu else None, legs=legs,
+                    step_bytes=int(step_bytes), concurrent_launches=sub if pipelined else 1, kernels=per_kernel,
+                    lib_sha256=lib_sha)
 
     out = dict(metric="env-steps/sec", value=round(value, 1), unit="env-steps/s", n_gpus=n_devices_used, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
                            parallelism="env-shard x%d (no step-path collective)" % world, ranks=world,
-                           hipgraph_steps=K, sub_batches=max(1, args.sub_batches), step_mode=args.step_mode, actions=args.actions,
+                           hipgraph_steps=K, sub_batches=sub, step_mode=env.effective_step_mode(max(1, n_local // sub)), actions=args.actions,
                            worlds_per_env=wpe, world_gen_s=round(t_gen, 1),
                            episodes_finished=int(stats["episodes"].sum().item())),
                roofline=roofline)
@@ -385,36 +457,39 @@ def main():
 
 
 def cpu_baseline(cfg, bank, n_local):
-    """The CPU oracle (C port of the reference algorithm, fp64, -O2) on this box's host cores, on
-    a bounded sample of the same workload (~10 s of CPU work): the first 1024 envs/worlds for 2500
-    steps on all usable cores (OpenMP over envs), then 100 steps on 1 thread.  Beside it, as a stated
-    constant, the reference's OWN Python step() timed in the build container
+    """The CPU oracle (C port of the reference algorithm, fp64, -O2) on this box's host cores, on a bounded sample of
+    the same workload, measured as BASELINE.md section 3 asks: warm-up, then the median of 5 repeats of >= 500 batched
+    steps -- the first 1024 envs/worlds on all usable cores (OpenMP over envs), the first 256 on 1 thread (~20 s in
+    all).  Beside it, as a stated constant, the reference's OWN Python step() timed in the build container
     (oracle/ref_harness/time_reference.py -> reference_timing.json; it cannot run on the GPU box)."""
     from gym_auv_amd._capi import make_config
     from oracle import pyoracle
-    n = min(1024, n_local)
-    ora = pyoracle.Oracle(make_config(cfg, auto_reset=True), n, bank)
     rs = np.random.RandomState(0)
-    acts = rs.uniform([-1, -0.15], [1, 0.15], (8, n, 2))
-    cores = pyoracle.set_threads(host_cores())
-    ora.reset()
-    for i in range(20):
-        ora.step(acts[i % 8])
-    steps = 2500
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ora.step(acts[i % 8])
-    dt_all = time.perf_counter() - t0
-    pyoracle.set_threads(1)
-    t0 = time.perf_counter()
-    for i in range(100):
-        ora.step(acts[i % 8])
-    dt_one = time.perf_counter() - t0
+    steps, repeats = 500, 5
+
+    def leg(n, threads):
+        ora = pyoracle.Oracle(make_config(cfg, auto_reset=True), n, bank)
+        acts = rs.uniform([-1, -0.15], [1, 0.15], (8, n, 2))
+        used = pyoracle.set_threads(threads)
+        ora.reset()
+        for i in range(50):
+            ora.step(acts[i % 8])
+        rates = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                ora.step(acts[i % 8])
+            rates.append(n * steps / (time.perf_counter() - t0))
+        return used, float(np.median(rates)), [round(r, 1) for r in rates]
+
+    n_all, n_one = min(1024, n_local), min(256, n_local)
+    cores, v_all, r_all = leg(n_all, host_cores())
+    _, v_one, r_one = leg(n_one, 1)
     pyoracle.set_threads(cores)
-    res = dict(value=round(n * steps / dt_all, 1), unit="env-steps/s", cores=cores, kind="port",
-               sample="%d envs x %d steps of the same workload (OpenMP over envs, %d threads, %.1f s); "
-                      "1 thread: %d envs x 100 steps (%.1f s)" % (n, steps, cores, dt_all, n, dt_one),
-               value_1thread=round(n * 100 / dt_one, 1))
+    res = dict(value=round(v_all, 1), unit="env-steps/s", cores=cores, kind="port",
+               sample="median of %d repeats of %d steps after 50 warm-up steps: %d envs of the same workload on %d threads "
+                      "(OpenMP over envs); 1 thread: %d envs" % (repeats, steps, n_all, cores, n_one),
+               repeats=r_all, value_1thread=round(v_one, 1), repeats_1thread=r_one)
     ref = os.path.join(ROOT, "oracle", "ref_harness", "reference_timing.json")
     if os.path.exists(ref):
         try:

@@ -195,6 +195,16 @@ class BatchedAuvEnv:
                                        C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
                                        C.c_void_p(self.done.data_ptr())), "auv_step_pipelined")
 
+    def step_pipelined_timed(self, actions: torch.Tensor):
+        """step_pipelined with every sub-batch's launch stamped by its own HIP events: ms per sub-batch launch
+        (its own duration while the other chains run beside it)."""
+        a, dt = self._act(actions)
+        ms = (C.c_float * self.sub_batches)()
+        _check(_LIB.auv_step_pipelined_timed(self._h, self.sub_batches, self._bounds_c, self._streams_c, C.c_void_p(a.data_ptr()), dt,
+                                             C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
+                                             C.c_void_p(self.done.data_ptr()), ms), "auv_step_pipelined_timed")
+        return [float(x) for x in ms]
+
     def step_async(self, actions: torch.Tensor):
         """VecEnv.step_async (what SubprocVecEnv does with its workers, scripts/run.py:293-296): enqueue the step of
         every sub-batch on its own stream and return at once.  The sub-batch streams first wait for the caller's
@@ -223,15 +233,14 @@ class BatchedAuvEnv:
     def _lazy_info(self):
         return _LazyInfo(self)
 
-    STEP_MODES = {"side_by_side": 0, "paired": 4, "one_launch": 5, "auto": 6, "two_launch": 7, "four_roles": 8}
+    STEP_MODES = {"side_by_side": 0, "one_launch": 5, "auto": 6}
     _MODE_NAMES = {v: k for k, v in STEP_MODES.items()}
 
     def set_step_mode(self, mode: str):
         """"auto" (default): "one_launch" below 16384 environments per launch, "side_by_side" from there on;
-        "one_launch": dynamics, LiDAR sweep and navigation + reward as three roles of ONE launch; "paired": K1 -> [K2 and
-        K3-nav side by side, the navigation wave also runs K3-reward]; "side_by_side": K1 -> [K2 + K3-nav in one
-        launch] -> K3-reward.  All give the same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise).
-        Where the in-launch hand-overs of the first two may not be used (see `health()`) the library steps in
+        "one_launch": dynamics, LiDAR sweep and navigation + reward as three roles of ONE launch; "side_by_side": K1 ->
+        [K2 + K3-nav in one launch] -> K3-reward.  The same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise).
+        Where the in-launch hand-overs of the first may not be used (see `health()`) the library steps in
         "side_by_side" whatever is set: `effective_step_mode()` tells."""
         _check(_LIB.auv_set_step_mode(self._h, self.STEP_MODES[mode]), "auv_set_step_mode")
         self.step_mode = mode
@@ -290,7 +299,7 @@ class BatchedAuvEnv:
 
     def step_timed(self, actions: torch.Tensor):
         """One step, every dispatch stamped with its own start/stop HIP event; returns four ms values: the launches
-        of the effective step mode in order (one_launch: the one launch; paired: K1, K2 + K3-nav + K3-reward;
+        of the effective step mode in order (one_launch: the one launch;
         side_by_side: K1, K2 + K3-nav, K3-reward), zeros, and last the whole step first start .. last stop.
         `timed_kernel_names()` names them."""
         a, dt = self._act(actions)
@@ -302,12 +311,8 @@ class BatchedAuvEnv:
 
     def timed_kernel_names(self):
         mode = self.effective_step_mode()
-        if mode in ("one_launch", "four_roles"):
+        if mode == "one_launch":
             return ["k_step_roles"]
-        if mode == "two_launch":
-            return ["k_step_search", "k_tail_reward_lanes"]     # (the kernel trace calls the first k_step_roles<false>)
-        if mode == "paired":
-            return ["k1_dynamics", "k23_lidar_nav_paired"]      # (the kernel trace calls it k23_lidar_nav<true>)
         return ["k1_dynamics", "k23_lidar_nav", "k3_reward"]
 
     # ------------------------------------------------------------------------------ optional post-kernel

@@ -32,18 +32,9 @@ bool auv_k23_ok(const AuvDev& d);
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t auv_step_fused_prepare(const AuvDev& d);
 uint32_t auv_step_lds_bytes(const AuvDev& d);
-bool auv_paired_ok(const AuvDev& d);
 bool auv_roles_ok(const AuvDev& d);
 void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
-                           hipEvent_t ev1 = nullptr);
-void auv_launch_step_roles4(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
-                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-void auv_launch_step_search(const AuvDev& d, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr,
-                            hipEvent_t ev1 = nullptr);
-void auv_launch_tail_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0 = nullptr,
-                            hipEvent_t ev1 = nullptr);
 void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st);
 hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
@@ -75,13 +66,14 @@ struct auv_handle {
   hipGraph_t graph;
   hipGraphExec_t graph_exec;
   int step_mode;                 // AUV_STEP_* as requested (include/auv_hip.h)
-  int32_t* pair_error_host;      // pinned, mapped: set by a wave of the one-launch / paired step that gave up polling
-  // in-launch hand-overs (one-launch and paired shapes): allowed only while the load-time probe of the dispatch
+  int32_t* pair_error_host;      // pinned, mapped: set by a wave of the one-launch step that gave up polling
+  // in-launch hand-overs (the one-launch shape): allowed only while the load-time probe of the dispatch
   // order has passed and no poll has ever run out on this handle
   bool handover_ok;
   int probe_failures;            // of the last probe (0 = the dispatch order is what the hand-overs rely on)
   int handover_timeouts;         // polls that ran out over the life of the handle (each one disables the hand-overs)
   hipEvent_t ev[6];
+  std::vector<hipEvent_t> slice_ev;   // auv_step_pipelined_timed: start / stop event per sub-batch launch
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
   GenOut gen;
@@ -97,14 +89,14 @@ struct auv_handle {
 static int effective_mode(const auv_handle* h, int ne) {
   int m = h->step_mode;
   if (m == AUV_STEP_AUTO) m = ne >= AUV_AUTO_THREE_LAUNCHES_FROM ? AUV_STEP_SIDE_BY_SIDE : AUV_STEP_ONE_LAUNCH;
-  if (m != AUV_STEP_SIDE_BY_SIDE && (!h->handover_ok || !auv_paired_ok(h->d))) m = AUV_STEP_SIDE_BY_SIDE;
+  if (m != AUV_STEP_SIDE_BY_SIDE && (!h->handover_ok || !auv_roles_ok(h->d))) m = AUV_STEP_SIDE_BY_SIDE;
   return m;
 }
 
 static int recover_from_timeout(auv_handle* h);
 static int probe_dispatch_order(auv_handle* h);
 
-// A wave of the one-launch / paired step that gave up polling has left its environment's step unfinished.  The
+// A wave of the one-launch step that gave up polling has left its environment's step unfinished.  The
 // next call on the handle notices (mapped host word), repairs the handle -- hand-over words cleared, EVERY
 // environment put back into its reset state, three-launch shape from now on -- and reports AUV_ESTATE once.
 #define PAIR_CHECK(h)                                                            \
@@ -204,7 +196,6 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.pose_cs, n);
   rc |= dev_alloc(ep, &d.pair_word, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
-  rc |= dev_alloc(ep, &d.nav_hand, 8 * n);
   rc |= dev_alloc(ep, &d.k1_done, 4);
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
@@ -237,7 +228,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   d.ring_slot_host = -1;
   HIP_TRY(hipMemset(d.ring_pos, 0, sizeof(int32_t)));
   {
-    // paired step: no sweep has left a word yet
+    // one-launch step: no sweep has left a word yet
     std::vector<unsigned long long> empty(n ? n : 1, AUV_PAIR_EMPTY);
     HIP_TRY(hipMemcpy(d.pair_word, empty.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
     if (!h->pair_error_host) {
@@ -281,7 +272,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   }
   d.w_ready = 1;
   {
-    // the device-side copy of this struct: what the rarely taken paths of the paired step read their tables from
+    // the device-side copy of this struct: what the rarely taken paths of the one-launch step read their tables from
     if (!d.self) {
       AuvDev* p = nullptr;
       HIP_TRY(hipMalloc((void**)&p, sizeof(AuvDev)));
@@ -389,6 +380,7 @@ int auv_destroy(auv_handle_t* h) {
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->slice_ev) (void)hipEventDestroy(e);
   free_pool(h->env_allocs);
   free_pool(h->bank_allocs);
   if (h->pair_error_host) (void)hipHostFree(h->pair_error_host);
@@ -682,22 +674,6 @@ static int enqueue_step(auv_handle_t* h, int mode, int e0, int ne, const void* a
     auv_launch_step_roles(d, actions, dtype, obs, reward, done, st);
     return AUV_OK;
   }
-  if (mode == AUV_STEP_FOUR_ROLES) {
-    auv_launch_step_roles4(d, actions, dtype, obs, reward, done, st);
-    return AUV_OK;
-  }
-  if (mode == AUV_STEP_TWO_LAUNCH) {
-    // [dynamics | sweep | path search as three roles of one launch] -> [navigation tail + reward, lanes <-> environments]
-    auv_launch_step_search(d, actions, dtype, obs, st);
-    auv_launch_tail_reward(d, obs, reward, done, st);
-    return AUV_OK;
-  }
-  if (mode == AUV_STEP_PAIRED) {
-    // K1 -> [K2 and K3-nav side by side, the second of an environment's two waves runs K3-reward]: two launches
-    auv_launch_k1(d, actions, dtype, st);
-    auv_launch_k23_paired(d, obs, reward, done, st);   // (advances a captured graph's action ring)
-    return AUV_OK;
-  }
   // K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward: no hand-over inside a launch
   if (!auv_k23_ok(d)) return fail(AUV_EINVAL, "path too long for the navigation's chunk list (%d chunks)", d.nch_max);
   if (!skip_k1) auv_launch_k1(d, actions, dtype, st);
@@ -762,6 +738,37 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
   return AUV_OK;
 }
 
+int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, const void* actions_dev,
+                             int32_t action_dtype, float* obs_dev, float* reward_dev, uint8_t* done_dev, float* out_ms) {
+  REQUIRE_READY(h);
+  int rc = check_actions(actions_dev, action_dtype, "auv_step_pipelined_timed");
+  if (rc) return rc;
+  if (n_slices < 1 || !bounds || !streams || !out_ms) return fail(AUV_EINVAL, "auv_step_pipelined_timed: bad arguments");
+  if (bounds[0] != 0 || bounds[n_slices] != h->d.n) return fail(AUV_EINVAL, "auv_step_pipelined_timed: bounds must run from 0 to %d", h->d.n);
+  PAIR_CHECK(h);
+  while ((int)h->slice_ev.size() < 2 * n_slices) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    h->slice_ev.push_back(e);
+  }
+  for (int i = 0; i < n_slices; i++) {
+    const int ne = bounds[i + 1] - bounds[i];
+    if (ne < 1) return fail(AUV_EINVAL, "auv_step_pipelined_timed: empty slice %d", i);
+    if (effective_mode(h, ne) != AUV_STEP_ONE_LAUNCH) return fail(AUV_ESTATE, "auv_step_pipelined_timed: needs the one-launch shape");
+    AuvDev d = h->d;
+    d.ring_slots = 1;
+    d.e0 = bounds[i], d.ne = ne;
+    auv_launch_step_roles(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)streams[i], h->slice_ev[2 * i],
+                          h->slice_ev[2 * i + 1]);
+  }
+  HIP_TRY(hipGetLastError());
+  for (int i = 0; i < n_slices; i++) {
+    HIP_TRY(hipEventSynchronize(h->slice_ev[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[i], h->slice_ev[2 * i], h->slice_ev[2 * i + 1]));
+  }
+  return AUV_OK;
+}
+
 int auv_health(auv_handle_t* h, int32_t* out4) {
   if (!h || !out4) return fail(AUV_EINVAL, "auv_health: bad arguments");
   out4[0] = h->handover_ok ? 1 : 0;
@@ -791,8 +798,7 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
 
 int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   if (!h) return fail(AUV_EINVAL, "null handle");
-  if (mode != AUV_STEP_SIDE_BY_SIDE && mode != AUV_STEP_PAIRED && mode != AUV_STEP_ONE_LAUNCH && mode != AUV_STEP_AUTO &&
-      mode != AUV_STEP_TWO_LAUNCH && mode != AUV_STEP_FOUR_ROLES)
+  if (mode != AUV_STEP_SIDE_BY_SIDE && mode != AUV_STEP_ONE_LAUNCH && mode != AUV_STEP_AUTO)
     return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
   h->step_mode = mode;
   if (h->graph_exec) {
@@ -813,7 +819,7 @@ int auv_diag_cuts(auv_handle_t* h, int32_t cut_lidar, int32_t cut_nav) {
 #endif
 
 #ifdef AUV_TEST_HOOKS
-// Only in libauv_hip_hooks.so (make hooks): skew = idle workgroups between the roles of the one-launch / paired
+// Only in libauv_hip_hooks.so (make hooks): skew = idle workgroups between the roles of the one-launch
 // shapes (an environment's waves then sit on different XCDs); fault = 1: the sweep of the first environment of every
 // launch never publishes its word, so the navigation wave's poll runs out.
 int auv_test_hooks(auv_handle_t* h, int32_t skew, int32_t fault) {
@@ -939,10 +945,10 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
   int rc = AUV_OK;
   // inside the graph, step k's reward phase and step k+1's dynamics share a launch (side-by-side shape with a LiDAR
   // sweep: the shapes whose reward kernel maps lanes to environments)
-  // (also for the paired and one-launch shapes: replayed launches cost ~3 us more than eager ones on this stack, and
-  // inside a graph of several steps the fused reward + dynamics launch makes up for more of that than they do --
-  // 97.6 M against 95.5 M (paired) and 96.6 M (one launch) env-steps/s at 16 steps per graph, 95.3 against 90.6 M at
-  // 8192 x 256 -- and the bits are the same.  A graph of ONE step keeps the handle's own shape.)
+  // (also when the handle steps in the one-launch shape: replayed launches cost ~3 us more than eager ones on this
+  // stack, and inside a graph of several steps the fused reward + dynamics launch makes up for more of that than the
+  // one launch does -- 97.6 M against 96.6 M env-steps/s at 16 steps per graph, 95.3 against 90.6 M at 8192 x 256 --
+  // and the bits are the same.  A graph of ONE step keeps the handle's own shape.)
   const bool fuse = n_steps > 1 && auv_k23_ok(h->d) && h->d.cfg.use_lidar;
   const int mode = fuse ? AUV_STEP_SIDE_BY_SIDE : effective_mode(h, h->d.n);
   for (int32_t k = 0; k < n_steps && rc == AUV_OK; k++)
@@ -984,17 +990,6 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
   if (mode == AUV_STEP_ONE_LAUNCH) {
     auv_launch_step_roles(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, st, h->ev[0], h->ev[1]);
     nk = 1;
-  } else if (mode == AUV_STEP_FOUR_ROLES) {
-    auv_launch_step_roles4(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, st, h->ev[0], h->ev[1]);
-    nk = 1;
-  } else if (mode == AUV_STEP_TWO_LAUNCH) {
-    auv_launch_step_search(d, actions_dev, action_dtype, obs_dev, st, h->ev[0], h->ev[1]);
-    auv_launch_tail_reward(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
-    nk = 2;
-  } else if (mode == AUV_STEP_PAIRED) {
-    auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);
-    auv_launch_k23_paired(d, obs_dev, reward_dev, done_dev, st, h->ev[2], h->ev[3]);
-    nk = 2;
   } else {
     if (!auv_k23_ok(d)) return fail(AUV_EINVAL, "auv_step_timed: path too long for the side-by-side launch");
     auv_launch_k1(d, actions_dev, action_dtype, st, h->ev[0], h->ev[1]);

@@ -79,16 +79,14 @@ struct AuvDev {
   uint8_t* collision;  // [N]
   double* step_info;   // [N][4] info of the last step (terminal values survive an auto-reset)
   double2* pose_cs;    // [N] cos, sin of the heading K1 has just produced (K1 -> LiDAR within one step only)
-  unsigned long long* pair_word; // [N] paired step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
-  int32_t* pair_error; // [1] paired step: set when a navigation wave gave up waiting for its sweep
-  double* nav_hand;            // [N][8] two-launch step: what the path search leaves for the navigation's tail (nav_tail_lane):
-                               //        end points of the nearest segment, arclength at its first vertex
+  unsigned long long* pair_word; // [N] one-launch step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
+  int32_t* pair_error; // [1] one-launch step: set when a navigation wave gave up waiting for its sweep
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position
   int32_t cut_lidar, cut_nav;  // diagnostic build only (-DAUV_CUTS, tools/valu_budget.py): phases from this number on are skipped
   int32_t pair_skew;   // paired step, test hook: idle workgroups between the two roles (puts them on different XCDs)
   int32_t pair_fault;  // paired step, test hook: environment 0's sweep never publishes its word (the poll must run out)
-  const struct AuvDev* self;  // this struct in device memory (as of the last bank load): the paired step's restore path
+  const struct AuvDev* self;  // this struct in device memory (as of the last bank load): the one-launch step's restore path
                               // reads its ~25 table pointers through it at the point of use -- as kernel arguments
                               // they would all be fetched (and spilled) at the entry of every wave of both roles
   int32_t* fresh_count; // [1]  } work list of the load-time pass that computes the reset rows
@@ -208,12 +206,12 @@ __device__ __forceinline__ int auv_pymod(int a, int s) {
   return r < 0 ? r + s : r;
 }
 
-#define AUV_PAIR_EMPTY 0x7ff8dead00000001ull       // paired step: "no word yet" (a NaN payload no arithmetic produces)
+#define AUV_PAIR_EMPTY 0x7ff8dead00000001ull       // one-launch step: "no word yet" (a NaN payload no arithmetic produces)
 #define AUV_PAIR_COLLISION 0x7ff8dead00000002ull   //              "the sweep found a collision"
 
 // Stores and loads that are coherent over the whole device one by one (relaxed agent-scope atomics: the
 // `sc1` forms, written through / read past the XCD's L2, which is not coherent with the other seven).  WT = false:
-// plain accesses.  Used by the paired step, where two waves on possibly different XCDs hand rows to each other
+// plain accesses.  Used by the one-launch step, where two waves on possibly different XCDs hand rows to each other
 // inside one launch (k_step_fused.hip: pair_finish).
 template <bool WT> __device__ __forceinline__ void auv_st(double* p, const double v) {
   if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;

@@ -493,11 +493,8 @@ struct NavOut {
   double u, v, r;                   // the velocities it was computed with (STATE rows 3..5)
 };
 
-// WT: the rows are stored write-through (auv_st), for the paired step.  `out`: lane 0's NavOut, or nullptr.
-// SEARCH_ONLY: stop after the nearest-point search and leave its result -- the winning segment's end points and the
-// arclength at its first vertex, NAV_HAND -- for nav_tail_lane (the two-launch step: the scalar tail of 64 environments
-// is then evaluated by ONE wave, lanes <-> environments, instead of by 64 waves with three busy lanes each).
-template <bool WT = false, bool SEARCH_ONLY = false>
+// WT: the rows are stored write-through (auv_st), for the one-launch step.  `out`: lane 0's NavOut, or nullptr.
+template <bool WT = false>
 __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const int lane, int* list,
                                            float* __restrict__ obs_out, const EnvPre* pre, NavSpec sp, const bool have_spec,
                                            const double* win_slots, const double2* pose_cs_in, NavOut* out = nullptr) {
@@ -539,11 +536,9 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
   const int n_act = sp.n_list;
   // cos / sin of the new heading for the reward's cos(heading error) below
   // (handed in by the dynamics wave of the two-kernel step, which forms them for eight environments at once)
-  double sin_psi = 0.0, cos_psi = 1.0;
-  if constexpr (!SEARCH_ONLY) {
-    if (pose_cs_in) cos_psi = pose_cs_in->x, sin_psi = pose_cs_in->y;
-    else sincos(psi, &sin_psi, &cos_psi);
-  }
+  double sin_psi, cos_psi;
+  if (pose_cs_in) cos_psi = pose_cs_in->x, sin_psi = pose_cs_in->y;
+  else sincos(psi, &sin_psi, &cos_psi);
   if (sp.in_regs) {
 #pragma unroll
     for (int q = 0; q < NAV_SPEC; q++) {
@@ -596,17 +591,6 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
   A.x = __shfl(bA.x, src, AUV_WAVE), A.y = __shfl(bA.y, src, AUV_WAVE);
   B.x = __shfl(bB.x, src, AUV_WAVE), B.y = __shfl(bB.y, src, AUV_WAVE);
   const double cum = __shfl(my_cum, src, AUV_WAVE);
-  if constexpr (SEARCH_ONLY) {
-    // NAV_HAND: 64-byte records [A.x, A.y, B.x, B.y, cum, mark, -, -].  WT (the tail runs in this very launch, on
-    // whichever XCD): written through, completed, then the mark (handoff-flag pattern of MI355X_MICROARCH.md).
-    double* h = d.nav_hand + 8 * (size_t)e;
-    if (lane == 0) auv_st<WT>((double2*)h, A), auv_st<WT>((double2*)h + 1, B), auv_st<WT>(h + 4, cum);
-    if constexpr (WT) {
-      auv_stores_done();
-      if (lane == 0) __hip_atomic_store((unsigned long long*)(h + 5), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
   // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure (all lanes, uniform)
   double dx = B.x - A.x, dy = B.y - A.y, len2 = dx * dx + dy * dy;
   double seglen = sqrt(len2);
@@ -690,7 +674,7 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
 // LDS, 16-byte aligned: three parked spline windows, then the list of surviving chunks.
 #define NAV_WIN_BYTES (3 * 20 * 8)
 #define NAV_SCRATCH_BYTES(nch_max) ((NAV_WIN_BYTES + (size_t)(nch_max) * sizeof(int) + 15) & ~(size_t)15)
-template <bool WT = false, bool SEARCH_ONLY = false>
+template <bool WT = false>
 __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const int lane, unsigned char* scratch,
                                            float* __restrict__ obs_out, const EnvPre* pre = nullptr,
                                            const double2* pose_cs = nullptr, NavOut* out = nullptr) {
@@ -703,86 +687,7 @@ __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const i
   const NavSpec sp = nav_speculate(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
                                    0.0, nullptr, pre ? pre->ed : nullptr);
   if (!AUV_RUN_N(d, 2)) return;
-  nav_finish<WT, SEARCH_ONLY>(d, e, lane, list, obs_out, pre, sp, true, nullptr, pose_cs ? pose_cs + e : nullptr, out);
-}
-
-// The navigation's tail for ONE environment by ONE lane (the two-launch step, lanes <-> environments): from the search's
-// NAV_HAND record the arclength, the spline at s and at the look-ahead point, the three angles, the navigation features
-// and observation columns, the path-following term of the reward -- operation for operation what nav_finish does with
-// lanes 0 / 1 / 2 of the environment's wave (same functions on the same inputs, hence the same bits: the launch shapes
-// are compared bit for bit in tests/test_gpu_parity.py), only evaluated one after the other in this lane.
-__device__ __forceinline__ NavOut nav_tail_core(const AuvDev& d, const int e, const EnvDesc& ed, const double2 A, const double2 B,
-                                                const double cum, const double px, const double py, const double psi, const double u,
-                                                const double v, const double r, float* __restrict__ obs_out) {
-  const int S = d.cfg.n_sensors;
-  const double* ws = d.world_scalar + 8 * (size_t)ed.w;
-  const double L = ws[0], goal_x = ws[1], goal_y = ws[2];
-  const double knot_first = d.knot_s[ed.kn0], knot_last = d.knot_s[ed.kn0 + ed.nk - 1];
-  double* inf = d.info64 + 8 * (size_t)e;
-  double* nv = d.nav64 + 8 * (size_t)e;
-  double* ob = d.obs64 + (size_t)e * (6 + S);
-  const double maxp_in = inf[5];
-  const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
-  double sin_psi, cos_psi;
-  sincos(psi, &sin_psi, &cos_psi);
-  // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure
-  const double dx = B.x - A.x, dy = B.y - A.y, len2 = dx * dx + dy * dy;
-  const double seglen = sqrt(len2);
-  const double pf = (len2 == 0.0) ? 0.0 : ((px - A.x) * dx + (py - A.y) * dy) / len2;
-  const double s = pf <= 0.0 ? cum : (pf <= 1.0 ? cum + pf * seglen : cum + seglen);
-  double s_t = s + d.cfg.look_ahead_distance;
-  if (L < s_t) s_t = L;
-  // vessel.py:471-515: the spline at s (nav_finish's lane 0) and at s_t (its lanes 1 and 2)
-  double p0[2], dp0[2], p1[2], dp1[2];
-  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, s, L, p0, dp0, nullptr);
-  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, s_t, L, p1, dp1, nullptr);
-  const double chi = atan2(dp0[1], dp0[0]);                                   // lane 0's angle
-  const double hyp0 = sqrt(dp0[0] * dp0[0] + dp0[1] * dp0[1]);
-  const double ux = hyp0 > 0.0 ? dp0[0] / hyp0 : 1.0, uy = hyp0 > 0.0 ? dp0[1] / hyp0 : 0.0;
-  const double la_dir = atan2(dp1[1], dp1[0]);                               // lane 1's
-  const double a2y = p1[1] - py, a2x = p1[0] - px;
-  const double tgt1 = atan2(a2y, a2x);                                        // lane 2's
-  const double hyp2 = sqrt(a2x * a2x + a2y * a2y);
-  const double tx = hyp2 > 0.0 ? a2x / hyp2 : 1.0, ty = hyp2 > 0.0 ? a2y / hyp2 : 0.0;
-  const double ddx = p0[0] - px, ddy = p0[1] - py;
-  const double cte = -uy * ddx + ux * ddy;                   // vessel.py:481-483: -sin(chi) dx + cos(chi) dy
-  const double la = auv_princip(la_dir - psi);
-  const double he = auv_princip(tgt1 - psi);
-  const double cos_he = tx * cos_psi + ty * sin_psi;        // cos(target direction - psi)
-  const double progress = s / L;
-  double maxp = maxp_in;
-  if (progress > maxp) maxp = progress;
-  const double gx = goal_x - px, gy = goal_y - py;
-  const double goal = sqrt(gx * gx + gy * gy);
-  const int reached = (goal <= d.cfg.min_goal_distance) || (progress >= d.cfg.min_path_progress);
-  const double cte100 = cte / 100;
-  double2* nv2 = (double2*)nv;
-  nv2[0] = make_double2(u, v), nv2[1] = make_double2(r, la), nv2[2] = make_double2(he, cte100), nv2[3] = make_double2(chi, s_t);
-  double2* inf2 = (double2*)inf;
-  inf[1] = (double)reached, inf2[1] = make_double2(goal, progress), inf[5] = maxp, inf2[3] = make_double2(s, 0.0);
-  const double rew_path = reward_path_term_cos(d, u, v, cos_he, cte100, progress, maxp);
-  d.rew_path[e] = rew_path;
-  NavOut out;
-  out.rew_path = rew_path, out.reached = reached, out.goal = goal, out.progress = progress, out.u = u, out.v = v, out.r = r;
-  const double c0 = auv_clip(u, -1.0, 1.0), c1 = auv_clip(v, -1.0, 1.0), c2 = auv_clip(r, -1.0, 1.0),
-               c3 = auv_clip(la, -1.0, 1.0), c4 = auv_clip(he, -1.0, 1.0), c5 = auv_clip(cte100, -1.0, 1.0);
-  ob[0] = c0, ob[1] = c1, ob[2] = c2, ob[3] = c3, ob[4] = c4, ob[5] = c5;
-  if (obs_out) {
-    float* oo = obs_out + (size_t)e * D;
-    oo[0] = (float)c0, oo[1] = (float)c1, oo[2] = (float)c2, oo[3] = (float)c3, oo[4] = (float)c4, oo[5] = (float)c5;
-  }
-  return out;
-}
-
-// ... with everything fetched from memory (the second launch of the two-launch step: all of it was stored by the first)
-__device__ __forceinline__ NavOut nav_tail_lane(const AuvDev& d, const int e, float* __restrict__ obs_out) {
-  const size_t n = (size_t)d.n;
-  const EnvDesc ed = d.env_desc[e];
-  const double2* hand = (const double2*)(d.nav_hand + 8 * (size_t)e);
-  const double2 A = hand[0], B = hand[1];
-  const double cum = hand[2].x;
-  return nav_tail_core(d, e, ed, A, B, cum, d.state[0 * n + e], d.state[1 * n + e], d.state[2 * n + e], d.state[3 * n + e],
-                       d.state[4 * n + e], d.state[5 * n + e], obs_out);
+  nav_finish<WT>(d, e, lane, list, obs_out, pre, sp, true, nullptr, pose_cs ? pose_cs + e : nullptr, out);
 }
 
 // ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----

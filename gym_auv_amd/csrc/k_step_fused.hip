@@ -2,12 +2,15 @@
 // same device functions as the individually launchable kernels (k1_dynamics / k2_lidar / k3_nav / k3_reward), so the
 // per-kernel parity tests cover their arithmetic and tests/test_gpu_parity.py pins the compositions bit for bit:
 //   k_step_roles            ONE launch per step: dynamics, LiDAR sweep, navigation + reward as three roles
-//   k23_lidar_nav<PAIRED>   K2 and K3-nav side by side in one launch (PAIRED: the navigation wave also finishes the step)
+//   k23_lidar_nav           K2 and K3-nav side by side in one launch (the fence-free three-launch shape)
 //   k31_reward_dyn          inside a captured graph of several steps: reward phase of step t + dynamics of step t + 1
 // Every launch covers the slice [e0, e0 + ne) of the handle's environments (AuvDev::e0 / ne; the whole batch by
 // default): sub-batches of one handle stepped on different streams overlap each other's head and tail.
 // (Measured and removed in round 3, numbers in DESIGN.md: the whole step as one wave per environment, 66.9 M
-// env-steps/s; [K1 + navigation] -> [LiDAR + reward], 73.6 M; navigation forked onto a second stream, 64.5 M.)
+// env-steps/s; [K1 + navigation] -> [LiDAR + reward], 73.6 M; navigation forked onto a second stream, 64.5 M; K1 ->
+// [LiDAR | navigation + reward] ("paired"), 98 M; the navigation's tail + reward with lanes <-> environments as a
+// second launch or a fourth role: 20 % fewer VALU instructions but a longer step per chain, 106-112 M against 133 M
+// with four sub-batch chains -- git history and profiles/r03/shapes_sweep*.log.)
 #include <cstdlib>
 #include <hip/hip_ext.h>
 
@@ -33,7 +36,7 @@
 
 namespace {
 
-// ---- the paired finish: reward / done / auto-reset inside the side-by-side launch -------------------
+// ---- the in-launch finish: reward / done / auto-reset by the navigation wave of the one-launch step ----
 // An environment's LiDAR wave and its navigation wave are two one-wave workgroups of the same launch; the
 // navigation wave also runs the reward phase (rewarder.py:78-140, :167-241; environment.py:333-347, :375-384) --
 // no third launch.  What it needs of the sweep is one 64-bit word per environment (the LiDAR term of the reward,
@@ -132,19 +135,12 @@ __device__ __forceinline__ void pair_finish_nav(const AuvDev& dk, const int e, c
   }
 }
 
-// K2 and K3-nav of the launch's environments in one launch of one-wave workgroups: workgroups [0, nb) sweep the LiDAR
-// of their environments, workgroups [nb, 2 nb) navigate theirs.  The two are independent given the new vessel state,
+// K2 and K3-nav of the launch's environments in one launch of one-wave workgroups: workgroups [0, ne) sweep the LiDAR
+// of their environments, workgroups [ne, 2 ne) navigate theirs.  The two are independent given the new vessel state,
 // so they run side by side (the LiDAR workgroups are dispatched first and fill the chip; navigation workgroups move
 // in as those retire; a wave slot is handed on the moment an environment's sweep ends) -- the concurrency of two
-// streams without the ~8 us a cross-stream event wait costs on each side.
-// PAIRED: the navigation wave also runs the reward phase (pair_finish_nav above); nb a multiple of 8.
-#ifndef AUV_PAIR_WT
-#define AUV_PAIR_WT 1   // (0: plain stores in the paired launch -- a measurement build only, see pair_finish)
-#endif
-template <bool PAIRED>
-__global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(AuvDev dk, float* __restrict__ obs_out,
-                                                                                 float* __restrict__ reward_out,
-                                                                                 uint8_t* __restrict__ done_out) {
+// streams without the ~8 us a cross-stream event wait costs on each side.  Nothing is handed over inside the launch.
+__global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(AuvDev dk, float* __restrict__ obs_out) {
   // (every table through the device-side copy AuvDev::self instead of the kernel arguments -- no scalar register
   // spilled any more -- was tried for the whole kernel: the loads then sit on the dependent chains, 36.3 -> 42.2 us)
   const AuvDev& d = dk;
@@ -152,63 +148,45 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
   const int lane = threadIdx.x;
   const int S = d.cfg.n_sensors;
   const int ne = d.ne;
-  const int nb = PAIRED ? 8 * ((ne + 7) / 8) : ne;                  // LiDAR workgroups: one environment each
-  const int nav0 = PAIRED ? nb + AUV_HOOK_SKEW(dk) : nb;            // first navigation workgroup
-  const bool nav_role = (int)blockIdx.x >= nb;                      // workgroup-uniform
-  constexpr bool WT = PAIRED && AUV_PAIR_WT;
-  unsigned char* slice = smem;
-  if (nav_role) {
-    const int el = (int)blockIdx.x - nav0;
-    if (el < 0 || el >= ne) return;
+  if ((int)blockIdx.x >= ne) {
+    const int el = (int)blockIdx.x - ne;
+    if (el >= ne) return;
     const int e = auv_uniform(d.e0 + el);
 #ifdef AUV_STAMPS
     const unsigned long long t_nav0 = wall_clock64();
 #endif
-    NavOut no;
-    no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
-    PairPre pp;
-    if constexpr (PAIRED) pp = pair_prefetch(d, e);
-    k3_nav_env(d, e, lane, slice, obs_out, nullptr, nullptr, PAIRED ? &no : nullptr);
+    k3_nav_env(d, e, lane, smem, obs_out);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 12] = t_nav0, d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif
-    if constexpr (PAIRED) pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
-#ifdef AUV_STAMPS
-    if (PAIRED && lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();     // end of the navigation wave incl. its finish
-#endif
   } else {
-    if ((int)blockIdx.x >= ne) return;
     const int e = auv_uniform(d.e0 + (int)blockIdx.x);
     // next action slot of a captured graph's ring: the dynamics kernel of this step has read the position, the
     // one of the next step has not been launched yet (a captured step covers the whole batch: e0 = 0)
     if (e == 0 && lane == 0 && dk.ring_slots > 1 && dk.ring_slot_host == -1) *dk.ring_pos = (*dk.ring_pos + 1) % dk.ring_slots;
-    const Slice L = carve(slice, S, d.k_max, d.m_max);
+    const Slice L = carve(smem, S, d.k_max, d.m_max);
     AUV_STAMP_DECL
 #ifdef AUV_STAMPS
     const unsigned long long t_real0 = wall_clock64();
 #endif
-    const int n_act = k2_front<WT>(d, e, lane, L, 1);
+    const int n_act = k2_front(d, e, lane, L, 1);
     if (d.cfg.use_lidar) {
       AUV_STAMP()
 #ifdef AUV_STAMPS
       unsigned long long sub[4] = {0, 0, 0, 0};
       k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e], sub);
-      if (lane == 0 && !PAIRED) d.stamps[(size_t)e * 16 + 7] = sub[0], d.stamps[(size_t)e * 16 + 14] = sub[1], d.stamps[(size_t)e * 16 + 15] = sub[2], d.stamps[(size_t)e * 16 + 6] = sub[3];
+      if (lane == 0) d.stamps[(size_t)e * 16 + 7] = sub[0], d.stamps[(size_t)e * 16 + 14] = sub[1], d.stamps[(size_t)e * 16 + 15] = sub[2], d.stamps[(size_t)e * 16 + 6] = sub[3];
 #else
       k2_stage_and_pairs(d, L, lane, n_act, d.state[2 * (size_t)d.n + e]);
 #endif
       AUV_STAMP()
       double term = 0.0;
-      const int collision = k2_back<WT>(d, e, lane, L, n_act, obs_out, &term);
+      k2_back(d, e, lane, L, n_act, obs_out, &term);
       AUV_STAMP()
       AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
 #ifdef AUV_STAMPS
       if (lane == 0) d.stamps[(size_t)e * 16 + 3] = t_real0, d.stamps[(size_t)e * 16 + 4] = wall_clock64();
       if (lane == 0) d.stamps[(size_t)e * 16 + 5] = (unsigned long long)L.sbase[n_act];
-#endif
-      if constexpr (PAIRED) pair_publish_lidar(d, e, lane, collision, term);
-#ifdef AUV_STAMPS
-      if (PAIRED && lane == 0) d.stamps[(size_t)e * 16 + 14] = wall_clock64();   // end of the LiDAR wave incl. its finish
 #endif
     }
   }
@@ -217,12 +195,12 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
 // ---- ONE launch per step: three roles -------------------------------------------------------------
 // k_step_roles   workgroups [0, nk) integrate the dynamics (Vessel.step, one wave = eight environments, eight lanes
 //                each: k1_group), workgroups [nk, nk + nb) sweep the LiDAR of one environment each, the rest navigate
-//                one environment each and run its reward phase (the paired finish above).  The sweep and the
+//                one environment each and run its reward phase (the in-launch finish above).  The sweep and the
 //                navigation need the state the dynamics role produces in the same launch: it hands each environment
 //                a 64-byte packet (x, y, psi, u, v, r, the vessel's step counter, a "ready" mark), stored
 //                write-through and completed before the mark is stored; the other two roles poll for the mark (the
 //                dynamics workgroups have the smallest indices, are dispatched first and wait for nobody; the poll
-//                is bounded like the paired finish's).  The navigation wave takes the mark away again when it has
+//                is bounded like the in-launch finish's).  The navigation wave takes the mark away again when it has
 //                finished the environment's step (its sweep wave has read the packet long before: the navigation
 //                wave has consumed the word the sweep stores last), so the next launch finds every mark down.  What
 //                is saved is the dynamics kernel's launch ramp and the kernel boundary behind it.  No launch
@@ -291,20 +269,6 @@ __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, c
   return true;
 }
 
-// FINISH = false (the two-launch step): the navigation role only SEARCHES (nearest segment of the path -> NAV_HAND)
-// and nobody finishes the step here -- the sweep needs no write-through stores and publishes no word, nothing polls
-// for one; the second launch, k_tail_reward_lanes, evaluates the navigation's scalar tail and the reward phase with
-// lanes <-> environments: 64 environments per wave instead of three busy lanes per environment (the tail is 19 % of
-// the one-launch step's VALU issue cycles, profiles/r03/valu_budget_polygons50.json).
-// SHAPE 2 (the one-launch step with FOUR roles): as SHAPE 0 the navigation role only searches, but the tail and the
-// reward phase follow in this very launch -- a fourth role of ne / 64 waves behind the others, lanes <-> environments.
-// A lane waits (bounded poll, sc1 loads) for its environment's state packet, its sweep's word and the search's
-// NAV_HAND mark, evaluates the tail and the reward phase, takes the three marks down; environments that ended are
-// then restored by the whole wave, one after the other.
-#define SHAPE_SEARCH 0
-#define SHAPE_WAVE_FINISH 1
-#define SHAPE_TAIL_ROLE 2
-template <int SHAPE>
 __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvDev dk, const void* __restrict__ actions,
                                                                            float* __restrict__ obs_out,
                                                                            float* __restrict__ reward_out,
@@ -373,7 +337,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     pre.cnt = d.counters[e];                               // t_step, episodes; the step counter comes with the state
     pre.ed = &ed;
     const Slice L = carve(smem, S, d.k_max, d.m_max);
-    k2_movers<SHAPE != SHAPE_SEARCH>(d, e, lane, L, ed, 1);
+    k2_movers<true>(d, e, lane, L, ed, 1);
     const K2Pre kp = k2_prefetch(d, e, lane, ed);
     k2_stage_beams(d, lane, L);
     // (also tried here: warming the caches with the nearby obstacles' boundary segments -- it has to wait for the
@@ -386,19 +350,19 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     if (lane == 0) d.stamps[(size_t)e * 16 + 2] = wall_clock64();
 #endif
     int n_act = 0;
-    if (AUV_RUN_L(d, 1)) n_act = k2_front<SHAPE != SHAPE_SEARCH>(d, e, lane, L, 1, &pre, nullptr, 1, &kp, true);
+    if (AUV_RUN_L(d, 1)) n_act = k2_front<true>(d, e, lane, L, 1, &pre, nullptr, 1, &kp, true);
     if (AUV_RUN_L(d, 3)) k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
     double term = 0.0;
-    const int collision = k2_back<SHAPE != SHAPE_SEARCH>(d, e, lane, L, n_act, obs_out, &term);
+    const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 4] = wall_clock64();
 #endif
-    if constexpr (SHAPE != SHAPE_SEARCH) pair_publish_lidar(d, e, lane, collision, term);
+    pair_publish_lidar(d, e, lane, collision, term);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 14] = wall_clock64();
 #endif
-  } else if (b < nk + 2 * nb + AUV_HOOK_SKEW(d)) {
-    // ---- Vessel.navigate of one environment (SHAPE_WAVE_FINISH: then its reward / done / auto-reset) ----
+  } else {
+    // ---- Vessel.navigate of one environment, then its reward / done / auto-reset ----
     const int el = b - nk - nb - AUV_HOOK_SKEW(d);
     if (el < 0 || el >= ne) return;
     const int e = auv_uniform(d.e0 + el);
@@ -412,95 +376,20 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 5] = wall_clock64();
 #endif
-    if constexpr (SHAPE != SHAPE_WAVE_FINISH) {
-      if (AUV_RUN_N(d, 1)) k3_nav_env<SHAPE == SHAPE_TAIL_ROLE, true>(d, e, lane, smem, obs_out, &pre, nullptr, nullptr);
+    PairPre pp = pair_prefetch(d, e);
+    pp.cnt = pre.cnt;
+    NavOut no;
+    no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
+    if (AUV_RUN_N(d, 1)) k3_nav_env(d, e, lane, smem, obs_out, &pre, nullptr, &no);
 #ifdef AUV_STAMPS
-      if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
+    if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif
-      return;
-    } else {
-      PairPre pp = pair_prefetch(d, e);
-      pp.cnt = pre.cnt;
-      NavOut no;
-      no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
-      if (AUV_RUN_N(d, 1)) k3_nav_env(d, e, lane, smem, obs_out, &pre, nullptr, &no);
+    pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
+    // the environment's step is complete (and its sweep wave gone): the packet's mark comes down for the next launch
+    if (lane == 0) __hip_atomic_store(d.k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef AUV_STAMPS
-      if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
+    if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();
 #endif
-      pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
-      // the environment's step is complete (and its sweep wave gone): the packet's mark comes down for the next launch
-      if (lane == 0) __hip_atomic_store(d.k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef AUV_STAMPS
-      if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();
-#endif
-    }
-  } else if constexpr (SHAPE == SHAPE_TAIL_ROLE) {
-    // ---- navigation tail + reward / done / auto-reset of 64 environments, lanes <-> environments ----
-    const int el = (b - nk - 2 * nb - AUV_HOOK_SKEW(d)) * AUV_WAVE + lane;
-    const bool valid = el < ne;
-    const int e = d.e0 + (valid ? el : ne - 1);                     // (idle lanes look at the last environment, store nothing)
-    // what earlier launches left
-    int4 cnt = d.counters[e];
-    const int w = d.world_idx[e];
-    const double cum_in = d.info64[8 * (size_t)e + 4];
-    const EnvDesc edl = d.env_desc[e];
-    const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
-    unsigned long long* hmark = (unsigned long long*)(d.nav_hand + 8 * (size_t)e + 5);
-    unsigned long long pw[7];
-    unsigned long long word = PAIR_EMPTY;
-    for (int polls = 0;; polls++) {
-      bool ready = !valid;
-      if (valid) {
-        unsigned long long x = 0ull;
-#pragma unroll
-        for (int i = 0; i < 7; i++) pw[i] = __hip_atomic_load(pk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), x ^= pw[i];
-        const unsigned long long mark = __hip_atomic_load(pk + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        word = __hip_atomic_load(d.pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hm = __hip_atomic_load(hmark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ready = mark != 0ull && roles_mark(x) == mark && word != PAIR_EMPTY && hm == 1ull;
-      }
-      if (!__any(!ready)) break;
-      if (polls == (AUV_HOOK_FAULT(d) ? (1 << 12) : PAIR_POLL_LIMIT)) {
-        if (lane == 0) __hip_atomic_store(d.pair_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-      }
-      __builtin_amdgcn_s_sleep(16);
-    }
-    int do_reset = 0;
-    if (valid) {
-      // the search's result: stored write-through and completed before its mark (which this lane has seen)
-      const double* h = d.nav_hand + 8 * (size_t)e;
-      const double2 A = make_double2(auv_ld<true>(h + 0), auv_ld<true>(h + 1)), B = make_double2(auv_ld<true>(h + 2), auv_ld<true>(h + 3));
-      const double cum = auv_ld<true>(h + 4);
-      const NavOut no = nav_tail_core(d, e, edl, A, B, cum, __longlong_as_double((long long)pw[0]), __longlong_as_double((long long)pw[1]),
-                                      __longlong_as_double((long long)pw[2]), __longlong_as_double((long long)pw[3]),
-                                      __longlong_as_double((long long)pw[4]), __longlong_as_double((long long)pw[5]), obs_out);
-      cnt.y = (int)(unsigned)pw[6];                                 // the vessel's step counter of this launch
-      // the three marks come down for the next launch
-      __hip_atomic_store(d.pair_word + e, PAIR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(d.k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(hmark, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      RewardIn in;
-      const int collision = word == PAIR_COLLISION;
-      in.closeness_reward = collision ? 0.0 : __longlong_as_double((long long)word);
-      in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
-      in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
-      in.cum = cum_in;
-      d.info64[8 * (size_t)e] = collision;
-      do_reset = reward_apply(d, e, collision, cnt, in, reward_out, done_out, false);
-    }
-    unsigned long long m = __ballot(do_reset);
-    if (m) {
-      // (rare) tables of the copy through the device-side copy of `d`, see pair_finish_nav
-      const AuvDev& dc = *(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)d.self;
-      while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int er = auv_uniform(__shfl(e, src, AUV_WAVE));
-        const int wr = __shfl(w, src, AUV_WAVE), ep = __shfl(cnt.z, src, AUV_WAVE);
-        restore_env(dc, er, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
-      }
-    }
   }
 }
 
@@ -535,44 +424,8 @@ __global__ void __launch_bounds__(AUV_WAVE) k31_reward_dyn(AuvDev d, const void*
   if (e < d.n) k1_env(d, e, actions, true);
 }
 
-// ---- second launch of the two-launch step: navigation tail + reward / done / auto-reset, lanes <-> environments ----
-// (rewarder.py:78-140, :167-241; environment.py:333-347, :375-384; vessel.py:471-541.)  Everything it reads was stored by
-// the launch before it.  It also takes the state packets' marks down for the next step's first launch.
-__global__ void __launch_bounds__(AUV_WAVE) k_tail_reward_lanes(AuvDev d, float* __restrict__ obs_out, float* __restrict__ reward_out,
-                                                                uint8_t* __restrict__ done_out) {
-  const int lane = threadIdx.x;
-  const int el = blockIdx.x * AUV_WAVE + lane;
-  const int e = d.e0 + el;
-  int do_reset = 0, w = 0;
-  int4 cnt = make_int4(0, 0, 0, 0);
-  if (el < d.ne) {
-    cnt = d.counters[e];
-    w = d.world_idx[e];
-    const int collision = d.collision[e];
-    const double rew_lidar = d.rew_lidar[e];
-    const double cum = d.info64[8 * (size_t)e + 4];
-    const NavOut no = nav_tail_lane(d, e, obs_out);
-    d.k1_pkt[8 * (size_t)e + 7] = 0ull;                      // (visible to the next launch's polls: kernel boundary)
-    RewardIn in;
-    in.closeness_reward = collision ? 0.0 : rew_lidar;
-    in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
-    in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
-    in.cum = cum;
-    d.info64[8 * (size_t)e] = collision;
-    do_reset = reward_apply(d, e, collision, cnt, in, reward_out, done_out, false);
-  }
-  unsigned long long m = __ballot(do_reset);
-  while (m) {
-    const int src = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    const int er = auv_uniform(__shfl(e, src, AUV_WAVE));
-    const int wr = __shfl(w, src, AUV_WAVE), ep = __shfl(cnt.z, src, AUV_WAVE);
-    restore_env(d, er, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
-  }
-}
-
 // ---- load-time probe of what the in-launch hand-overs rely on ----------------------------------------------------
-// The one-launch and paired shapes let a wave poll for a word that a workgroup with a SMALLER index of the same
+// The one-launch shape lets a wave poll for a word that a workgroup with a SMALLER index of the same
 // launch stores.  That terminates if workgroups are dispatched in index order (a poller's producer is resident or
 // done by the time the poller gets a slot) -- what gfx950 does, but HIP does not promise it.  k_probe_order has the
 // step's structure without its arithmetic: `np` producers (a short wait, then an sc1 word each), behind them
@@ -629,23 +482,11 @@ bool auv_k23_ok(const AuvDev& d) { return NAV_SCRATCH_BYTES(d.nch_max) <= k2_sli
 // ends -- the navigation workgroups queued behind the LiDAR ones start (and end) earlier.
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
-  hipExtLaunchKernelGGL(k23_lidar_nav<false>, dim3(2 * d.ne), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs,
-                        (float*)nullptr, (uint8_t*)nullptr);
+  hipExtLaunchKernelGGL(k23_lidar_nav, dim3(2 * d.ne), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs);
 }
 
-// ... with the reward phase run by the second of an environment's two waves (the paired step; needs a LiDAR sweep)
-bool auv_paired_ok(const AuvDev& d) { return auv_k23_ok(d) && d.cfg.use_lidar; }
-
-void auv_launch_k23_paired(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0,
-                           hipEvent_t ev1) {
-  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
-  const int nb = 8 * ((d.ne + 7) / 8);
-  hipExtLaunchKernelGGL(k23_lidar_nav<true>, dim3(2 * nb + AUV_HOOK_SKEW(d)), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs,
-                        reward, done);
-}
-
-// ---- the one-launch step ----
-bool auv_roles_ok(const AuvDev& d) { return auv_paired_ok(d); }
+// ---- the one-launch step (needs a LiDAR sweep: its word is what the navigation wave finishes the step on) ----
+bool auv_roles_ok(const AuvDev& d) { return auv_k23_ok(d) && d.cfg.use_lidar; }
 
 void auv_launch_step_roles(const AuvDev& d0, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
@@ -654,33 +495,7 @@ void auv_launch_step_roles(const AuvDev& d0, const void* actions, int dtype, flo
   const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
   const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
   const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d)), block(AUV_WAVE);
-  hipExtLaunchKernelGGL(k_step_roles<SHAPE_WAVE_FINISH>, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
-}
-
-// ... with the navigation tail + reward phase as a FOURTH role (lanes <-> environments)
-void auv_launch_step_roles4(const AuvDev& d0, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
-                            hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-  AuvDev d = d0;
-  d.act_f64 = dtype == AUV_F64;
-  const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
-  const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8), nt = (d.ne + AUV_WAVE - 1) / AUV_WAVE;
-  const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d) + nt), block(AUV_WAVE);
-  hipExtLaunchKernelGGL(k_step_roles<SHAPE_TAIL_ROLE>, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
-}
-
-// ---- the two-launch step: [dynamics | sweep | path search] -> [navigation tail + reward, lanes <-> environments] ----
-void auv_launch_step_search(const AuvDev& d0, const void* actions, int dtype, float* obs, hipStream_t st, hipEvent_t ev0,
-                            hipEvent_t ev1) {
-  AuvDev d = d0;
-  d.act_f64 = dtype == AUV_F64;
-  const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
-  const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
-  const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d)), block(AUV_WAVE);
-  hipExtLaunchKernelGGL(k_step_roles<SHAPE_SEARCH>, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, (float*)nullptr, (uint8_t*)nullptr);
-}
-
-void auv_launch_tail_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-  hipExtLaunchKernelGGL(k_tail_reward_lanes, dim3((d.ne + AUV_WAVE - 1) / AUV_WAVE), dim3(AUV_WAVE), 0, st, ev0, ev1, 0, d, obs, reward, done);
+  hipExtLaunchKernelGGL(k_step_roles, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
 }
 
 uint32_t auv_step_lds_bytes(const AuvDev& d) { return (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
@@ -688,13 +503,7 @@ uint32_t auv_step_lds_bytes(const AuvDev& d) { return (uint32_t)k2_slice_bytes(d
 hipError_t auv_step_fused_prepare(const AuvDev& d) {
   const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
   if (b <= 64 * 1024) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k23_lidar_nav<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_step_roles<SHAPE_SEARCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_step_roles<SHAPE_TAIL_ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)k_step_roles<SHAPE_WAVE_FINISH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  return hipFuncSetAttribute((const void*)k_step_roles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
 }

@@ -177,6 +177,13 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
                        const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
                        uint8_t* done_dev);
 
+/* The same with every sub-batch's launch stamped with its own start / stop HIP event on ITS stream (the kernel's own
+ * duration while the other chains run beside it, as a kernel trace reports it): out_ms[n_slices].  Waits for the
+ * step's launches (not for earlier work on other streams).  One-launch shape only.                            */
+int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams,
+                             const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
+                             uint8_t* done_dev, float* out_ms);
+
 /* The three kernels of step(), individually launchable (per-kernel parity tests):        */
 /* K1  Vessel.step: clip -> RKF45 of the 3-DOF model -> wrap psi.  (vessel.py:226-247,561-578) */
 int auv_step_dynamics(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, void* stream);
@@ -227,13 +234,11 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
  *                                    The roles hand their results on inside the launch through per-environment
  *                                    words stored and loaded coherently (csrc/k_step_fused.hip: k_step_roles,
  *                                    pair_finish_nav); waves that need a result poll for it, bounded.
- *   AUV_STEP_PAIRED                  K1 -> one launch whose workgroups do K2 for all envs and K3-nav for all envs
- *                                    side by side, the navigation wave also running K3-reward.  Two launches.
  *   AUV_STEP_SIDE_BY_SIDE            K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward: nothing is
  *                                    handed over inside a launch.  Inside a captured graph of several steps
  *                                    K3-reward of step t and K1 of step t + 1 share a launch (also what a graph
  *                                    of several steps captured in the modes above uses: it replays faster).
- * The in-launch hand-overs of ONE_LAUNCH and PAIRED assume that the workgroups of a launch are dispatched in index
+ * The in-launch hand-overs of ONE_LAUNCH assume that the workgroups of a launch are dispatched in index
  * order (a polling wave's producer has a smaller index; true on gfx950, not promised by HIP).  Every bank load
  * therefore runs a probe launch of the same structure (more one-wave workgroups than the chip has slots, three
  * generations polling each other); if any of its polls runs out, and whenever the LiDAR is off, the handle steps in
@@ -242,9 +247,9 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
  * into its reset state and switched the handle to AUV_STEP_SIDE_BY_SIDE for good; later calls succeed.  A step
  * replayed from a captured graph (hipGraphLaunch, or a torch CUDAGraph around auv_step) is not checked per replay:
  * poll auv_health() once per rollout there.
- * (Removed in round 3, measured slower: the whole step as one kernel, [K1 + K3-nav] -> [K2 + K3-reward], and
- * K3-nav forked onto a second stream; their enum values 1, 2, 3 are rejected.)                                */
-enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_PAIRED = 4, AUV_STEP_ONE_LAUNCH = 5, AUV_STEP_AUTO = 6, AUV_STEP_TWO_LAUNCH = 7, AUV_STEP_FOUR_ROLES = 8 };
+ * (Removed in round 3, measured slower: the whole step as one kernel, [K1 + K3-nav] -> [K2 + K3-reward], K3-nav
+ * forked onto a second stream, and K1 -> [K2 | K3-nav + K3-reward]; their enum values 1 .. 4 are rejected.)      */
+enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_LAUNCH = 5, AUV_STEP_AUTO = 6 };
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
 /* The shape a launch of n_envs_per_launch environments (<= 0: the whole batch) is really stepped in: AUV_STEP_*. */
 int auv_effective_step_mode(auv_handle_t* h, int32_t n_envs_per_launch);
@@ -256,7 +261,6 @@ int auv_health(auv_handle_t* h, int32_t* out4);
 /* One step with every dispatch stamped with its own start / stop HIP event on `stream` (the kernel's
  * own duration, as a kernel trace reports it).  out_ms[0..3] by effective mode:
  *   AUV_STEP_ONE_LAUNCH    the one launch, 0, 0, whole step
- *   AUV_STEP_PAIRED        K1, [K2 + K3-nav + K3-reward], 0, whole step (first start .. last stop)
  *   AUV_STEP_SIDE_BY_SIDE  K1, [K2 + K3-nav], K3-reward, whole step. */
 int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                    float* reward_dev, uint8_t* done_dev, void* stream, float* out_ms4);

@@ -51,7 +51,7 @@ def main():
 
     # ---- the hand-overs with an environment's waves on DIFFERENT XCDs (three idle workgroups between the roles):
     # bit for bit the three-launch shape over short episodes (every environment restored >= 10 times)
-    for mode in ("paired", "one_launch"):
+    for mode in ("one_launch",):
         n = 1024
         cfg = effective_reference_config(use_lidar=True)
         cfg.episode.max_timesteps = 5
@@ -72,7 +72,7 @@ def main():
 
     # ---- a poll that runs out: the launch ENDS, the next call reports it once, every environment is back in its
     # reset state, the handle goes on in the three-launch shape -- bit for bit what a fresh handle does from reset
-    for mode in ("paired", "one_launch"):
+    for mode in ("one_launch",):
         n = 64
         cfg = effective_reference_config(use_lidar=True)
         env = env_(cfg, n, mode, fault=1)

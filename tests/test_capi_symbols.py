@@ -31,6 +31,20 @@ def test_library_loads_and_exports_all_symbols():
     assert lib.auv_last_error() is not None
 
 
+def test_shipped_library_exports_no_test_or_diagnostic_hooks():
+    """auv_test_hooks (roles skewed over XCDs, a sweep that withholds its word) and auv_diag_cuts (phase cuts for the
+    VALU budget) exist only in separate builds (make hooks; tools/build_variant.sh cuts); the product library has
+    neither, and does not look at the environment variables round 2's build did."""
+    lib = _capi.load_library()
+    assert not hasattr(lib, "auv_test_hooks") and not hasattr(lib, "auv_diag_cuts")
+    blob = open(_capi.LIB_PATH, "rb").read()
+    for name in (b"AUV_PAIR_FAULT", b"AUV_PAIR_SKEW", b"AUV_K23_WPB", b"getenv"):
+        assert name not in blob, name
+    if os.path.exists(_capi.HOOKS_LIB_PATH):
+        hooks = C.CDLL(_capi.HOOKS_LIB_PATH)
+        assert hasattr(hooks, "auv_test_hooks")
+
+
 def test_struct_sizes_match_header(tmp_path):
     """sizeof() from the real header (compiled with gcc) == the ctypes mirrors."""
     import subprocess

@@ -183,7 +183,7 @@ def test_cull_limits_at_integer_boundaries():
     env.close()
 
 
-@pytest.mark.parametrize("mode", ["paired", "one_launch", "two_launch", "four_roles", "side_by_side"])
+@pytest.mark.parametrize("mode", ["one_launch", "side_by_side"])
 def test_vessel_far_from_the_path_many_surviving_chunks(mode):
     """Far from a curved path many 64-segment chunks can hold the nearest point: the navigation's survivor list is
     longer than what it keeps in registers and takes the route through memory (and, at equal distances to two parts of

@@ -252,7 +252,7 @@ def test_step_modes_agree_bitwise(dtype):
     cfg = effective_reference_config(use_lidar=True)
     cfg.episode.max_timesteps = 9
     envs = []
-    for mode in ("side_by_side", "paired", "one_launch", "auto", "two_launch", "four_roles"):
+    for mode in ("side_by_side", "one_launch", "auto"):
         e = _env(cfg, bank, n)
         e.set_step_mode(mode)
         assert e.effective_step_mode() == (AUTO_SMALL if mode == "auto" else mode)
@@ -263,17 +263,17 @@ def test_step_modes_agree_bitwise(dtype):
         a = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (n, 2)), dtype=dtype, device="cuda:0")
         outs = [e.step(a)[:3] for e in envs]
         torch.cuda.synchronize()
-        for other in (1, 2, 3, 4, 5):
+        for other in (1, 2):
             for x, y in zip(outs[0], outs[other]):
                 assert torch.equal(x, y)
             for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO"):
                 assert torch.equal(envs[0].read(f), envs[other].read(f)), f
 
 
-@pytest.mark.parametrize("mode", ["paired", "one_launch", "two_launch", "four_roles"])
-def test_paired_step_bitwise_with_many_resets(mode):
-    """The in-launch hand-overs (paired: the second of an environment's two waves runs the reward phase inside the
-    side-by-side launch; one_launch: the dynamics role too) against the three-launch shape, bit for bit, over short
+@pytest.mark.parametrize("mode", ["one_launch"])
+def test_one_launch_step_bitwise_with_many_resets(mode):
+    """The in-launch hand-overs of the one-launch step (dynamics role -> sweep and navigation waves; sweep wave ->
+    navigation wave, which runs the reward phase) against the three-launch shape, bit for bit, over short
     episodes: every environment is restored many times, by whichever of its waves ends last.  Production placement
     (an environment's waves share an XCD); the same with the roles skewed onto different XCDs needs the hook build:
     test_hook_build_cases."""
@@ -305,7 +305,7 @@ def test_paired_step_bitwise_with_many_resets(mode):
     ms = par.step_timed(a)
     ref.step(a)
     torch.cuda.synchronize()
-    assert ms[2] == 0.0 and len(par.timed_kernel_names()) == (1 if mode in ("one_launch", "four_roles") else 2) and torch.equal(ref.obs, par.obs)
+    assert ms[2] == 0.0 and len(par.timed_kernel_names()) == 1 and torch.equal(ref.obs, par.obs)
 
 
 @pytest.fixture(scope="module")
@@ -330,12 +330,12 @@ def hook_cases():
 def test_hook_build_cases(hook_cases):
     """(a) hand-overs across XCDs: with three idle workgroups between the roles an environment's waves sit on
     different XCDs, so the packet, the word and the restore rows cross L2s -- still bit for bit the three-launch shape.
-    (b) the waits inside the one-launch / paired step are bounded: with one sweep withholding its word its navigation
+    (b) the waits inside the one-launch step are bounded: with one sweep withholding its word its navigation
     wave gives up, the launch ENDS, the next call raises once ("timed out") having put every environment back into
     its reset state, and the handle carries on in the three-launch shape, bit for bit what a fresh handle does."""
     skew = [c for c in hook_cases if c["case"] == "skew"]
     fault = [c for c in hook_cases if c["case"] == "fault"]
-    assert {c["mode"] for c in skew} == {"paired", "one_launch"} and {c["mode"] for c in fault} == {"paired", "one_launch"}
+    assert {c["mode"] for c in skew} == {"one_launch"} and {c["mode"] for c in fault} == {"one_launch"}
     for c in skew:
         assert c["bitwise"] and c["n_done"] >= 10 * c["n"] and c["effective"] == c["mode"], c
     for c in fault:
@@ -378,7 +378,7 @@ def test_probe_health_and_mode_selection():
     assert env.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0)
     assert env.step_mode == "auto" and env.effective_step_mode() == AUTO_SMALL
     assert env.effective_step_mode(16383) == AUTO_SMALL and env.effective_step_mode(16384) == "side_by_side"
-    for removed in (1, 2, 3, 9, -1):
+    for removed in (1, 2, 3, 4, 7, -1):
         assert _LIB.auv_set_step_mode(env._h, removed) != 0
     nol = _env(effective_reference_config(use_lidar=False), bank, 16)      # no sweep, nothing to hand over
     assert nol.effective_step_mode() == "side_by_side"
@@ -389,7 +389,7 @@ def test_probe_health_and_mode_selection():
     assert rc != 0 and b"aligned" in _LIB.auv_last_error()
 
 
-@pytest.mark.parametrize("mode", ["one_launch", "two_launch", "four_roles", "paired", "side_by_side"])
+@pytest.mark.parametrize("mode", ["one_launch", "side_by_side"])
 @pytest.mark.parametrize("n,k", [(1000, 3), (192, 2), (70, 4)])
 def test_sub_batches_bitwise(mode, n, k):
     """The batch stepped as k sub-batches on k streams (auv_step_slice / auv_step_pipelined; VecEnv step_async /

@@ -1,8 +1,10 @@
-"""Copy the judged summaries of a tools/run_profiles.sh run from gpurun_out/<run>/ to profiles/<tag>/ and refresh
-the two files bench.py reads for the dominant kernel of the headline workload:
-  profiles/pmc_traffic.json  HBM bytes per launch from the separate FETCH_SIZE / WRITE_SIZE passes
-  profiles/pmc_sq.json       SQ counters per launch (VALU leg)
-usage: python tools/publish_profiles.py gpurun_out/<run> <tag> [workload]"""
+"""Copy the judged summaries of a tools/run_profiles.sh (or pmc_workload.sh) run from gpurun_out/<run>/ to
+profiles/<tag>/ and refresh the two files bench.py reads:
+  profiles/pmc_traffic.json  HBM bytes per STEP from the separate FETCH_SIZE / WRITE_SIZE passes
+  profiles/pmc_sq.json       SQ counters per STEP (VALU leg, wait share) and the shader clock of the pass
+both keyed "<workload>/sub<K>" and carrying the sha256 of the libauv_hip.so they were measured on (recorded on the
+GPU box by the run script), so that bench.py can mark a leg stale when the library has changed since.
+usage: python tools/publish_profiles.py gpurun_out/<run> <tag> [workload] [sub-batches]"""
 import glob
 import json
 import os
@@ -11,36 +13,38 @@ import sys
 
 run, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "polygons50"
+sub = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(os.path.join(run, "bench_*.json")) + [os.path.join(run, n) for n in (
-        "kernel_trace_summary.txt", "kernel_stats.csv", "pmc_summary.json", "pmc_sq_summary.json", "pmc_sq_kernel_durations.txt",
-        "bench_2ranks_refused.out")]:
+for f in glob.glob(os.path.join(run, "bench_*.json")) + glob.glob(os.path.join(run, "*.txt")) + glob.glob(os.path.join(run, "pmc_*.json")) + \
+        [os.path.join(run, n) for n in ("kernel_stats.csv", "bench_2ranks_refused.out", "lib_sha256.txt")]:
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, dst)
-clean = lambda k: k.split("<")[0]   # noqa: E731
-pmc = json.load(open(os.path.join(run, "pmc_summary.json")))
-traffic = {clean(k): v["bytes_reads_doubled"] for k, v in pmc.items() if "fresh" not in k}
-raw = {clean(k): v["bytes_raw"] for k, v in pmc.items() if "fresh" not in k}
+sha = open(os.path.join(run, "lib_sha256.txt")).read().split()[0]
+summ = json.load(open(os.path.join(run, "pmc_step_summary.json")))
+ps = summ["per_step"]
+key = "%s/sub%d" % (workload, sub)
 tpath = os.path.join(root, "profiles", "pmc_traffic.json")
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-t.setdefault(workload, {}).update(traffic)            # (kernels of launch shapes profiled in earlier runs stay)
-t.setdefault(workload + "_raw", {}).update(raw)
-t["_note"] = ("HBM bytes per launch at 4096 envs per GPU from SEPARATE rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes "
-              "(tools/run_profiles.sh; profiles/%s/pmc_summary.json).  <workload>: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 "
-              "correction of MI355X_MICROARCH.md for wide coalesced reads (FETCH_SIZE counts 64 B per 128-B request); "
-              "<workload>_raw: (FETCH_SIZE + WRITE_SIZE) x 1024.  K1's 8-byte accesses read 1:1 (274 KiB fetched vs 288 KiB "
-              "algorithmic reads), the kernels with 16/32-byte loads lie between the two figures." % tag)
+t = {k: v for k, v in t.items() if "/" in k or k == "_note"}     # (keys of earlier rounds' layout are dropped)
+t[key] = dict(bytes_reads_doubled=ps["bytes_reads_doubled"], bytes_raw=ps["bytes_raw"], FETCH_SIZE_KiB=ps.get("FETCH_SIZE"),
+              WRITE_SIZE_KiB=ps.get("WRITE_SIZE"), launches_per_step=summ["launches_per_step"], lib_sha256=sha, profile="profiles/%s/pmc_step_summary_%s_sub%d.json" % (tag, workload, sub))
+t["_note"] = ("HBM bytes per STEP (all launches of one step of 4096 envs per GPU) from SEPARATE rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+              "passes (tools/run_profiles.sh, tools/pmc_workload.sh, tools/pmc_step_summary.py).  bytes_reads_doubled = (2 x FETCH_SIZE + "
+              "WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads; bytes_raw = (FETCH_SIZE + WRITE_SIZE) x "
+              "1024; the kernels' 16/32-byte loads lie between the two.  lib_sha256: the library the pass ran on.")
 json.dump(t, open(tpath, "w"), indent=1)
-sq = json.load(open(os.path.join(run, "pmc_sq_summary.json")))
 spath = os.path.join(root, "profiles", "pmc_sq.json")
 s = json.load(open(spath)) if os.path.exists(spath) else {}
-s.setdefault(workload, {}).update({clean(k): {c: v[c] for c in v if c.startswith("SQ_") or c == "launches"} for k, v in sq.items()})
-s["_note"] = ("SQ counters per launch (medians) at 4096 envs per GPU from one rocprofv3 --pmc pass, steady state (steps 1900-2200 of "
-              "the headline run), tools/run_profiles.sh; profiles/%s/pmc_sq_summary.json.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* "
-              "count quad-cycles summed over waves, SQ_INSTS_* wave-instructions, SQ_BUSY_CYCLES busy cycles summed over the 32 shader "
-              "engines.  VALU leg = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x SQ_BUSY_CYCLES / 32)." % tag)
+s = {k: v for k, v in s.items() if "/" in k or k == "_note"}
+s[key] = dict({c: ps[c] for c in ps if c.startswith("SQ_")}, clock_ghz=ps["clock_ghz"], launches_per_step=summ["launches_per_step"],
+              lib_sha256=sha, profile="profiles/%s/pmc_step_summary_%s_sub%d.json" % (tag, workload, sub))
+s["_note"] = ("SQ counters per STEP (summed over the launches of one step of 4096 envs per GPU, steady state) from one rocprofv3 --pmc pass.  "
+              "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves, SQ_INSTS_* wave-instructions.  clock_ghz = "
+              "SQ_BUSY_CYCLES / 32 shader engines / dispatch duration in the same pass.  VALU leg of bench.py = 4 x SQ_ACTIVE_INST_VALU / "
+              "(1024 SIMDs x clock x measured time per step); wait share = SQ_WAIT_ANY / SQ_WAVE_CYCLES.")
 json.dump(s, open(spath, "w"), indent=1)
-print("published", dst, "| traffic", traffic, "| valu frac",
-      {k: round(4 * v["SQ_ACTIVE_INST_VALU"] / (1024 * v["SQ_BUSY_CYCLES"] / 32), 3) for k, v in s[workload].items()})
+shutil.copy(os.path.join(run, "pmc_step_summary.json"), os.path.join(dst, "pmc_step_summary_%s_sub%d.json" % (workload, sub)))
+print("published", dst, key, "| traffic", t[key]["bytes_raw"], t[key]["bytes_reads_doubled"], "| valu issue cycles per step",
+      int(4 * s[key]["SQ_ACTIVE_INST_VALU"]), "clock", s[key]["clock_ghz"], "| sha", sha[:12])
