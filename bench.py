@@ -288,7 +288,8 @@ def main():
     K = max(0, args.graph)
     sub = args.sub_batches
     if sub <= 0:
-        sub = 4 if (n_local >= 2048 and not K and env.effective_step_mode(n_local // 4) == "one_launch") else 1
+        sub = 4 if (n_local >= 2048 and not K and args.actions == "uniform" and
+                    env.effective_step_mode(n_local // 4) == "one_launch") else 1
     if K:
         sub = 1
     if K:
@@ -310,24 +311,31 @@ def main():
 
         if sub > 1:
             env.set_sub_batches(sub)
+            sub = env.sub_batches
 
         def run(i0, n):
             # look-ahead pilot: full thrust, rudder proportional to the heading error (observation
-            # column 4, already clipped to +-1 rad): two tiny torch kernels per step, all on the device.  With
-            # sub-batches: VecEnv step_async / step_wait (the chains wait for the action, the caller's stream for them)
+            # column 4, already clipped to +-1 rad): a tiny torch kernel per step, all on the device.  With sub-batches the
+            # pilot of a sub-batch runs on that sub-batch's stream, so the chains stay independent of each other (a
+            # per-step step_async / step_wait over all chains costs two cross-stream waits per chain and step: 37 M)
             for _ in range(n):
-                torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
                 if sub > 1:
-                    env.step_async(act)
-                    env.step_wait()
+                    for i, (lo, cnt) in enumerate(env._slices):
+                        with torch.cuda.stream(env._sub_streams[i]):
+                            torch.mul(env.obs[lo:lo + cnt, 4], 0.15, out=act[lo:lo + cnt, 1])
+                        env.step_slice(i, act)
                 else:
+                    torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
                     env.step(act)
     elif sub > 1:
         env.set_sub_batches(sub)
+        sub = env.sub_batches          # (fewer if the device does not run that many streams side by side)
 
         def run(i0, n):
             # K independent launch chains: sub-batch s of step i goes to stream s; nothing orders the chains against
             # each other (the actions are resident), the synchronize() around the timed region waits for all of them
+            # (delaying chain i once by i / K of a step period when a stretch starts -- chains that start together might
+            # run in lockstep -- was measured: no difference at 20, 100, 500 steps; they are out of phase by themselves)
             for i in range(n):
                 env.step_pipelined(pool[(i0 + i) % n_pool])
     else:
@@ -356,7 +364,7 @@ def main():
     n_prof = min(max(args.steps, 20), 100)
     alg = algorithmic_bytes(bank, S, world_of_env, nearby)
     step_bytes = sum(alg[ph] for ph in ("k1", "lidar", "nav", "reward"))
-    pipelined = sub > 1 and args.actions == "uniform"
+    pipelined = sub > 1 and args.actions == "uniform" and env.effective_step_mode(max(1, n_local // sub)) == "one_launch"
     if pipelined:
         # every sub-batch launch stamped on its own stream while the other chains run beside it
         lms = np.zeros(env.sub_batches)
@@ -392,7 +400,7 @@ def main():
     # launches of a step run CONCURRENTLY, so one launch's bytes / duration is a quarter of what the chip moves; the
     # leg is then all launches' bytes of a step / the measured time per step of the timed region (gaps included).
     ms_step = 1e3 * elapsed / args.steps
-    if pipelined:
+    if sub > 1:
         achieved = step_bytes / (ms_step * 1e-3) / 1e9
     else:
         achieved = per_kernel[dom]["achieved_GBs"]

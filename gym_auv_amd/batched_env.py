@@ -155,21 +155,45 @@ class BatchedAuvEnv:
         return self.obs, self.reward, self.done, self._lazy_info()
 
     # ------------------------------------------------------------------------------ sub-batches
+    def _concurrent_streams(self, k: int):
+        """k streams whose kernels really run side by side.  HIP multiplexes streams onto a few hardware queues (four
+        by default, GPU_MAX_HW_QUEUES) and two streams on the same queue serialise, so candidates are tested pairwise
+        (auv_streams_overlap: a 300 us do-nothing wave on each) and a set that overlaps mutually is chosen.  Returns
+        fewer than k when the device does not offer k (at most four kernels run concurrently on MI355X anyway)."""
+        with torch.cuda.device(self.device):
+            cands = [torch.cuda.Stream(device=self.device) for _ in range(max(8, 2 * k))]
+        ratio = C.c_float()
+
+        def overlap(a, b):
+            _check(_LIB.auv_streams_overlap(self._h, C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), C.byref(ratio)),
+                   "auv_streams_overlap")
+            return ratio.value < 1.5
+        chosen = [cands[0]]
+        for c in cands[1:]:
+            if len(chosen) == k:
+                break
+            if all(overlap(c, o) for o in chosen):
+                chosen.append(c)
+        return chosen
+
     def set_sub_batches(self, k: int):
-        """Split the batch into `k` contiguous sub-batches, each with a stream of its own.  `step_async` then steps
-        them as k independent launch chains that overlap on the GPU (one sub-batch's sweeps run under another's
-        dynamics chain and navigation tail); results are bit-identical to `step`.  k = 1 restores the single
-        launch on the caller's stream.  Slice boundaries are multiples of 64 environments."""
+        """Split the batch into `k` contiguous sub-batches, each with a stream of its own.  `step_pipelined` /
+        `step_async` then step them as k independent launch chains that overlap on the GPU (one sub-batch's sweeps run
+        under another's dynamics chain and navigation tail); results are bit-identical to `step`.  k = 1 restores the
+        single launch.  Slice boundaries are multiples of 64 environments; if the device runs fewer than k streams
+        side by side (see _concurrent_streams) the batch is split into that many."""
         k = int(k)
         if k < 1 or k > 64:
             raise ValueError("sub-batches must be in [1, 64]")
         n = self.n_envs
+        torch.cuda.synchronize(self.device)
+        streams = self._concurrent_streams(k) if k > 1 else [torch.cuda.Stream(device=self.device)]
+        k = min(k, len(streams))
         per = -(-n // k)
         per = -(-per // 64) * 64
         self._slices = [(lo, min(per, n - lo)) for lo in range(0, n, per)]
         self.sub_batches = len(self._slices)
-        with torch.cuda.device(self.device):
-            self._sub_streams = [torch.cuda.Stream(device=self.device) for _ in self._slices]
+        self._sub_streams = streams[:self.sub_batches]
         self._bounds_c = (C.c_int32 * (self.sub_batches + 1))(*([lo for lo, _ in self._slices] + [n]))
         self._streams_c = (C.c_void_p * self.sub_batches)(*[st.cuda_stream for st in self._sub_streams])
         self._async_pending = False

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -36,6 +37,7 @@ bool auv_roles_ok(const AuvDev& d);
 void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st);
+void auv_launch_spin(unsigned long long ticks, hipStream_t st);
 hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
                    float* out_closeness, hipStream_t st);
@@ -766,6 +768,26 @@ int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* b
     HIP_TRY(hipEventSynchronize(h->slice_ev[2 * i + 1]));
     HIP_TRY(hipEventElapsedTime(&out_ms[i], h->slice_ev[2 * i], h->slice_ev[2 * i + 1]));
   }
+  return AUV_OK;
+}
+
+int auv_streams_overlap(auv_handle_t* h, void* stream_a, void* stream_b, float* out_ratio) {
+  if (!h || !out_ratio) return fail(AUV_EINVAL, "auv_streams_overlap: bad arguments");
+  HIP_TRY(hipSetDevice(h->device));
+  const double spin_us = 300.0;
+  const unsigned long long ticks = (unsigned long long)(spin_us * 100.0);          // wall_clock64 runs at 100 MHz
+  hipStream_t sa = (hipStream_t)stream_a, sb = (hipStream_t)stream_b;
+  auv_launch_spin(100, sa), auv_launch_spin(100, sb);                               // (code object loaded, queues awake)
+  HIP_TRY(hipStreamSynchronize(sa));
+  HIP_TRY(hipStreamSynchronize(sb));
+  const auto t0 = std::chrono::steady_clock::now();
+  auv_launch_spin(ticks, sa);
+  auv_launch_spin(ticks, sb);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(sa));
+  HIP_TRY(hipStreamSynchronize(sb));
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  *out_ratio = (float)(us / spin_us);
   return AUV_OK;
 }
 

@@ -457,7 +457,15 @@ __global__ void __launch_bounds__(AUV_WAVE) k_probe_order(unsigned int* __restri
   if (lane == 0 && b < np + nc) __hip_atomic_store(mine, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// a wave that does nothing for `ticks` of the 100 MHz wall clock (auv_streams_overlap: do two streams run side by side?)
+__global__ void k_spin(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 }  // namespace
+
+void auv_launch_spin(unsigned long long ticks, hipStream_t st) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(AUV_WAVE), 0, st, ticks); }
 
 hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {

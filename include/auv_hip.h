@@ -184,6 +184,13 @@ int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* b
                              const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
                              uint8_t* done_dev, float* out_ms);
 
+/* Do kernels on these two streams run side by side?  HIP multiplexes streams onto a few hardware queues (four by
+ * default); two streams that land on the same one run their kernels one after the other, and sub-batch chains on them
+ * do not overlap.  Launches a 300 us do-nothing wave on each and reports (wall time until both have ended) / 300 us:
+ * about 1 when they overlap, about 2 when they do not.  Synchronises both streams.  For choosing the streams of
+ * auv_step_pipelined (BatchedAuvEnv.set_sub_batches does).                                                        */
+int auv_streams_overlap(auv_handle_t* h, void* stream_a, void* stream_b, float* out_ratio);
+
 /* The three kernels of step(), individually launchable (per-kernel parity tests):        */
 /* K1  Vessel.step: clip -> RKF45 of the 3-DOF model -> wrap psi.  (vessel.py:226-247,561-578) */
 int auv_step_dynamics(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, void* stream);

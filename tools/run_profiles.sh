@@ -16,11 +16,11 @@ echo "headline: $(cut -c1-140 $OUT/bench_polygons50.json)"
 python bench.py --gpus 1 --steps 20 --warmup 5 --bank-cache /tmp/bank --cpu-baseline 0 > $OUT/bench_driver_command.json 2>/dev/null
 for k in 1 2 3; do $B --sub-batches $k --cpu-baseline 0 > $OUT/bench_polygons50_sub$k.json 2>/dev/null; done
 $B --step-mode side_by_side --sub-batches 1 --cpu-baseline 0 > $OUT/bench_polygons50_side_by_side_sub1.json 2>/dev/null
-$B --step-mode side_by_side --cpu-baseline 0 > $OUT/bench_polygons50_side_by_side_sub4.json 2>/dev/null
+$B --step-mode side_by_side --sub-batches 4 --cpu-baseline 0 > $OUT/bench_polygons50_side_by_side_sub4.json 2>/dev/null
 $B --graph 16 --cpu-baseline 0 > $OUT/bench_polygons50_graph16.json 2>/dev/null
 $B --worlds-per-env 1 --cpu-baseline 0 > $OUT/bench_polygons50_worlds1.json 2>/dev/null
-$B --actions pilot --cpu-baseline 0 > $OUT/bench_polygons50_pilot_sub4.json 2>/dev/null
-$B --actions pilot --sub-batches 1 --cpu-baseline 0 > $OUT/bench_polygons50_pilot_sub1.json 2>/dev/null
+$B --actions pilot --cpu-baseline 0 > $OUT/bench_polygons50_pilot_sub1.json 2>/dev/null
+$B --actions pilot --sub-batches 2 --cpu-baseline 0 > $OUT/bench_polygons50_pilot_sub2.json 2>/dev/null
 $B --workload circles20 --cpu-baseline 0 > $OUT/bench_circles20.json 2>/dev/null
 $B --workload moving28 --cpu-baseline 0 > $OUT/bench_moving28.json 2>/dev/null
 $B --workload mixed47 --envs 8192 --cpu-baseline 0 > $OUT/bench_mixed47_8192.json 2>/dev/null
