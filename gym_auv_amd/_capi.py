@@ -137,6 +137,7 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_step_pipelined": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp]),
         "auv_step_pipelined_timed": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp, C.POINTER(C.c_float)]),
         "auv_streams_overlap": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float)]),
+        "auv_episode_log": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.POINTER(C.c_int64), vp]),
         "auv_health": (C.c_int, [vp, C.POINTER(i32)]),
         "auv_effective_step_mode": (C.c_int, [vp, i32]),
         "auv_step_dynamics": (C.c_int, [vp, vp, i32, vp]),
@@ -173,7 +174,7 @@ def load_library(path: str = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset", "auv_step", "auv_step_slice",
-                    "auv_step_pipelined", "auv_step_pipelined_timed", "auv_streams_overlap", "auv_health", "auv_effective_step_mode",
+                    "auv_step_pipelined", "auv_step_pipelined_timed", "auv_streams_overlap", "auv_episode_log", "auv_health", "auv_effective_step_mode",
                     "auv_step_dynamics", "auv_lidar", "auv_nav_reward", "auv_read", "auv_write",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",

@@ -115,6 +115,7 @@ class BatchedAuvEnv:
         self.k_max = max(1, int(bank["k_max"]))
         self.m_max = max(1, int(bank["m_max"]))
         self._graph_actions = None
+        self._log_first = 0
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -375,6 +376,7 @@ class BatchedAuvEnv:
                                         C.c_void_p(draws.data_ptr()), nd, unit.ctypes.data_as(C.c_void_p),
                                         nseg.ctypes.data_as(C.c_void_p), len(nseg)), "auv_generate_worlds")
         self._gen = spec
+        self._log_first = 0
         self.n_worlds = spec.n_worlds
         self.k_max = max(1, spec.n_moving + spec.n_static)
         self.m_max = max(1, spec.n_moving)
@@ -422,6 +424,22 @@ class BatchedAuvEnv:
         _check(_LIB.auv_write(self._h, FIELDS[name], C.c_void_p(t.data_ptr()), nbytes, self._stream()),
                "auv_write(%s)" % name)
         torch.cuda.current_stream(self.device).synchronize()   # `t` may be a temporary
+
+    EPISODE_LOG_COLUMNS = ("env", "reward", "timesteps", "collision", "reached_goal", "progress", "cross_track_error", "world")
+
+    def episode_log(self, max_rows: int = 1 << 20) -> torch.Tensor:
+        """Episodes that ended since the last call (or since the bank was loaded), in completion order: [k, 8] float64 on
+        the device, columns EPISODE_LOG_COLUMNS -- what the reference appends to `env.history` in save_latest_episode
+        (environment.py:466-489), for the whole batch.  One small host synchronisation per call."""
+        total = C.c_int64()
+        first = getattr(self, "_log_first", 0)
+        _check(_LIB.auv_episode_log(self._h, None, 0, first, C.byref(total), self._stream()), "auv_episode_log")
+        k = min(int(total.value) - first, int(max_rows))
+        rows = torch.empty((max(k, 0), 8), dtype=torch.float64, device=self.device)
+        if k > 0:
+            _check(_LIB.auv_episode_log(self._h, C.c_void_p(rows.data_ptr()), k, first, C.byref(total), self._stream()), "auv_episode_log")
+            self._log_first = first + k
+        return rows
 
     def episode_stats(self) -> Dict[str, torch.Tensor]:
         ep = self.read("EPISODE")

@@ -195,6 +195,9 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.limits, n * k_max);
   rc |= dev_alloc(ep, &d.collision, n);
   rc |= dev_alloc(ep, &d.step_info, n * 4);
+  d.ep_log_cap = (int32_t)(4 * n > 65536 ? 4 * n : 65536);
+  rc |= dev_alloc(ep, &d.ep_log, 8 * (size_t)d.ep_log_cap);
+  rc |= dev_alloc(ep, &d.ep_log_count, 4);
   rc |= dev_alloc(ep, &d.pose_cs, n);
   rc |= dev_alloc(ep, &d.pair_word, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
@@ -225,6 +228,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.w_collision, (size_t)W);
   if (rc) return AUV_EHIP;
   }
+  HIP_TRY(hipMemset(d.ep_log_count, 0, sizeof(unsigned int)));   // the episode log restarts with every bank
   // a new bank starts with a plain action buffer (a captured graph, and with it the ring, is gone)
   d.ring_slots = 1;
   d.ring_slot_host = -1;
@@ -767,6 +771,31 @@ int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* b
   for (int i = 0; i < n_slices; i++) {
     HIP_TRY(hipEventSynchronize(h->slice_ev[2 * i + 1]));
     HIP_TRY(hipEventElapsedTime(&out_ms[i], h->slice_ev[2 * i], h->slice_ev[2 * i + 1]));
+  }
+  return AUV_OK;
+}
+
+int auv_episode_log(auv_handle_t* h, double* dst_dev, int64_t max_rows, int64_t first, int64_t* out_total, void* stream) {
+  REQUIRE_READY(h);
+  if (!out_total || (max_rows > 0 && !dst_dev) || max_rows < 0 || first < 0) return fail(AUV_EINVAL, "auv_episode_log: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned int total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, h->d.ep_log_count, sizeof(total), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *out_total = (int64_t)total;
+  const int64_t cap = h->d.ep_log_cap;
+  if (first > (int64_t)total) return fail(AUV_EINVAL, "auv_episode_log: first = %lld beyond the %u episodes logged", (long long)first, total);
+  if ((int64_t)total - first > cap) return fail(AUV_ESTATE, "auv_episode_log: %lld episodes since row %lld, the ring holds %lld -- read more often",
+                                                (long long)((int64_t)total - first), (long long)first, (long long)cap);
+  int64_t nrow = (int64_t)total - first;
+  if (nrow > max_rows) nrow = max_rows;
+  // rows first .. first + nrow of the ring, in at most two pieces
+  int64_t done = 0;
+  while (done < nrow) {
+    const int64_t pos = (first + done) % cap;
+    const int64_t piece = (nrow - done < cap - pos) ? nrow - done : cap - pos;
+    HIP_TRY(hipMemcpyAsync(dst_dev + 8 * done, h->d.ep_log + 8 * pos, (size_t)piece * 64, hipMemcpyDeviceToDevice, st));
+    done += piece;
   }
   return AUV_OK;
 }

@@ -77,6 +77,9 @@ struct AuvDev {
   double* episode;     // [N][4]
   int2* limits;        // [N][Kmax]
   uint8_t* collision;  // [N]
+  double* ep_log;      // [ep_log_cap][8] finished episodes in completion order (reward phase; auv_episode_log)
+  unsigned int* ep_log_count;  // [1] episodes logged so far (the ring position is count % cap)
+  int32_t ep_log_cap;
   double* step_info;   // [N][4] info of the last step (terminal values survive an auto-reset)
   double2* pose_cs;    // [N] cos, sin of the heading K1 has just produced (K1 -> LiDAR within one step only)
   unsigned long long* pair_word; // [N] one-launch step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)

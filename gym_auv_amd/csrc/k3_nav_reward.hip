@@ -491,6 +491,7 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
 struct NavOut {
   double rew_path, reached, goal, progress;
   double u, v, r;                   // the velocities it was computed with (STATE rows 3..5)
+  double cte100;                    // cross-track error / 100 (NAV64 [5])
 };
 
 // WT: the rows are stored write-through (auv_st), for the one-launch step.  `out`: lane 0's NavOut, or nullptr.
@@ -633,12 +634,12 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
         auv_st<WT>(nv2 + 3, make_double2(chi, s_t));
     double2* inf2 = (double2*)inf;
     auv_st<WT>(inf + 1, (double)reached), auv_st<WT>(inf2 + 1, make_double2(goal, progress)), auv_st<WT>(inf + 5, maxp),
-        auv_st<WT>(inf2 + 3, make_double2(s, 0.0));
+        auv_st<WT>(inf + 6, s);                                  // ([7]: the episode's running sum of |cross-track error|, kept by the reward phase)
     // path-following term of the reward: everything it needs is at hand here, so the
     // transcendentals stay out of the reward phase
     const double rew_path = reward_path_term_cos(d, u, v, cos_he, cte100, progress, maxp);
     auv_st<WT>(d.rew_path + e, rew_path);
-    if (out) out->rew_path = rew_path, out->reached = reached, out->goal = goal, out->progress = progress, out->u = u, out->v = v, out->r = r;
+    if (out) out->rew_path = rew_path, out->reached = reached, out->goal = goal, out->progress = progress, out->u = u, out->v = v, out->r = r, out->cte100 = cte100;
     // environment.py:276-280; lane 0 also emits the float32 copies of its own six values.  OBS64 rows
     // start 16-byte aligned when 6 + S is even, float32 rows 8-byte aligned when their stride is even.
     const double c0 = auv_clip(u, -1.0, 1.0), c1 = auv_clip(v, -1.0, 1.0), c2 = auv_clip(r, -1.0, 1.0),
@@ -705,6 +706,7 @@ struct RewardIn {
   double path_reward, closeness_reward;
   double reached, goal, progress;   // INFO64 [1] [2] [3] of this step
   double cum;                       // cumulative reward before this step
+  double cte100, cte_sum;           // NAV64 [5] of this step; INFO64 [7] before it (sum of |cross-track error| so far)
 };
 
 __device__ __forceinline__ int reward_apply(const AuvDev& d, const int e, const int collision, int4& cnt, const RewardIn in,
@@ -738,6 +740,9 @@ __device__ __forceinline__ int reward_apply(const AuvDev& d, const int e, const 
   d.reward64[e] = reward;
   double cum = cum_in + reward;
   inf[4] = cum;
+  // environment.py:345, :460-464 (_save_latest_step): |cross-track error| in metres of every step, for the episode's mean
+  const double cte_sum = in.cte_sum + fabs(in.cte100) * 100;
+  inf[7] = cte_sum;
   const int t_step = cnt.x;
   const int done = collision || (reached_in != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
                    (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);
@@ -752,6 +757,13 @@ __device__ __forceinline__ int reward_apply(const AuvDev& d, const int e, const 
     double2* ep = (double2*)(d.episode + 4 * (size_t)e);
     ep[0] = make_double2(cum, t_step + 1), ep[1] = make_double2(collision, reached_in);
     cnt.z += 1;
+    // episode log (environment.py:466-489 save_latest_episode: what the reference appends to env.history), a ring of
+    // 64-byte records filled in completion order: env, return, timesteps, collision, reached_goal, progress,
+    // mean |cross-track error|, world
+    const unsigned int slot = atomicAdd(d.ep_log_count, 1u);
+    double2* row = (double2*)(d.ep_log + 8 * (size_t)(slot % (unsigned int)d.ep_log_cap));
+    row[0] = make_double2((double)e, cum), row[1] = make_double2(t_step + 1, collision), row[2] = make_double2(reached_in, progress_in);
+    row[3] = make_double2(cte_sum / (double)(t_step + 1), (double)d.world_idx[e]);
   }
   const int do_reset = done && d.cfg.auto_reset;
   if (!do_reset) d.counters[e] = cnt;
@@ -778,6 +790,7 @@ __device__ __forceinline__ int reward_block(const AuvDev& d, const int e, const 
   const double rew_path_in = d.rew_path[e], rew_lidar_in = rew_lidar_pre ? *rew_lidar_pre : d.rew_lidar[e];
   const double2 gp = ((const double2*)inf)[1];
   in.cum = inf[4], in.reached = inf[1], in.goal = gp.x, in.progress = gp.y;
+  in.cte100 = nv[5], in.cte_sum = inf[7];
   in.path_reward = rew_path_in, in.closeness_reward = rew_lidar_in;
   if (!collision) {
     if (from_buffers) in.path_reward = reward_path_term(d, in.u, in.v, nv[4], nv[5], inf[3], inf[5]);

@@ -74,7 +74,7 @@ __device__ __forceinline__ void pair_publish_lidar(const AuvDev& d, const int e,
 // what the navigation wave requests before it starts working (one trip, hidden behind the search)
 struct PairPre {
   unsigned long long word;
-  double cum;
+  double cum, cte_sum;
   int4 cnt;
   int w;
 };
@@ -83,6 +83,7 @@ __device__ __forceinline__ PairPre pair_prefetch(const AuvDev& d, const int e) {
   p.word = __hip_atomic_load(d.pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // (written by earlier launches: the dynamics kernel and the previous step's reward phase)
   p.cum = d.info64[8 * (size_t)e + 4];
+  p.cte_sum = d.info64[8 * (size_t)e + 7];
   p.cnt = d.counters[e];
   p.w = d.world_idx[e];
   return p;
@@ -121,6 +122,7 @@ __device__ __forceinline__ void pair_finish_nav(const AuvDev& dk, const int e, c
     in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
     in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
     in.cum = p.cum;
+    in.cte100 = no.cte100, in.cte_sum = p.cte_sum;
     d.info64[8 * (size_t)e] = collision;
     do_reset = reward_apply(d, e, collision, cnt, in, reward_out, done_out, false);
   }
@@ -379,7 +381,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     PairPre pp = pair_prefetch(d, e);
     pp.cnt = pre.cnt;
     NavOut no;
-    no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = 0.0;
+    no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = no.cte100 = 0.0;
     if (AUV_RUN_N(d, 1)) k3_nav_env(d, e, lane, smem, obs_out, &pre, nullptr, &no);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();

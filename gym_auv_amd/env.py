@@ -114,17 +114,19 @@ class _ObstacleView:
 
 
 class _RewarderView:
-    """`env.rewarder.params` (objects/rewarder.py:30-53, :143-159): the constants the reward kernel applies."""
+    """`env.rewarder.params`: the dicts of the reference's rewarders, key for key (objects/rewarder.py:56-70 PathFollowRewarder,
+    :143-159 ColavRewarder).  The reward kernels apply these constants (csrc/k3_nav_reward.hip: reward_apply,
+    reward_path_term; csrc/k2_lidar.hip: k2_back) -- and, like the reference's calculate(), a few literals that are
+    not in the dict (PathFollow: slow-speed threshold 0.1 and penalty -2, max_speed 2, rewarder.py:78-140)."""
 
     def __init__(self, kind: str):
-        self.params = {"cruise_speed": 0.1, "neutral_speed": 0.05, "negative_multiplier": 2.0, "collision": -10000.0,
-                       "lambda": 0.5, "eta": 0}
+        self.params = {"gamma_theta": 10.0, "gamma_x": 0.1, "gamma_v_y": 1.0, "gamma_y_e": 5.0, "penalty_yawrate": 10.0,
+                       "penalty_torque_change": 0.0}
         if kind == "colav":
-            self.params.update({"gamma_theta": 10.0, "gamma_x": 0.1, "gamma_v_y": 1.0, "gamma_y_e": 5.0, "penalty_yawrate": 10.0,
-                                "penalty_torque_change": 0.0, "penalty_slow": -2, "slow_speed": 0.04})
+            self.params.update({"penalty_slow": -2, "cruise_speed": 0.1, "slow_speed": 0.04})
         else:
-            self.params.update({"gamma_y_e": 5.0, "penalty_yawrate": 10.0, "penalty_torque_change": 0.0, "penalty_slow": -2,
-                                "slow_speed": 0.1, "max_speed": 2.0})
+            self.params.update({"cruise_speed": 0.1})
+        self.params.update({"neutral_speed": 0.05, "negative_multiplier": 2.0, "collision": -10000.0, "lambda": 0.5, "eta": 0})
 
 
 class AuvEnv:

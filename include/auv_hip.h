@@ -120,7 +120,8 @@ enum {
   AUV_FIELD_OBS64 = 2,       /* [N][6+S] observation before the float32 cast               */
   AUV_FIELD_REWARD64 = 3,    /* [N]                                                        */
   AUV_FIELD_INFO64 = 4,      /* [N][8] collision, reached_goal, goal_distance, progress,
-                                 cumulative_reward, max_progress, vessel_arclength, spare   */
+                                 cumulative_reward, max_progress, vessel_arclength, sum of |cross-track
+                                 error| [m] over the steps of the episode so far               */
   AUV_FIELD_WORLD_IDX = 5,   /* [N] int32                                                  */
   AUV_FIELD_COUNTERS = 6,    /* [N][4] int32: t_step, vessel step_counter, episodes, pad   */
   AUV_FIELD_MOVER_STATE = 7, /* [N][Mmax][4] pos_x, pos_y, heading, counter                */
@@ -183,6 +184,15 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
 int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams,
                              const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
                              uint8_t* done_dev, float* out_ms);
+
+/* Episode log: what the reference appends to env.history when an episode ends (save_latest_episode,
+ * environment.py:466-489), for all environments of the batch, in completion order.  Row = 8 doubles: environment,
+ * return (cumulative reward), timesteps, collision, reached_goal, progress, mean |cross-track error| in metres over the
+ * episode's steps (_save_latest_step, environment.py:460-464), world index.  Copies rows [first, first + max_rows) of
+ * the log (as far as they exist) to dst_dev on `stream` and returns the number of episodes logged so far in
+ * *out_total (this read synchronises `stream`).  The device keeps the last max(65536, 4 N) rows; asking for older
+ * ones fails with AUV_ESTATE.  The log restarts (count 0) whenever a bank is loaded or generated.                 */
+int auv_episode_log(auv_handle_t* h, double* dst_dev, int64_t max_rows, int64_t first, int64_t* out_total, void* stream);
 
 /* Do kernels on these two streams run side by side?  HIP multiplexes streams onto a few hardware queues (four by
  * default); two streams that land on the same one run their kernels one after the other, and sub-batch chains on them

@@ -448,8 +448,7 @@ static void navigate(oracle_t* o, int e, double nav[6]) {
   inf[2] = goal;
   inf[3] = progress;
   inf[5] = maxp;
-  inf[6] = s;
-  inf[7] = 0.0;
+  inf[6] = s;   /* (inf[7]: running sum of |cross-track error| of the episode, kept by finish_step) */
   double* nv = o->nav64 + 8 * (size_t)e;
   for (int i = 0; i < 6; i++) nv[i] = nav[i];
   nv[6] = chi;
@@ -631,6 +630,9 @@ static void finish_step(oracle_t* o, int e, uint8_t* done_out) {
   double reward = reward_calc(o, e);
   o->reward64[e] = reward;
   inf[4] += reward; /* cumulative_reward */
+  /* environment.py:345, :460-464 `_save_latest_step`: abs(cross_track_error) * 100 of every step is kept for the
+   * episode's mean (save_latest_episode, :466-489); here as a running sum */
+  inf[7] += fabs(o->nav64[8 * (size_t)e + 5]) * 100;
   int t_step = o->counters[4 * e];
   int done = o->collision[e] || (inf[1] != 0.0) || (t_step >= c->max_timesteps - 1 && !c->test_mode) ||
              (inf[4] < c->min_cumulative_reward && !c->test_mode); /* environment.py:375-384 */
