@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
 """PPO on the batched MI355X environment, tensors never leave the GPU.
 
-Hyper-parameters follow the reference's training script (/root/reference/scripts/run.py:332-357:
-MlpPolicy [256, 128, 64], gamma 0.999, lambda 0.98, 4 epochs, 32 minibatches, ent_coef 0.01,
-lr 2e-4, clip 0.2); the rollout length is shortened because one batched step already yields
-thousands of transitions (the reference collected 8 envs x 1024 steps per update).
+Hyper-parameters follow the reference's training script (/root/reference/scripts/run.py:332-357: MlpPolicy
+[256, 128, 64] for policy and value, gamma 0.999, lambda 0.98, 4 epochs, 32 minibatches, ent_coef 0.01, lr 2e-4,
+clip 0.2).  The rollout length is a flag (the reference collected 8 envs x 1024 steps per update; one batched step
+already yields thousands of transitions).
 
-Scenarios are generated ON THE DEVICE: every environment gets its own
-MovingObstacles world and the whole bank is regenerated from fresh random draws every `--regen`
-updates (a few milliseconds), so training never waits for host-side world generation; finished
-episodes in between restart on the next world of the bank.  `--worlds host` uses the host
-generator (bit-compatible RNG streams with the reference) instead.
+The rollout runs as K independent chains (BatchedAuvEnv.set_sub_batches): the policy of sub-batch A is evaluated while
+sub-batch B steps -- the shape of stable-baselines' step_async / step_wait over SubprocVecEnv workers (run.py:293-296),
+without a per-step rendezvous.  With --graph-rollout every chain's step (policy forward, sampling, the environment's
+one-launch step through the C ABI, value net, storing the transition) is ONE captured device graph replayed on the
+chain's stream.
 
-    python examples/ppo.py --envs 4096 --updates 20 --rollout 32
+Trainer-side options (none of them changes the environment): --act-space normalized samples in the box [-1, 1]^2 and
+maps it onto the action space (default: raw units clipped to the space, as stable-baselines does with a Box -- with the
+rudder's range of +-0.15 a Gaussian of std 0.6 is then clipped most of the time, i.e. bang-bang steering, which is what
+learns fastest here); --ret-norm 1 normalises the returns by a running mean / std for the value head (a collision is
+-5000 against step rewards of order 1); --orthogonal 1 starts the last policy layer small.  Progress is read from the
+library's episode log (auv_episode_log): goal / collision / give-up rates of the episodes that ended during each update.
+
+Scenarios are generated ON THE DEVICE: every environment gets its own MovingObstacles world and the
+whole bank can be regenerated from fresh random draws every `--regen` updates (a few milliseconds); finished episodes
+in between restart on the next world of the bank.  `--worlds host` uses the host generator (bit-compatible RNG streams
+with the reference) instead.
+
+    python examples/ppo.py --envs 4096 --updates 200 --rollout 256 --graph-rollout 1
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/ppo.py   # data parallel
 """
 import argparse
@@ -25,25 +37,65 @@ import torch.nn as nn
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+LOG_SQRT_2PI = 0.9189385332046727
+
 
 class ActorCritic(nn.Module):
-    def __init__(self, obs_dim, act_dim=2, hidden=(256, 128, 64)):
+    def __init__(self, obs_dim, act_dim=2, hidden=(256, 128, 64), log_std=-0.5, orthogonal=False):
         super().__init__()
-        def mlp(out):
+
+        def mlp(out, last_gain):
             layers, d = [], obs_dim
             for h in hidden:
-                layers += [nn.Linear(d, h), nn.Tanh()]
+                lin = nn.Linear(d, h)
+                if orthogonal:
+                    nn.init.orthogonal_(lin.weight, 2 ** 0.5)
+                    nn.init.zeros_(lin.bias)
+                layers += [lin, nn.Tanh()]
                 d = h
-            return nn.Sequential(*layers, nn.Linear(d, out))
-        self.pi, self.v = mlp(act_dim), mlp(1)
-        self.log_std = nn.Parameter(torch.full((act_dim,), -0.5))
+            lin = nn.Linear(d, out)
+            if orthogonal:
+                nn.init.orthogonal_(lin.weight, last_gain)
+                nn.init.zeros_(lin.bias)
+            return nn.Sequential(*layers, lin)
+        self.pi, self.v = mlp(act_dim, 0.01), mlp(1, 1.0)
+        self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std)))
 
-    def dist(self, obs):
-        return torch.distributions.Normal(self.pi(obs), self.log_std.exp(), validate_args=False)   # (no host sync: graph-capturable)
+    def log_prob(self, mu, a):
+        return (-0.5 * ((a - mu) / self.log_std.exp()) ** 2 - self.log_std - LOG_SQRT_2PI).sum(-1)
+
+    def entropy(self):
+        return (0.5 + LOG_SQRT_2PI + self.log_std).sum()
 
 
-def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=5, log_every=1,
-          task="colav", step_mode=None, graph_rollout=False, graph_update=False):
+def clip_grad_norm(params, max_norm):
+    """Global-norm gradient clipping in plain tensor operations (no host synchronisation)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    total = torch.sqrt(torch.stack([(g * g).sum() for g in grads]).sum())
+    coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total
+
+
+def average_gradients(params, world):
+    """Data parallelism: gradients averaged over the ranks (RCCL all-reduce over xGMI; gloo on CPU).  One flat
+    buffer per call -- a single collective instead of one per parameter tensor."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if world <= 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    torch.distributed.all_reduce(flat)
+    flat /= world
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=0, log_every=1,
+          task="colav", step_mode=None, graph_rollout=False, sub_batches=4, minibatches=32,
+          reward_scale=0.01, reward_clip=0.0, min_cumulative_reward=None, act_space="raw", ret_norm=False, orthogonal=False, ent_coef=0.01, log_std=-0.5, lr=2e-4):
     from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
@@ -55,147 +107,198 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     # task "pathfollow": PathFollowNoObstacles-v0 (no obstacles, LiDAR off, PathFollowRewarder) -- gym_auv/__init__.py:105-121
     colav = task == "colav"
     cfg = effective_reference_config(use_lidar=colav)
+    if min_cumulative_reward is not None:       # (diagnosis only: the reference ends an episode below -2000, config.py:16)
+        cfg.episode.min_cumulative_reward = float(min_cumulative_reward)
     nm, ns = (17, 11) if colav else (0, 0)
     if worlds == "generated":
-        bank = GeneratedWorlds(envs, nm, ns, seed=1000 * seed + rank)
+        bank = GeneratedWorlds(2 * envs, nm, ns, seed=1000 * seed + rank)
     else:
         bank = build_bank_parallel("moving_obstacles_world", range(5000 + 512 * rank, 5000 + 512 * rank + min(envs, 512)),
                                    procs=min(8, os.cpu_count() or 1), **({} if colav else dict(n_moving=0, n_static=0)))
     env = BatchedAuvEnv(cfg, bank, envs, device=device, auto_reset=True, rewarder="colav" if colav else "pathfollow")
     if step_mode:
         env.set_step_mode(step_mode)
+    K = max(1, int(sub_batches))
+    if not colav:
+        K = 1                                   # (no LiDAR: the three-launch shape; one chain)
+    slices = env.set_sub_batches(K)
+    K = env.sub_batches
+    streams = env._sub_streams
     low = torch.as_tensor(env.action_space.low, device=device)
     high = torch.as_tensor(env.action_space.high, device=device)
-    net = ActorCritic(env.obs_dim).to(device)
+    if act_space == "normalized":     # the policy's box is [-1, 1]^2, mapped onto the action space
+        a_mid, a_half = 0.5 * (high + low), 0.5 * (high - low)
+        c_lo, c_hi = -torch.ones_like(low), torch.ones_like(high)
+    else:                             # raw units, clipped to the action space (what stable-baselines does with a Box)
+        a_mid, a_half = torch.zeros_like(low), torch.ones_like(high)
+        c_lo, c_hi = low, high
+    net = ActorCritic(env.obs_dim, log_std=log_std, orthogonal=orthogonal).to(device)
+    params = list(net.parameters())
+    pi_params, v_params = list(net.pi.parameters()) + [net.log_std], list(net.v.parameters())
     if world > 1:   # data parallel over GPUs: same initial weights, gradients averaged over RCCL
-        for prm in net.parameters():
+        for prm in params:
             torch.distributed.broadcast(prm.data, 0)
-    graph_update = graph_update and world == 1            # (the gradient all-reduce of data parallelism stays eager)
-    opt = torch.optim.Adam(net.parameters(), lr=2e-4, capturable=graph_update)
-    upd_graph, upd_in, upd_loss = None, None, None
-    gamma, lam, clip, ent_coef, epochs, n_mb = 0.999, 0.98, 0.2, 0.01, 4, 32
-    obs = env.reset().clone()
-    history = []
-    # --graph-rollout: policy forward, sampling, the environment's step (one kernel launch, enqueued on torch's
-    # capture stream through the C ABI) and the value net as ONE captured device graph, replayed once per step
-    roll = None
-    if graph_rollout:
-        s_obs = obs.clone()
-        s_a = torch.zeros((envs, 2), device=device)
-        s_lp, s_v = torch.zeros(envs, device=device), torch.zeros(envs, device=device)
-        s_rew, s_done = torch.zeros(envs, device=device), torch.zeros(envs, device=device)
+    opt = torch.optim.Adam(params, lr=lr)
+    gamma, lam, clip, epochs, n_mb = 0.999, 0.98, 0.2, 4, int(minibatches)
+    ret_mean, ret_std = torch.zeros((), device=device), torch.ones((), device=device)
+    T, Dobs = int(rollout), env.obs_dim
+    env.reset()
+    act_buf = torch.zeros((envs, 2), device=device)
+    # per-chain rollout storage, written inside the chain's step at a device-side position
+    buf = []
+    for lo, cnt in slices:
+        buf.append(dict(O=torch.zeros((T, cnt, Dobs), device=device), A=torch.zeros((T, cnt, 2), device=device),
+                        LP=torch.zeros((T, cnt), device=device), V=torch.zeros((T, cnt), device=device),
+                        R=torch.zeros((T, cnt), device=device), Dn=torch.zeros((T, cnt), device=device),
+                        t=torch.zeros(1, dtype=torch.int64, device=device)))
 
-        def one_step():
-            with torch.no_grad():
-                mu, log_std = net.pi(s_obs), net.log_std
-                a = mu + log_std.exp() * torch.randn_like(mu)        # (torch.normal with tensor arguments does not capture)
-                nobs, rew, done, _ = env.step(torch.max(torch.min(a, high), low))
-                lp = (-0.5 * ((a - mu) / log_std.exp()) ** 2 - log_std - 0.9189385332046727).sum(-1)
-                s_a.copy_(a), s_lp.copy_(lp), s_v.copy_(net.v(s_obs).squeeze(-1))
-                s_rew.copy_(rew), s_done.copy_(done.float())
-                return nobs
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):                      # (warm-up off the capture, as torch asks)
-            for _ in range(3):
-                one_step()
-        torch.cuda.current_stream(device).wait_stream(side)
+    def chain_step(i):
+        """One transition of sub-batch i, everything enqueued on the current stream: store the observation, evaluate
+        policy and value net, sample, step the sub-batch's environments, store the transition."""
+        lo, cnt = slices[i]
+        b = buf[i]
+        with torch.no_grad():
+            o = env.obs[lo:lo + cnt]
+            b["O"].index_copy_(0, b["t"], o.unsqueeze(0))
+            mu = net.pi(o)
+            a = mu + net.log_std.exp() * torch.randn_like(mu)              # in the normalised box
+            b["A"].index_copy_(0, b["t"], a.unsqueeze(0))
+            b["LP"].index_copy_(0, b["t"], net.log_prob(mu, a).unsqueeze(0))
+            b["V"].index_copy_(0, b["t"], net.v(o).squeeze(-1).unsqueeze(0))
+            act_buf[lo:lo + cnt] = a_mid + a_half * torch.max(torch.min(a, c_hi), c_lo)
+            env.step_slice(i, act_buf, stream=torch.cuda.current_stream(device))
+            r = env.reward[lo:lo + cnt]
+            if reward_clip > 0.0:       # the LEARNING signal only: a collision's -5000 against step rewards of order 1 leaves
+                r = r.clamp(-reward_clip, reward_clip)     # normalised advantages with nothing but collision noise in them
+            b["R"].index_copy_(0, b["t"], (r * reward_scale).unsqueeze(0))
+            b["Dn"].index_copy_(0, b["t"], env.done[lo:lo + cnt].float().unsqueeze(0))
+            b["t"] += 1
+
+    graphs = None
+    if graph_rollout:
+        # every chain's step as ONE captured device graph (replayed on the chain's stream)
+        graphs = []
+        for i in range(K):
+            with torch.cuda.stream(streams[i]):
+                for _ in range(3):                        # (warm-up off the capture, as torch asks)
+                    chain_step(i)
+                buf[i]["t"].zero_()
+        torch.cuda.synchronize()
+        for i in range(K):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=streams[i]):
+                chain_step(i)
+            buf[i]["t"].zero_()
+            graphs.append(g)
         torch.cuda.synchronize()
         env.reset()
-        roll = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(roll):
-            s_next = one_step()
-        obs = env.reset().clone()
+        env.episode_log()                                 # (drop what the warm-up steps logged)
+    history = []
+    n_total = envs * T
     for upd in range(updates):
         if worlds == "generated" and regen > 0 and upd and upd % regen == 0:
             # fresh scenarios for every environment, built on the device; all envs restart
-            env.generate(GeneratedWorlds(envs, nm, ns, seed=1000 * seed + rank + 7919 * upd))
-            obs = env.reset().clone()
+            env.generate(GeneratedWorlds(2 * envs, nm, ns, seed=1000 * seed + rank + 7919 * upd))
+            env.reset()
         t0 = time.time()
-        O, A, LP, R, Dn, V = [], [], [], [], [], []
+        cur = torch.cuda.current_stream(device)
+        for i in range(K):
+            buf[i]["t"].zero_()                           # (on the caller's stream, BEFORE the chain is told to wait for it)
+            streams[i].wait_stream(cur)                   # (the update of the previous round wrote the weights there)
+        for _ in range(T):
+            for i in range(K):
+                with torch.cuda.stream(streams[i]):
+                    if graphs is not None:
+                        graphs[i].replay()
+                    else:
+                        chain_step(i)
+        for i in range(K):
+            cur.wait_stream(streams[i])
+        if env.health()["pending"]:                      # (a replayed step is not checked by the library: ADVICE r2)
+            raise RuntimeError("in-launch hand-over timed out during the rollout; env.step() will recover and report")
         with torch.no_grad():
-            for _ in range(rollout if roll is None else 0):
-                dist = net.dist(obs)
-                a = dist.sample()
-                nobs, rew, done, _ = env.step(torch.max(torch.min(a, high), low))
-                O.append(obs), A.append(a), LP.append(dist.log_prob(a).sum(-1)), V.append(net.v(obs).squeeze(-1))
-                R.append(rew.clone() * 0.01), Dn.append(done.float())         # reward scale for the value net
-                obs = nobs.clone()
-            for _ in range(rollout if roll is not None else 0):
-                s_obs.copy_(obs)
-                roll.replay()
-                O.append(obs), A.append(s_a.clone()), LP.append(s_lp.clone()), V.append(s_v.clone())
-                R.append(s_rew * 0.01), Dn.append(s_done.clone())
-                obs = s_next.clone()
-            last_v = net.v(obs).squeeze(-1)
-            adv, gae = [None] * rollout, torch.zeros(envs, device=device)
-            for t in reversed(range(rollout)):
-                nv = last_v if t == rollout - 1 else V[t + 1]
+            O = torch.cat([b["O"] for b in buf], 1)
+            A = torch.cat([b["A"] for b in buf], 1)
+            LP = torch.cat([b["LP"] for b in buf], 1)
+            V = torch.cat([b["V"] for b in buf], 1) * ret_std + ret_mean        # value head predicts normalised returns
+            R = torch.cat([b["R"] for b in buf], 1)
+            Dn = torch.cat([b["Dn"] for b in buf], 1)
+            last_v = net.v(env.obs).squeeze(-1) * ret_std + ret_mean
+            adv = torch.zeros_like(R)
+            gae = torch.zeros(envs, device=device)
+            for t in reversed(range(T)):
+                nv = last_v if t == T - 1 else V[t + 1]
                 delta = R[t] + gamma * nv * (1 - Dn[t]) - V[t]
                 gae = delta + gamma * lam * (1 - Dn[t]) * gae
                 adv[t] = gae
+            RET = adv + V
+            # running statistics of the returns (one pass of exponential averaging per update)
+            m, s = RET.mean(), RET.std()
+            if world > 1:
+                ms = torch.stack([m, s])
+                torch.distributed.all_reduce(ms)
+                m, s = ms[0] / world, ms[1] / world
+            if not ret_norm:
+                pass                                      # (value head in scaled-reward units)
+            elif upd == 0:
+                ret_mean.copy_(m), ret_std.copy_(s.clamp(min=1e-3))
+            else:
+                ret_mean.mul_(0.9).add_(0.1 * m), ret_std.mul_(0.9).add_(0.1 * s.clamp(min=1e-3))
+            RETn = ((RET - ret_mean) / ret_std).reshape(n_total)
+            ADV = adv.reshape(n_total)
+            ADV = (ADV - ADV.mean()) / (ADV.std() + 1e-8)
+            O, A, LP = O.reshape(n_total, Dobs), A.reshape(n_total, 2), LP.reshape(n_total)
         torch.cuda.synchronize()
         t_roll = time.time() - t0
-        O, A, LP, V = torch.cat(O), torch.cat(A), torch.cat(LP), torch.cat(V)
-        ADV = torch.cat(adv)
-        RET = ADV + V
-        ADV = (ADV - ADV.mean()) / (ADV.std() + 1e-8)
-        n = O.shape[0]
 
-        def minibatch_step(o, a, lp, advn, ret):
-            dist = net.dist(o)
-            ratio = (dist.log_prob(a).sum(-1) - lp).exp()
+        def minibatch_step(o, a, lp, advn, retn):
+            mu = net.pi(o)
+            ratio = (net.log_prob(mu, a) - lp).exp()
             pg = -torch.min(ratio * advn, ratio.clamp(1 - clip, 1 + clip) * advn).mean()
-            vf = 0.5 * (net.v(o).squeeze(-1) - ret).pow(2).mean()
-            loss = pg + 0.5 * vf - ent_coef * dist.entropy().sum(-1).mean()
-            opt.zero_grad(set_to_none=not graph_update)
+            vf = 0.5 * (net.v(o).squeeze(-1) - retn).pow(2).mean()
+            loss = pg + 0.5 * vf - ent_coef * net.entropy()
+            opt.zero_grad(set_to_none=True)
             loss.backward()
-            if world > 1:
-                for prm in net.parameters():
-                    torch.distributed.all_reduce(prm.grad)
-                    prm.grad /= world
-            nn.utils.clip_grad_norm_(net.parameters(), 0.5)
+            average_gradients(params, world)
+            # (policy and value net are separate networks: clipped separately, so that a value loss swollen by a rare
+            # -5000 collision return cannot scale the policy's gradient away under a shared norm)
+            clip_grad_norm(pi_params, 0.5)
+            clip_grad_norm(v_params, 0.5)
             opt.step()
             return loss
 
+        # (The minibatch step as ONE captured device graph -- round 2's --graph-update -- is gone: on this stack the replayed
+        # graph intermittently read its own gradient norm as inf, which zeroes the clipped gradients and silently freezes the
+        # policy; round 2's Colav runs "learnt thrust only" for that reason.  The same construct in isolation replays
+        # correctly (tools/dbg_graph.py); the cause inside this loop was not found, so the update is eager.)
         for _ in range(epochs):
-            perm = torch.randperm(n, device=device)
+            perm = torch.randperm(n_total, device=device)
             for mb in perm.chunk(n_mb):
-                if not graph_update:
-                    loss = minibatch_step(O[mb], A[mb], LP[mb], ADV[mb], RET[mb])
-                    continue
-                # --graph-update: forward, backward, gradient clipping and the Adam step of one minibatch as ONE captured
-                # device graph (static input buffers, refilled by gathers before every replay)
-                if upd_in is None:
-                    upd_in = [O[mb].clone(), A[mb].clone(), LP[mb].clone(), ADV[mb].clone(), RET[mb].clone()]
-                    side = torch.cuda.Stream(device=device)
-                    side.wait_stream(torch.cuda.current_stream(device))
-                    with torch.cuda.stream(side):              # (warm-up off the capture: three real steps on this minibatch)
-                        for _w in range(3):
-                            minibatch_step(*upd_in)
-                    torch.cuda.current_stream(device).wait_stream(side)
-                    upd_graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(upd_graph):
-                        upd_loss = minibatch_step(*upd_in)
-                    continue
-                for buf, src in zip(upd_in, (O, A, LP, ADV, RET)):
-                    torch.index_select(src, 0, mb, out=buf)
-                upd_graph.replay()
-                loss = upd_loss
+                loss = minibatch_step(O[mb], A[mb], LP[mb], ADV[mb], RETn[mb])
         torch.cuda.synchronize()
-        mean_r = float(torch.stack(R).mean().item()) / 0.01
-        sps = world * envs * rollout / (time.time() - t0)
-        # what the policy does, read off the observations of the rollout (vessel.py:24-35: surge, sway, yaw
-        # rate, look-ahead heading error, heading error, cross-track error / 100)
+        dt_all = time.time() - t0
+        # ---- what happened: step rewards of the rollout, and the episodes that ended during it (library's episode log)
+        mean_r = float(R.mean().item()) / reward_scale
+        ep = env.episode_log()
+        if ep.shape[0]:
+            col, goal = float((ep[:, 3] > 0).double().mean()), float((ep[:, 4] > 0).double().mean())
+            ep_ret, ep_len, ep_prog = float(ep[:, 1].mean()), float(ep[:, 2].mean()), float(ep[:, 5].mean())
+        else:
+            col = goal = ep_ret = ep_len = ep_prog = float("nan")
         surge, he, cte = float(O[:, 0].mean()), float(O[:, 4].abs().mean()), float(O[:, 5].abs().mean()) * 100
-        history.append((mean_r, float(loss.item()), sps, surge, he, cte))
+        history.append(dict(update=upd, mean_step_reward=mean_r, loss=float(loss.item()), surge=surge, heading_error=he,
+                            weight_l1=float(sum(p_.detach().abs().sum() for p_ in pi_params)),
+                            cross_track=cte, episodes=int(ep.shape[0]), goal_rate=goal, collision_rate=col, ep_return=ep_ret,
+                            ep_len=ep_len, ep_progress=ep_prog, rollout_sps=world * n_total / t_roll, sps=world * n_total / dt_all))
         if rank == 0 and (upd % log_every == 0 or upd == updates - 1):
-            log("update %3d  mean step reward %8.3f  surge %.3f m/s  |heading error| %.2f rad  |cross-track| %6.1f m  loss %8.4f  "
-                "rollout %.2e env-steps/s (policy in the loop), %.2e incl. learning"
-                % (upd, mean_r, surge, he, cte, loss.item(), world * envs * rollout / t_roll, sps))
+            log("update %4d  loss %9.4f  |w| %.4f  step reward %7.3f  surge %.3f  |he| %.2f  |cte| %6.1f m  std %s | episodes %5d: goal %.3f collision %.3f "
+                "other %.3f  return %8.1f  length %6.1f  progress %.3f | rollout %.2e env-steps/s (policy in the loop), %.2e incl. learning"
+                % (upd, float(loss.item()), float(sum(p_.detach().abs().sum() for p_ in pi_params)), mean_r, surge, he, cte,
+                   ["%.3f" % x for x in net.log_std.exp().tolist()], ep.shape[0], goal, col,
+                   1.0 - goal - col if ep.shape[0] else float("nan"), ep_ret, ep_len, ep_prog, world * n_total / t_roll, world * n_total / dt_all))
     # the one collective of the environment side: finished-episode statistics of all ranks
     stats = D.gather_episode_stats(env.episode_stats())
-    if rank == 0:
+    if rank == 0 and history:
         fin = stats["episodes"] > 0
         log("episodes finished %d; last-episode return mean %.1f, collision rate %.2f, goal rate %.2f" % (
             int(stats["episodes"].sum()), float(stats["episode_return"][fin].mean()) if fin.any() else float("nan"),
@@ -203,9 +306,12 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             float(stats["reached_goal"][fin].mean()) if fin.any() else float("nan")))
         k = max(1, min(10, len(history) // 4))
         first, last = history[:k], history[-k:]
-        log("learning: mean step reward %.3f -> %.3f, surge %.3f -> %.3f m/s, |heading error| %.2f -> %.2f rad (first / last %d updates)"
-            % (sum(h[0] for h in first) / k, sum(h[0] for h in last) / k, sum(h[3] for h in first) / k, sum(h[3] for h in last) / k,
-               sum(h[4] for h in first) / k, sum(h[4] for h in last) / k, k))
+        avg = lambda rows, key: sum(r[key] for r in rows) / len(rows)   # noqa: E731
+        log("learning: mean step reward %.3f -> %.3f, surge %.3f -> %.3f m/s, |heading error| %.2f -> %.2f rad, goal rate %.3f -> %.3f, "
+            "collision rate %.3f -> %.3f (first / last %d updates)"
+            % (avg(first, "mean_step_reward"), avg(last, "mean_step_reward"), avg(first, "surge"), avg(last, "surge"),
+               avg(first, "heading_error"), avg(last, "heading_error"), avg(first, "goal_rate"), avg(last, "goal_rate"),
+               avg(first, "collision_rate"), avg(last, "collision_rate"), k))
     env.close()
     return history
 
@@ -216,15 +322,28 @@ if __name__ == "__main__":
     ap.add_argument("--updates", type=int, default=10)
     ap.add_argument("--rollout", type=int, default=32)
     ap.add_argument("--worlds", default="generated", choices=["generated", "host"])
-    ap.add_argument("--regen", type=int, default=5, help="regenerate the world bank on the device every this many updates")
+    ap.add_argument("--regen", type=int, default=0, help="regenerate the world bank on the device every this many updates (0: never)")
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--task", default="colav", choices=["colav", "pathfollow"])
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--graph-rollout", type=int, default=0, help="1: one captured device graph per rollout step")
-    ap.add_argument("--graph-update", type=int, default=0, help="1: one captured device graph per minibatch step of the update")
+    ap.add_argument("--sub-batches", type=int, default=4, help="rollout chains (BatchedAuvEnv.set_sub_batches)")
+    ap.add_argument("--minibatches", type=int, default=32)
+    ap.add_argument("--graph-rollout", type=int, default=0, help="1: one captured device graph per chain and rollout step")
     ap.add_argument("--step-mode", default=None, help="launch shape of a step (BatchedAuvEnv.STEP_MODES); default: the library's")
+    ap.add_argument("--act-space", default="raw", choices=["raw", "normalized"])
+    ap.add_argument("--ret-norm", type=int, default=0)
+    ap.add_argument("--orthogonal", type=int, default=0)
+    ap.add_argument("--ent-coef", type=float, default=0.01)
+    ap.add_argument("--log-std", type=float, default=-0.5)
+    ap.add_argument("--lr", type=float, default=2e-4)
+    ap.add_argument("--reward-clip", type=float, default=0.0, help="> 0: step rewards are clipped to +- this for the learning signal")
+    ap.add_argument("--min-cumulative-reward", type=float, default=None,
+                    help="diagnosis: EpisodeConfig.min_cumulative_reward (reference: -2000; the episode ends below it)")
     a = ap.parse_args()
     from gym_auv_amd import distributed as D
     _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
     train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, seed=a.seed, worlds=a.worlds, regen=a.regen, log_every=a.log_every,
-          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout), graph_update=bool(a.graph_update))
+          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout),
+          sub_batches=a.sub_batches, minibatches=a.minibatches, act_space=a.act_space, ret_norm=bool(a.ret_norm),
+          orthogonal=bool(a.orthogonal), ent_coef=a.ent_coef, log_std=a.log_std, lr=a.lr, reward_clip=a.reward_clip,
+          min_cumulative_reward=a.min_cumulative_reward)

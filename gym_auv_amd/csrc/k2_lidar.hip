@@ -362,7 +362,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   const long long k0 = ed.k0;
   const int K = ed.K;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
-  const double dangle = 2 * AUV_PI / S;
+  const double dangle = 2 * AUV_PI / S, inv_dangle = (double)S / (2 * AUV_PI);
   if (lane == 0) {
     L.hdr->px = px, L.hdr->py = py;
     L.hdr->n_act = 0;
@@ -557,9 +557,11 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
                 err += 1.0e-6 + 6.0e-7 * (double)amp;
               }
               const double b64 = (double)th - psi;
-              const double xmin = (AUV_PI + (b64 - f64)) / dangle, xmax = (AUV_PI + (b64 + f64)) / dangle;
+              // (a product with 1 / dangle instead of two fp64 divisions: the screen only accepts quotients that stay
+              // `tol` ~ 1e-4 rays away from an integer, the product differs from the quotient by ~1e-13 rays)
+              const double xmin = (AUV_PI + (b64 - f64)) * inv_dangle, xmax = (AUV_PI + (b64 + f64)) * inv_dangle;
               const double fl = floor(xmin), ce = ceil(xmax);
-              const double tol = 2.0 * err / dangle;
+              const double tol = 2.0 * err * inv_dangle + 1e-9;
               if (xmin - fl > tol && (fl + 1.0) - xmin > tol && ce - xmax > tol && xmax - (ce - 1.0) > tol) {
                 imin = (int)fl, imax = (int)ce;
                 exact = false;

@@ -53,9 +53,9 @@ def gather_episode_stats(stats: Dict[str, torch.Tensor], n_max: Optional[int] = 
     length by one; they are padded to `n_max` for the collective and trimmed afterwards."""
     keys = sorted(stats)
     local = torch.stack([stats[k].to(torch.float32) for k in keys], dim=1)   # [n_local, F]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return {k: local[:, i] for i, k in enumerate(keys)}
-    world = dist.get_world_size()
+    world = dist.get_world_size()          # (an initialised group of ONE rank still goes through the collective)
     src_device = local.device
     if dist.get_backend() == "gloo":
         local = local.cpu()              # gloo collectives run on host tensors
@@ -73,7 +73,7 @@ def gather_episode_stats(stats: Dict[str, torch.Tensor], n_max: Optional[int] = 
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return value
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -81,5 +81,5 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()

@@ -1,7 +1,7 @@
 """-m gpu: the PPO example drives the batched env with device tensors only, with the
 reference's hyper-parameters (scripts/run.py:332-357), and it LEARNS: on PathFollowNoObstacles-v0 the policy
-picks up speed and turns onto the path within a few dozen updates (profiles/r02/ppo_pathfollow_*_seed*.log hold
-120-update runs of three seeds: surge 0.2 -> 0.47 m/s, |heading error| 0.85 -> 0.3 rad)."""
+picks up speed and turns onto the path within a few dozen updates, and the reward TREND is asserted (VERDICT r2
+weak #10: the last updates' mean step reward against the first updates', not merely against update 0)."""
 import math
 import os
 import sys
@@ -11,35 +11,47 @@ import pytest
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
 
+mean = lambda rows, key: sum(r[key] for r in rows) / len(rows)   # noqa: E731
 
-def test_ppo_colav_runs():
+
+def test_ppo_colav_runs_as_chains_with_episode_metrics():
+    """The Colav task with the rollout as four sub-batch chains (eager and as one captured graph per chain and step):
+    finite, the same bookkeeping either way, and the per-update episode metrics come from the library's episode log."""
     import ppo
-    hist = ppo.train(envs=1024, updates=6, rollout=16, log=lambda *_: None)
-    assert len(hist) == 6
-    assert all(math.isfinite(h[0]) and math.isfinite(h[1]) for h in hist)
-    assert hist[-1][0] > hist[0][0] - 1.0        # the mean step reward does not collapse
+    for graphs in (False, True):
+        hist = ppo.train(envs=1024, updates=5, rollout=16, log=lambda *_: None, sub_batches=4, graph_rollout=graphs)
+        assert len(hist) == 5
+        assert all(math.isfinite(h["mean_step_reward"]) and math.isfinite(h["loss"]) for h in hist)
+        assert all(h["rollout_sps"] > 0 and h["episodes"] >= 0 for h in hist)
+        assert hist[-1]["mean_step_reward"] > hist[0]["mean_step_reward"] - 1.0        # the mean step reward does not collapse
 
 
 def test_ppo_learns_path_following():
+    """PathFollowNoObstacles-v0, eager rollouts and updates.  What the curve looks like (profiles/r03/ppo_pathfollow_*.log):
+    the thruster is learnt within ten updates (step reward -1.1 -> -0.25), then the vessels -- started near the path with
+    random headings -- run away from it at speed and the reward DIPS (-0.45 around updates 20-35) until the rudder is learnt
+    (|heading error| 0.86 -> 0.35 rad) and it recovers.  Asserted: speed up, heading error down, reward above the
+    untrained policy's AND recovering from the dip (VERDICT r2 weak #10: a trend, not only "better than update 0")."""
     import ppo
-    hist = ppo.train(envs=2048, updates=60, rollout=32, regen=0, task="pathfollow", log=lambda *_: None)
-    k = 6
-    first, last = hist[:k], hist[-k:]
-    mean = lambda rows, i: sum(r[i] for r in rows) / len(rows)   # noqa: E731
-    assert mean(last, 3) > mean(first, 3) + 0.12, (mean(first, 3), mean(last, 3))     # surge speed: it learnt to use the thruster
-    assert mean(last, 4) < mean(first, 4) - 0.15, (mean(first, 4), mean(last, 4))     # |heading error|: ... and the rudder
-    assert mean(last, 0) > hist[0][0] + 0.3, (hist[0][0], mean(last, 0))              # the step reward against the untrained policy's
+    hist = ppo.train(envs=2048, updates=90, rollout=32, task="pathfollow", log=lambda *_: None)
+    first, dip, last = hist[:3], hist[20:36], hist[-8:]
+    assert mean(last, "surge") > mean(first, "surge") + 0.12, (mean(first, "surge"), mean(last, "surge"))     # it learnt to use the thruster
+    assert mean(last, "heading_error") < mean(first, "heading_error") - 0.3, (mean(first, "heading_error"), mean(last, "heading_error"))   # ... and the rudder
+    assert mean(last, "mean_step_reward") > hist[0]["mean_step_reward"] + 0.5, (hist[0]["mean_step_reward"], mean(last, "mean_step_reward"))
+    assert mean(last, "mean_step_reward") > mean(first, "mean_step_reward") + 0.15, (mean(first, "mean_step_reward"), mean(last, "mean_step_reward"))
+    assert mean(last, "mean_step_reward") > mean(dip, "mean_step_reward") + 0.05, (mean(dip, "mean_step_reward"), mean(last, "mean_step_reward"))
+    w = [h["weight_l1"] for h in hist]
+    assert all(abs(b - a) > 1e-3 for a, b in zip(w[:-1], w[1:]))          # every update moved the policy's weights
 
 
-def test_ppo_rollout_as_one_captured_graph_per_step():
-    """--graph-rollout: policy forward, sampling, the environment's step (ONE kernel launch, enqueued through the C
-    ABI on torch's capture stream) and the value net replayed as one device graph per rollout step.  It runs, stays
-    finite, and the policy still picks up speed on path following."""
+def test_ppo_rollout_as_captured_graphs_learns_and_moves_the_weights():
+    """--graph-rollout: a chain's whole step (policy forward, sampling, the environment's launch through the C ABI on
+    torch's capture stream, value net, storing the transition) as one captured device graph per chain.  The policy learns
+    path following as with eager rollouts, and its weights change with EVERY update (round 2's captured update step froze
+    them silently after the first update and nothing noticed: that path is gone and this is asserted now)."""
     import ppo
-    hist = ppo.train(envs=1024, updates=4, rollout=16, regen=0, log=lambda *_: None, graph_rollout=True)
-    assert len(hist) == 4 and all(math.isfinite(h[0]) and math.isfinite(h[1]) for h in hist)
-    hist = ppo.train(envs=2048, updates=40, rollout=32, regen=0, task="pathfollow", log=lambda *_: None, graph_rollout=True,
-                     graph_update=True)      # (... and forward + backward + clipping + Adam of a minibatch as one graph too)
-    mean = lambda rows, i: sum(r[i] for r in rows) / len(rows)   # noqa: E731
-    assert mean(hist[-5:], 3) > mean(hist[:5], 3) + 0.04, (mean(hist[:5], 3), mean(hist[-5:], 3))    # surge speed
-    assert mean(hist[-5:], 0) > hist[0][0] + 0.3, (hist[0][0], mean(hist[-5:], 0))                    # step reward
+    hist = ppo.train(envs=2048, updates=40, rollout=32, task="pathfollow", log=lambda *_: None, graph_rollout=True)
+    assert mean(hist[-5:], "surge") > mean(hist[:2], "surge") + 0.04, (mean(hist[:2], "surge"), mean(hist[-5:], "surge"))
+    assert mean(hist[-5:], "mean_step_reward") > hist[0]["mean_step_reward"] + 0.3, (hist[0]["mean_step_reward"], mean(hist[-5:], "mean_step_reward"))
+    w = [h["weight_l1"] for h in hist]
+    assert all(abs(b - a) > 1e-3 for a, b in zip(w[:-1], w[1:])), w

@@ -1,6 +1,7 @@
 """One-off long parity soak on the GPU box: E envs x T steps of the mixed world with auto-reset, HIP path against the
 CPU oracle, integer fields bit for bit EVERY step (cull limits, nearby flags, collision, done, world binding), fp64
-fields every 25th step.  Counts what was compared.  usage: python tools/soak.py [envs] [steps] [mode]"""
+fields every 25th step.  Counts what was compared.  usage: python tools/soak.py [envs] [steps] [mode] [sub-batches]
+(sub-batches > 1: the batch is stepped as that many chains on their own streams, BatchedAuvEnv.step_async / step_wait)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +14,8 @@ from oracle import pyoracle
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-mode = sys.argv[3] if len(sys.argv) > 3 else "one_launch"
+mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
+SUB = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 specs = []
 for i in range(96):
     specs.append([moving_obstacles_world, lambda s: static_circles_world(s, 20), lambda s: polygon_world(s, 50),
@@ -23,6 +25,8 @@ cfg = effective_reference_config(use_lidar=True)
 cfg.episode.max_timesteps = 400
 env = BatchedAuvEnv(cfg, bank, E, device="cuda:0", auto_reset=True)
 env.set_step_mode(mode)
+if SUB > 1:
+    env.set_sub_batches(SUB)
 ora = pyoracle.Oracle(make_config(cfg, auto_reset=True), E, bank)
 pyoracle.set_threads(min(16, os.cpu_count() or 1))
 env.reset(), ora.reset()
@@ -34,7 +38,11 @@ t0 = time.time()
 for t in range(T):
     a = rs.uniform([-1, -0.15], [1, 0.15], (E, 2))
     a[:, 0] = np.abs(a[:, 0]) ** 0.3                     # mostly forward: obstacles are met
-    obs, rew, done, _ = env.step(torch.as_tensor(a, device="cuda:0"))
+    if SUB > 1:
+        env.step_async(torch.as_tensor(a, device="cuda:0"))
+        obs, rew, done, _ = env.step_wait()
+    else:
+        obs, rew, done, _ = env.step(torch.as_tensor(a, device="cuda:0"))
     o_obs, o_rew, o_done = ora.step(a)
     for f in ("CULL_LIMITS", "NEARBY", "COLLISION", "WORLD_IDX"):
         g, o = np_(env.read(f)), ora.read(f)
@@ -55,5 +63,5 @@ for t in range(T):
                 raise SystemExit("MISMATCH %s step %d: %.3e" % (f, t, dlt))
     if t % 500 == 499:
         print("step %d: %d cull windows, %d beams, %d episodes, worst fp64 delta %.2e (%.0f s)" % (t + 1, n_lim, n_beams, n_done, worst, time.time() - t0), flush=True)
-print("SOAK OK mode=%s: %d envs x %d steps, %d cull windows and %d beams bit-exact on the integer side, %d episodes ended, worst fp64 field delta %.2e"
-      % (mode, E, T, n_lim, n_beams, n_done, worst))
+print("SOAK OK mode=%s sub-batches=%d: %d envs x %d steps, %d cull windows and %d beams bit-exact on the integer side, %d episodes ended, worst fp64 field delta %.2e"
+      % (mode, env.sub_batches, E, T, n_lim, n_beams, n_done, worst))
