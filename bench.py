@@ -76,6 +76,9 @@ def parse():
                          "own (auv_step_pipelined); the chains overlap on the GPU -- same envs, same results, bit for bit.  "
                          "0 (default): 4 (the four compute pipes of the chip) when the rank has >= 2048 envs and the step "
                          "is launched eagerly from resident actions, else 1")
+    ap.add_argument("--probe-streams", type=int, default=1,
+                    help="0: take any K streams for the sub-batch chains instead of K that were measured to run side by side "
+                         "(for runs under a counter-collecting profiler, which serialises dispatches)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
     ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
@@ -310,7 +313,7 @@ def main():
         act = torch.ones((n_local, 2), dtype=torch.float32, device=dev)
 
         if sub > 1:
-            env.set_sub_batches(sub)
+            env.set_sub_batches(sub, probe_streams=bool(args.probe_streams))
             sub = env.sub_batches
 
         def run(i0, n):
@@ -328,7 +331,7 @@ def main():
                     torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
                     env.step(act)
     elif sub > 1:
-        env.set_sub_batches(sub)
+        env.set_sub_batches(sub, probe_streams=bool(args.probe_streams))
         sub = env.sub_batches          # (fewer if the device does not run that many streams side by side)
 
         def run(i0, n):
@@ -450,7 +453,11 @@ def main():
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
                            parallelism="env-shard x%d (no step-path collective)" % world, ranks=world,
-                           hipgraph_steps=K, sub_batches=sub, step_mode=env.effective_step_mode(max(1, n_local // sub)), actions=args.actions,
+                           hipgraph_steps=K, sub_batches=sub,
+                           # the shape the TIMED loop ran: a captured graph of several steps replays the three-launch shape with
+                           # its fused reward + dynamics launch whatever the handle's mode is (include/auv_hip.h)
+                           step_mode=("side_by_side+k31 (captured, %d steps per graph)" % K) if K > 1 else env.effective_step_mode(max(1, n_local // sub)),
+                           roofline_step_mode=env.effective_step_mode(max(1, n_local // sub)), actions=args.actions,
                            worlds_per_env=wpe, world_gen_s=round(t_gen, 1),
                            episodes_finished=int(stats["episodes"].sum().item())),
                roofline=roofline)

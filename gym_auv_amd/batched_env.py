@@ -177,7 +177,7 @@ class BatchedAuvEnv:
                 chosen.append(c)
         return chosen
 
-    def set_sub_batches(self, k: int):
+    def set_sub_batches(self, k: int, probe_streams: bool = True):
         """Split the batch into `k` contiguous sub-batches, each with a stream of its own.  `step_pipelined` /
         `step_async` then step them as k independent launch chains that overlap on the GPU (one sub-batch's sweeps run
         under another's dynamics chain and navigation tail); results are bit-identical to `step`.  k = 1 restores the
@@ -188,7 +188,12 @@ class BatchedAuvEnv:
             raise ValueError("sub-batches must be in [1, 64]")
         n = self.n_envs
         torch.cuda.synchronize(self.device)
-        streams = self._concurrent_streams(k) if k > 1 else [torch.cuda.Stream(device=self.device)]
+        # (probe_streams = False: any k streams -- under a counter-collecting profiler dispatches are serialised, the
+        # probe would find no two streams side by side and the batch would not be split at all)
+        if k > 1 and probe_streams:
+            streams = self._concurrent_streams(k)
+        else:
+            streams = [torch.cuda.Stream(device=self.device) for _ in range(k)]
         k = min(k, len(streams))
         per = -(-n // k)
         per = -(-per // 64) * 64

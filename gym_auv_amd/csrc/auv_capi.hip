@@ -198,7 +198,6 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   d.ep_log_cap = (int32_t)(4 * n > 65536 ? 4 * n : 65536);
   rc |= dev_alloc(ep, &d.ep_log, 8 * (size_t)d.ep_log_cap);
   rc |= dev_alloc(ep, &d.ep_log_count, 4);
-  rc |= dev_alloc(ep, &d.pose_cs, n);
   rc |= dev_alloc(ep, &d.pair_word, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
   rc |= dev_alloc(ep, &d.k1_done, 4);

@@ -81,7 +81,6 @@ struct AuvDev {
   unsigned int* ep_log_count;  // [1] episodes logged so far (the ring position is count % cap)
   int32_t ep_log_cap;
   double* step_info;   // [N][4] info of the last step (terminal values survive an auto-reset)
-  double2* pose_cs;    // [N] cos, sin of the heading K1 has just produced (K1 -> LiDAR within one step only)
   unsigned long long* pair_word; // [N] one-launch step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
   int32_t* pair_error; // [1] one-launch step: set when a navigation wave gave up waiting for its sweep
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)

@@ -332,12 +332,10 @@ __device__ __forceinline__ K2Pre k2_prefetch(const AuvDev& d, const int e, const
 }
 
 // phases A, C, B, S for one environment, by one wave
-// cs_pre: cos / sin of the heading when the dynamics kernel of this step has left them (pose_cs);
-// nullptr = form them here (same function, same argument: the same bits)
 // movers_done / kp: phase A has been run / the first 64 obstacle records have been fetched by the caller already
 template <bool WT = false>
 __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
-                        const EnvPre* pre = nullptr, const double2* cs_pre = nullptr, const int movers_done = 0,
+                        const EnvPre* pre = nullptr, const int movers_done = 0,
                         const K2Pre* kp = nullptr, const bool beams_staged = false) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
@@ -349,15 +347,9 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   // the ~100 dependent fp64 instructions are off the chain that follows phase B (the obstacle records were also
   // requested ahead of it once: 11 more live registers, 10 spilled, and the gain was gone)
   {
-    double2 cs_in;
-    if (cs_pre) {
-      cs_in = cs_pre[e];
-    } else {
-      double sn, co;
-      sincos(psi, &sn, &co);
-      cs_in = make_double2(co, sn);
-    }
-    if (lane == 0) L.hdr->cpsi = cs_in.x, L.hdr->spsi = cs_in.y;   // (read back after the LDS sync that ends phase B)
+    double sn, co;
+    sincos(psi, &sn, &co);
+    if (lane == 0) L.hdr->cpsi = co, L.hdr->spsi = sn;               // (read back after the LDS sync that ends phase B)
   }
   const long long k0 = ed.k0;
   const int K = ed.K;

@@ -41,29 +41,10 @@ struct MinIdx {
   int j;
 };
 
-__device__ __forceinline__ MinIdx min_first(MinIdx a, MinIdx b) {
-  // strict '<' with ascending traversal == "first minimum wins"; ties -> smaller index
-  if (b.d < a.d || (b.d == a.d && b.j < a.j)) return b;
-  return a;
-}
-
-__device__ __forceinline__ MinIdx wave_min_first(MinIdx v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    MinIdx t;
-    t.d = __shfl_xor(v.d, o, AUV_WAVE);
-    t.j = __shfl_xor(v.j, o, AUV_WAVE);
-    v = min_first(v, t);
-  }
-  return v;
-}
-
 // SciPy PPoly: interval search + power-basis eval.  The knots are near-uniform, so the interval
 // is guessed from s / L and the knots and coefficient rows around the guess are fetched together
 // (one trip to memory); only a guess that is off by more than one interval walks and re-fetches.
-// KnotWin = such a two-interval window: knots [g, g+2] and the coefficient rows g, g+1.  The step's
-// navigation requests it for LAST step's arclength before the vessel has even moved (the vessel
-// advances a fraction of an interval per step), so the evaluation usually needs no trip at all.
+// KnotWin = such a two-interval window: knots [g, g+2] and the coefficient rows g, g+1.
 struct KnotWin {
   double xa, xb, xc;       // knots g, g+1, g+2
   double ca[8], cb[8];     // coefficient rows g, g+1
@@ -100,26 +81,9 @@ __device__ __forceinline__ KnotWin knot_window(const AuvDev& d, long long k0, in
   return w;
 }
 
-// a lane's spline window parked in LDS (20 doubles) while something register-hungry runs
-__device__ __forceinline__ void knot_win_store(const KnotWin& w, double* slot) {
-  slot[0] = w.have ? 1.0 : 0.0, slot[1] = w.xa, slot[2] = w.xb, slot[3] = w.xc;
-#pragma unroll
-  for (int a = 0; a < 8; a++) slot[4 + a] = w.ca[a], slot[12 + a] = w.cb[a];
-}
-__device__ __forceinline__ KnotWin knot_win_load(const double* slot) {
-  KnotWin w;
-  w.have = slot[0] != 0.0, w.xa = slot[1], w.xb = slot[2], w.xc = slot[3];
-#pragma unroll
-  for (int a = 0; a < 8; a++) w.ca[a] = slot[4 + a], w.cb[a] = slot[12 + a];
-  return w;
-}
-
-// x0 / xl: the first / last knot, fetched by the caller ahead of time.  `slot`: a window requested
-// earlier for a nearby arclength and parked in LDS (knot_win_store; used if it contains s, and read
-// row by row so that it never occupies registers as a whole); the coefficient row is the same row
-// whichever way it is reached, so the result does not depend on the window.
+// x0 / xl: the first / last knot, fetched by the caller ahead of time.
 __device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk, double x0, double xl, double s,
-                                          double L, double xy[2], double dxy[2], const double* slot = nullptr) {
+                                          double L, double xy[2], double dxy[2]) {
   const double* x = d.knot_s + k0;
   const double* cf = d.knot_coef + 8 * k0;
   int i;
@@ -131,26 +95,13 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk,
   } else if (s >= xl) {
     i = nk - 2;
   } else {
-    if (slot && slot[0] != 0.0) {
-      const double xa = slot[1], xb = slot[2], xc = slot[3];
-      if (s >= xa && s < xc) {
-        const bool second = s >= xb;
-        xi = second ? xb : xa;
-        const double* row = slot + (second ? 12 : 4);
+    const KnotWin w = knot_window(d, k0, nk, x0, xl, s, L);
+    if (w.have && s >= w.xa && s < w.xc) {
+      const bool second = s >= w.xb;
+      xi = second ? w.xb : w.xa;
 #pragma unroll
-        for (int a = 0; a < 8; a++) c[a] = row[a];
-        have = true;
-      }
-    }
-    if (!have) {
-      const KnotWin w = knot_window(d, k0, nk, x0, xl, s, L);
-      if (w.have && s >= w.xa && s < w.xc) {
-        const bool second = s >= w.xb;
-        xi = second ? w.xb : w.xa;
-#pragma unroll
-        for (int a = 0; a < 8; a++) c[a] = second ? w.cb[a] : w.ca[a];
-        have = true;
-      }
+      for (int a = 0; a < 8; a++) c[a] = second ? w.cb[a] : w.ca[a];
+      have = true;
     }
     if (!have) {
       const double fi = s / L * (nk - 1);
@@ -341,43 +292,30 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
 // ---- navigation part (Vessel.navigate + the six navigation observations) ----------------------
 // Independent of the LiDAR sweep, so the step path runs it concurrently with K2 or right behind K1.
 //
-// The nearest-point search is split in two so that everything that touches memory can be requested
-// BEFORE the vessel's new pose exists (the dynamics + navigation kernel does this while the dynamics
-// are being integrated):
-//   nav_speculate(q, slack)  chunk circles against a pose guess q (the pose before the step), U =
-//                            min (|q - c| + rad), survivors |q - c| - rad <= U + slack listed in
-//                            LDS, and -- if at most NAV_SPEC survive -- their 64 segments each
-//                            fetched into registers; plus the spline windows around last step's
-//                            arclength.
-//   nav_finish(p)            if |p - q| <= NAV_DELTA the survivor list is a superset of the
-//                            survivors of p (every circle distance moves by at most |p - q|, so a
-//                            survivor of p has |q - c| - rad <= U_p + |p - q| <= U_q + 2 |p - q|; the
-//                            slack is 2 NAV_DELTA): the exact distances to the listed segments are
-//                            formed with p, the (distance, first index) minimum over them is the
-//                            brute-force result.  Otherwise (or without a guess) the speculation is
-//                            simply redone for p with zero slack.
-// The winner is the same segment whichever superset it was picked from, so all launch shapes
-// produce the same bits.
+// The nearest-point search in two parts:
+//   nav_bounds(p)   chunk circles against the pose p, U = min over circles of (|p - c| + rad) and over the 64 segments
+//                   of the chunk that held the nearest point LAST step (exact distances: within centimetres of the
+//                   truth), survivors |p - c| - rad <= U listed in LDS, and -- if at most NAV_SPEC survive -- their 64
+//                   segments each fetched into registers;
+//   nav_finish(p)   exact distances to the listed segments, (distance, first index) minimum = the brute-force result
+//                   incl. its tie-break, then the scalar tail.
+// (Round 2's two-kernel shape ran the first part for the pose BEFORE the step while the dynamics integrated and
+// re-validated it afterwards; that shape was measured slower and removed in round 3, and with it the guess logic.)
 constexpr int NAV_CPL = 4;           // chunk circles per lane kept in registers (paths up to 16 k vertices)
 constexpr int NAV_SPEC = 2;          // speculative chunks whose segments are held in registers
-#define NAV_DELTA 1.0                // metres the pose may differ from the guess (a step moves ~0.25 m)
 
 struct NavSpec {
   EnvDesc ed;
   double L, goal_x, goal_y, knot_first, knot_last, maxp_in;
-  double qx, qy;                     // the pose guess the list was made for
   int n_list;                        // surviving chunks listed in LDS (ascending)
   bool in_regs;                      // n_list <= NAV_SPEC: their segments are in A / B / cum below
   double2 A[NAV_SPEC], B[NAV_SPEC];  // this lane's segment of speculative chunk q
   double cum[NAV_SPEC];              // cumulative arclength at its first vertex
-  double dist[NAV_SPEC];             // exact distance of the guess q to that segment where it was already formed (else < 0)
+  double dist[NAV_SPEC];             // exact distance of p to that segment where the bound has formed it already (else < 0)
 };
 
-// win_slots: LDS, [3][20] doubles of this wave, or nullptr: the spline windows around last step's arclength
-// (lane 0 will evaluate at s, lanes 1 and 2 at min(L, s + look-ahead)) are parked there
-__device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, const int lane, int* list, const double qx,
-                                                 const double qy, const double slack, double* win_slots,
-                                                 const EnvDesc* ed_pre = nullptr) {
+__device__ __forceinline__ NavSpec nav_bounds(const AuvDev& d, const int e, const int lane, int* list, const double qx,
+                                              const double qy, const EnvDesc* ed_pre = nullptr) {
   NavSpec sp;
   sp.ed = ed_pre ? *ed_pre : d.env_desc[e];
   const EnvDesc& ed = sp.ed;
@@ -386,7 +324,6 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
   sp.knot_first = d.knot_s[ed.kn0], sp.knot_last = d.knot_s[ed.kn0 + ed.nk - 1];
   const double2 prog = ((const double2*)(d.info64 + 8 * (size_t)e))[3 - 0];   // [6] arclength of last step, [7] spare
   sp.maxp_in = d.info64[8 * (size_t)e + 5];
-  sp.qx = qx, sp.qy = qy;
   const int nch = ed.nch, P = ed.P;
   const double4* cb = d.chunk_bound + ed.c0;
   const double2* xy = d.poly_xy + ed.p0;
@@ -397,7 +334,7 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
   double scum = 0.0, sdist = -1.0;
   if (nch <= NAV_CPL * AUV_WAVE) {
     double4 b[NAV_CPL];
-    float cdist[NAV_CPL], cmarg[NAV_CPL];
+    double cdist[NAV_CPL];
     // hint: the chunk that held the nearest point LAST step (its arclength is in INFO64; the dense polyline
     // is uniform in the spline parameter, so arclength / L locates the segment to within a few).  Its 64
     // segments are requested together with the chunk circles: the exact distance to them bounds the
@@ -417,28 +354,25 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
       const int jj = jhl < P - 1 ? jhl : 0;
       sA = xy[jj], sB = xy[jj + 1], scum = d.poly_cum[ed.p0 + jj];   // kept if this chunk survives
     }
-    // Distances to the chunk circles in fp32 (four fp64 square roots per lane were a third of this phase's
-    // issue cycles): they only PRUNE -- the upper bound stays an upper bound and the survivor list a superset as long
-    // as every comparison is widened by the fp32 error.  |q - c| <= a few km and the float of it is off by < 4e-7
-    // relative (two conversions, two squares, a sum, a square root), so 1e-6 |q - c| + 1e-6 m covers it; the exact
-    // fp64 distances to the survivors' segments decide, and those are the same whichever superset they are picked from.
 #pragma unroll
     for (int i = 0; i < NAV_CPL; i++) {
-      const float dxf = (float)(qx - b[i].x), dyf = (float)(qy - b[i].y);
-      cdist[i] = sqrtf(dxf * dxf + dyf * dyf);
-      cmarg[i] = 1e-6f * cdist[i] + 1e-6f;
-      if (i * AUV_WAVE + lane < nch) U = fmin(U, (double)(cdist[i] + cmarg[i]) + b[i].z);   // from the circles: min of |q - c| + rad
+      const double dx = qx - b[i].x, dy = qy - b[i].y;
+      cdist[i] = sqrt(dx * dx + dy * dy);
+      if (i * AUV_WAVE + lane < nch) U = fmin(U, cdist[i] + b[i].z);   // from the circles: min of |q - c| + rad
     }
+    // (round 3: these four distances in fp32 with widened comparisons -- they only prune -- were measured under the SQ
+    // counters: 325 -> 347 VALU instructions per wave for this phase; the conversions and margins cost what the fp64
+    // square roots do, so the fp64 form stays)
     {
       double dd = 1.7976931348623157e308;
       if (jhl < P - 1) dd = auv_pt_seg_dist(qx, qy, sA.x, sA.y, sB.x, sB.y);
       sdist = dd;
-      U = auv_wave_min(fmin(U, dd)) + slack;
+      U = auv_wave_min(fmin(U, dd));
     }
 #pragma unroll
     for (int i = 0; i < NAV_CPL; i++) {
       const int c = i * AUV_WAVE + lane;
-      const bool act = (c < nch) && ((double)(cdist[i] - cmarg[i]) - b[i].z <= U);
+      const bool act = (c < nch) && (cdist[i] - b[i].z <= U);
       const unsigned long long mask = __ballot(act);
       if (act) list[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = c;
       n_act += __popcll(mask);
@@ -449,7 +383,7 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
       const double dx = qx - b.x, dy = qy - b.y;
       U = fmin(U, sqrt(dx * dx + dy * dy) + b.z);
     }
-    U = auv_wave_min(U) + slack;
+    U = auv_wave_min(U);
     for (int cbase = 0; cbase < nch; cbase += AUV_WAVE) {
       const int c = cbase + lane;
       bool act = false;
@@ -481,14 +415,6 @@ __device__ __forceinline__ NavSpec nav_speculate(const AuvDev& d, const int e, c
       }
     }
   }
-  if (win_slots && lane < 3) {
-    double s_guess = prog.x;
-    if (lane != 0) {
-      s_guess += d.cfg.look_ahead_distance;
-      if (sp.L < s_guess) s_guess = sp.L;
-    }
-    knot_win_store(knot_window(d, ed.kn0, ed.nk, sp.knot_first, sp.knot_last, s_guess, sp.L), win_slots + lane * 20);
-  }
   return sp;
 }
 
@@ -502,8 +428,7 @@ struct NavOut {
 // WT: the rows are stored write-through (auv_st), for the one-launch step.  `out`: lane 0's NavOut, or nullptr.
 template <bool WT = false>
 __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const int lane, int* list,
-                                           float* __restrict__ obs_out, const EnvPre* pre, NavSpec sp, const bool have_spec,
-                                           const double* win_slots, const double2* pose_cs_in, NavOut* out = nullptr) {
+                                           float* __restrict__ obs_out, const EnvPre* pre, const NavSpec sp, NavOut* out = nullptr) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
@@ -511,14 +436,6 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
   const double u = pre ? pre->s[3] : d.state[3 * n + e], v = pre ? pre->s[4] : d.state[4 * n + e],
                r = pre ? pre->s[5] : d.state[5 * n + e];
   AUV_STAMP_DECL
-  // is the guess close enough for its list to cover the survivors of the real pose?
-  bool usable = have_spec;
-  if (usable) {
-    const double mx = px - sp.qx, my = py - sp.qy;
-    usable = (mx * mx + my * my) <= NAV_DELTA * NAV_DELTA;   // (NaN compares false)
-  }
-  if (!usable) sp = nav_speculate(d, e, lane, list, px, py, 0.0, nullptr);   // (parked spline windows stay valid: they do not depend on the pose)
-  const bool same_pose = (px == sp.qx) && (py == sp.qy);
   const EnvDesc ed = sp.ed;
   const double L = sp.L;
   double* inf = d.info64 + 8 * (size_t)e;
@@ -541,18 +458,16 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
   double my_cum = 0.0;
   const int n_act = sp.n_list;
   // cos / sin of the new heading for the reward's cos(heading error) below
-  // (handed in by the dynamics wave of the two-kernel step, which forms them for eight environments at once)
   double sin_psi, cos_psi;
-  if (pose_cs_in) cos_psi = pose_cs_in->x, sin_psi = pose_cs_in->y;
-  else sincos(psi, &sin_psi, &cos_psi);
+  sincos(psi, &sin_psi, &cos_psi);
   if (sp.in_regs) {
 #pragma unroll
     for (int q = 0; q < NAV_SPEC; q++) {
       if (q < n_act) {
         const int j = list[q] * AUV_CHUNK + lane;
         if (j < P - 1) {
-          // (the very same distance was formed for the upper bound when the guess IS the pose)
-          const double dd = (same_pose && sp.dist[q] >= 0.0) ? sp.dist[q]
+          // (the very same distance was formed for the upper bound already)
+          const double dd = (sp.dist[q] >= 0.0) ? sp.dist[q]
                                                              : auv_pt_seg_dist(px, py, sp.A[q].x, sp.A[q].y, sp.B[q].x, sp.B[q].y);
           if (dd < best.d) best.d = dd, best.j = j, bA = sp.A[q], bB = sp.B[q], my_cum = sp.cum[q];   // ascending j: strict '<' keeps the first minimum
         }
@@ -608,8 +523,7 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
   // one atan2 then serves all three angles: lane 0 chi, lane 1 the look-ahead direction, lane 2
   // the heading towards the look-ahead point
   double p[2], dp[2];
-  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, lane == 0 ? s : s_t, L, p, dp,
-            (win_slots && lane < 3) ? win_slots + lane * 20 : nullptr);
+  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, lane == 0 ? s : s_t, L, p, dp);
   // The wave issues the square root and the division below once whatever the number of busy lanes, so the lanes behind
   // the three angle lanes take the tail's other square roots and its quotient along in the same instructions (VERDICT r2
   // #2: the tail is 19 % of the step's VALU issue cycles): lane 3 the distance to the goal, |goal - p|; lane 4 the speed,
@@ -683,25 +597,18 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
   AUV_STAMP_FLUSH(e, 8)   // 8:bounds 9:list 10:scan 11:nav
 }
 
-// the navigation of one environment in one go (no pose guess): the per-kernel API, the reset pass and the
-// launch shapes that run it behind a finished dynamics kernel.  `scratch`: NAV_SCRATCH_BYTES(nch_max) of
-// LDS, 16-byte aligned: three parked spline windows, then the list of surviving chunks.
-#define NAV_WIN_BYTES (3 * 20 * 8)
-#define NAV_SCRATCH_BYTES(nch_max) ((NAV_WIN_BYTES + (size_t)(nch_max) * sizeof(int) + 15) & ~(size_t)15)
+// the navigation of one environment.  `scratch`: NAV_SCRATCH_BYTES(nch_max) of LDS, 16-byte aligned: the list of
+// surviving chunks.
+#define NAV_SCRATCH_BYTES(nch_max) (((size_t)(nch_max) * sizeof(int) + 15) & ~(size_t)15)
 template <bool WT = false>
 __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const int lane, unsigned char* scratch,
-                                           float* __restrict__ obs_out, const EnvPre* pre = nullptr,
-                                           const double2* pose_cs = nullptr, NavOut* out = nullptr) {
-  double* wins = (double*)scratch;
-  int* list = (int*)(scratch + NAV_WIN_BYTES);
+                                           float* __restrict__ obs_out, const EnvPre* pre = nullptr, NavOut* out = nullptr) {
+  int* list = (int*)scratch;
   const size_t n = (size_t)d.n;
-  // (no spline windows ahead of time here: with nothing to overlap them with, requesting them early only
-  // lengthened the search -- measured 8.8 -> 9.9 us per navigation wave in the side-by-side launch)
-  (void)wins;
-  const NavSpec sp = nav_speculate(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
-                                   0.0, nullptr, pre ? pre->ed : nullptr);
+  const NavSpec sp = nav_bounds(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
+                                pre ? pre->ed : nullptr);
   if (!AUV_RUN_N(d, 2)) return;
-  nav_finish<WT>(d, e, lane, list, obs_out, pre, sp, true, nullptr, pose_cs ? pose_cs + e : nullptr, out);
+  nav_finish<WT>(d, e, lane, list, obs_out, pre, sp, out);
 }
 
 // ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----

@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     if (lane == 0) d.stamps[(size_t)e * 16 + 2] = wall_clock64();
 #endif
     int n_act = 0;
-    if (AUV_RUN_L(d, 1)) n_act = k2_front<true>(d, e, lane, L, 1, &pre, nullptr, 1, &kp, true);
+    if (AUV_RUN_L(d, 1)) n_act = k2_front<true>(d, e, lane, L, 1, &pre, 1, &kp, true);
     if (AUV_RUN_L(d, 3)) k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
     double term = 0.0;
     const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term);
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     pp.cnt = pre.cnt;
     NavOut no;
     no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = no.cte100 = 0.0;
-    if (AUV_RUN_N(d, 1)) k3_nav_env(d, e, lane, smem, obs_out, &pre, nullptr, &no);
+    if (AUV_RUN_N(d, 1)) k3_nav_env(d, e, lane, smem, obs_out, &pre, &no);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
 #endif

@@ -53,6 +53,12 @@ class AuvVecEnv:
         self.num_envs = int(n_envs)
         self.config = config
         self.observation_space, self.action_space = self.env.observation_space, self.env.action_space
+        v = config.vessel
+        self._dict_obs = bool(v.use_dict_observation and v.use_lidar)
+        if self._dict_obs:                                                    # environment.py:116-137
+            from .spaces import Box, Dict
+            self.observation_space = Dict({"proprioceptive": Box(low=-1.0, high=1.0, shape=(6,), dtype=np.float32),
+                                           "lidar": Box(low=-1.0, high=1.0, shape=v.lidar_shape, dtype=np.float32)})
         self.numpy = bool(numpy)
         self._rewarder = _RewarderView(rewarder)
         if sub_batches > 1:
@@ -78,6 +84,15 @@ class AuvVecEnv:
         a = t.detach().cpu().numpy()
         return a.astype(dtype) if dtype is not None else a
 
+    def _obs(self, obs: torch.Tensor):
+        """The batched observation as the caller wants it: flat [N, 6 + channels * S], or -- use_dict_observation,
+        environment.py:281-288 -- {"proprioceptive": [N, 6], "lidar": [N, channels, S]} (closeness row over the velocity
+        rows, which the reference hard-wires to zero, sensor.py:159)."""
+        if not self._dict_obs:
+            return self._out(obs)
+        c, S = self.config.vessel.lidar_shape
+        return {"proprioceptive": self._out(obs[:, :6]), "lidar": self._out(obs[:, 6:6 + c * S].reshape(-1, c, S))}
+
     def _record_pose(self):
         if self._track:
             st = self.env.read("STATE")                                      # [6, N] on the device
@@ -89,7 +104,7 @@ class AuvVecEnv:
         obs = self.env.reset()
         self._traj_n = 0
         self._record_pose()
-        return self._out(obs.clone() if not self.numpy else obs)
+        return self._obs(obs.clone() if not self.numpy else obs)
 
     def step_async(self, actions):
         a = torch.as_tensor(np.asarray(actions) if isinstance(actions, (list, tuple)) else actions)
@@ -103,11 +118,11 @@ class AuvVecEnv:
         self._waiting = False
         self._record_pose()
         if not self.numpy:
-            return obs, rew, done, info
+            return self._obs(obs), rew, done, info
         step_info = self.env.read("STEP_INFO").cpu().numpy()                 # one read for all four keys
         infos = [dict(collision=bool(r[0]), reached_goal=bool(r[1]), goal_distance=float(r[2]), progress=float(r[3]))
                  for r in step_info]
-        return self._out(obs), self._out(rew), self._out(done).astype(bool), infos
+        return self._obs(obs), self._out(rew), self._out(done).astype(bool), infos
 
     def step(self, actions):
         self.step_async(actions)

@@ -144,3 +144,31 @@ def test_vecenv_cross_track_error_mean_and_device_tensors():
             # all but the terminal step's |cte| are in `s`: the record's sum lies between s and s + (a step's |cte| <= a few 100 m)
             assert h["cross_track_error"] * c >= s - 1e-6
     vec_env.close()
+
+
+def test_vecenv_dict_observation_with_velocity_channels():
+    """use_dict_observation + sensor_use_velocity_observations for the whole batch (environment.py:116-137, :281-288):
+    {"proprioceptive": [N, 6], "lidar": [N, 3, S]} with the closeness row over two all-zero velocity rows (the
+    reference's simulate_sensor always returns velocity (0, 0), sensor.py:159), equal to the flat layout's columns."""
+    from gym_auv_amd.vec_env import AuvVecEnv
+    n = 32
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.use_dict_observation = True
+    cfg.vessel.sensor_use_velocity_observations = True
+    worlds = _worlds(n)
+    vec_env = AuvVecEnv(cfg, worlds, n, track_trajectories=())
+    flat_cfg = effective_reference_config(use_lidar=True)
+    flat = AuvVecEnv(flat_cfg, worlds, n, track_trajectories=())
+    S = cfg.vessel.n_sensors
+    assert set(vec_env.observation_space.spaces) == {"proprioceptive", "lidar"} and vec_env.observation_space["lidar"].shape == (3, S)
+    o, f = vec_env.reset(), flat.reset()
+    rs = np.random.RandomState(0)
+    for _ in range(10):
+        a = rs.uniform([0, -0.15], [1, 0.15], (n, 2)).astype(np.float32)
+        o, _, _, _ = vec_env.step(a)
+        f, _, _, _ = flat.step(a)
+        assert o["proprioceptive"].shape == (n, 6) and o["lidar"].shape == (n, 3, S) and o["lidar"].dtype == np.float32
+        np.testing.assert_array_equal(o["proprioceptive"], f[:, :6])
+        np.testing.assert_array_equal(o["lidar"][:, 0, :], f[:, 6:])
+        assert (o["lidar"][:, 1:, :] == 0.0).all()
+    vec_env.close(), flat.close()

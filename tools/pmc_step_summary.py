@@ -15,6 +15,12 @@ import sys
 import numpy as np
 
 out, per_step = sys.argv[1], int(sys.argv[2])
+import os
+for nm in ("pmc_fetch", "pmc_write", "pmc_sq"):      # the passes must have stepped with that many launches per step
+    f = os.path.join(out, nm + "_bench.json")
+    if os.path.exists(f) and os.path.getsize(f):
+        got = json.load(open(f))["config"]["sub_batches"]
+        assert got == per_step, "%s ran with %d sub-batches, summary asked for %d" % (nm, got, per_step)
 STEP_KERNELS = ("k_step_roles", "k1_dynamics", "k23_lidar_nav", "k3_reward")
 
 
