@@ -50,6 +50,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 256 * 4               # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
+CLOCK_PEAK_GHZ = 2.4           # max shader clock (MI355X_MICROARCH.md): the VALU leg's peak is N_SIMD x this
 
 
 def parse():
@@ -432,10 +433,14 @@ def main():
         # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) in which a wave executes a VALU instruction, summed over
         # waves and (here) over the launches of one step.  Issue capacity of a step = 1024 SIMDs x shader clock x time per
         # step; the clock is the counter pass's own SQ_BUSY_CYCLES / 32 shader engines / kernel duration.
+        # `frac` prices the step against the PEAK clock (a lower bound of the share: the clock under load is lower);
+        # `frac_at_measured_clock` against the counter pass's own SQ_BUSY_CYCLES / 32 shader engines / dispatch duration
+        # (an upper bound: short launches do not keep every shader engine busy from first to last cycle).
         issue = 4.0 * sq["SQ_ACTIVE_INST_VALU"]
-        cyc_step = sq["clock_ghz"] * 1e9 * ms_step * 1e-3
-        valu = dict(insts=int(sq["SQ_INSTS_VALU"]), issue_cycles=int(issue), step_cycles=int(cyc_step), clock_ghz=sq["clock_ghz"],
+        cyc_step = CLOCK_PEAK_GHZ * 1e9 * ms_step * 1e-3
+        valu = dict(insts=int(sq["SQ_INSTS_VALU"]), issue_cycles=int(issue), step_cycles=int(cyc_step), clock_ghz=CLOCK_PEAK_GHZ,
                     frac=round(issue / (N_SIMD * cyc_step), 4),
+                    frac_at_measured_clock=round(issue / (N_SIMD * sq["clock_ghz"] * 1e9 * ms_step * 1e-3), 4), measured_clock_ghz=sq["clock_ghz"],
                     wait_frac=round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 4) if sq.get("SQ_WAVE_CYCLES") else None,
                     source="profiles/pmc_sq.json [%s]" % cfg_key, lib_sha256=sq.get("lib_sha256"),
                     stale=sq.get("lib_sha256") != lib_sha)
