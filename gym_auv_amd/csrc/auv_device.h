@@ -86,8 +86,8 @@ struct AuvDev {
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position
   int32_t cut_lidar, cut_nav;  // diagnostic build only (-DAUV_CUTS, tools/valu_budget.py): phases from this number on are skipped
-  int32_t pair_skew;   // paired step, test hook: idle workgroups between the two roles (puts them on different XCDs)
-  int32_t pair_fault;  // paired step, test hook: environment 0's sweep never publishes its word (the poll must run out)
+  int32_t pair_skew;   // one-launch step, test-hook build only: idle workgroups between the roles (an environment's waves on different XCDs)
+  int32_t pair_fault;  // one-launch step, test-hook build only: the launch's first sweep never publishes its word (the poll must run out)
   const struct AuvDev* self;  // this struct in device memory (as of the last bank load): the one-launch step's restore path
                               // reads its ~25 table pointers through it at the point of use -- as kernel arguments
                               // they would all be fetched (and spilled) at the entry of every wave of both roles
@@ -111,11 +111,11 @@ struct AuvDev {
                           //     sum of beam_w (in the wave-reduction order), -
   int32_t* ring_pos;    // [1]  current slot of the action ring (advanced once per step by K3)
   int32_t ring_slots;   // 1 = plain action buffer
-  int32_t ring_slot_host; // >= 0: the host names the slot (single-kernel step); -1: read ring_pos
+  int32_t ring_slot_host; // -1: read ring_pos and advance it; -2: read it, another kernel of the step advances it; >= 0: the host names the slot
   unsigned long long* stamps;  // [N][16] per-env phase cycle counts (diagnostic builds, -DAUV_STAMPS)
 };
 
-// State handed from one phase to the next inside the single-kernel step (registers instead of
+// State handed from one phase to the next inside a launch (registers instead of
 // a global-memory round trip): the advanced vessel state and the env's counters.
 struct EnvPre {
   double s[6];     // x, y, psi, u, v, r after Vessel.step

@@ -687,8 +687,7 @@ __device__ __forceinline__ int reward_apply(const AuvDev& d, const int e, const 
   }
   const int do_reset = done && d.cfg.auto_reset;
   if (!do_reset) d.counters[e] = cnt;
-  // next action slot (the single-kernel step advances the ring from the host or a follow-up node:
-  // other waves of that kernel may still be reading the position)
+  // next action slot of a captured graph's ring
   // (ring_slot_host: >= 0 the host names the slot; -1 the device position, advanced here; -2 the device position,
   // advanced by another kernel of the step -- the side-by-side shape does it in k23_lidar_nav, so that a reward phase
   // fused with the NEXT step's dynamics never races with its own readers)

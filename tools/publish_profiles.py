@@ -17,10 +17,14 @@ sub = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
+headline = (workload, sub) == ("polygons50", 4)       # the headline run keeps the plain names; other passes get a suffix
 for f in glob.glob(os.path.join(run, "bench_*.json")) + glob.glob(os.path.join(run, "*.txt")) + glob.glob(os.path.join(run, "pmc_*.json")) + \
         [os.path.join(run, n) for n in ("kernel_stats.csv", "bench_2ranks_refused.out", "lib_sha256.txt")]:
     if os.path.exists(f) and os.path.getsize(f) > 0:
-        shutil.copy(f, dst)
+        if headline:
+            shutil.copy(f, dst)
+        elif os.path.basename(f).startswith("pmc_") and f.endswith("_bench.json"):
+            shutil.copy(f, os.path.join(dst, os.path.basename(f)[:-5] + "_%s_sub%d.json" % (workload, sub)))
 sha = open(os.path.join(run, "lib_sha256.txt")).read().split()[0]
 summ = json.load(open(os.path.join(run, "pmc_step_summary.json")))
 ps = summ["per_step"]
