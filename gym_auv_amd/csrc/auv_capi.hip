@@ -200,6 +200,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.ep_log_count, 4);
   rc |= dev_alloc(ep, &d.pair_word, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
+  rc |= dev_alloc(ep, &d.nav_hand, 8 * n);
   rc |= dev_alloc(ep, &d.k1_done, 4);
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
@@ -243,8 +244,9 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     }
     *h->pair_error_host = 0;   // (a new bank starts with a clean slate; see PAIR_CHECK)
     HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d.k1_done, 0, sizeof(int32_t)));
-    if (((uintptr_t)d.k1_pkt & 63) != 0) return fail(AUV_EHIP, "state packets are not 64-byte aligned");
+    if (((uintptr_t)d.k1_pkt & 63) != 0 || ((uintptr_t)d.nav_hand & 63) != 0) return fail(AUV_EHIP, "hand-over records are not 64-byte aligned");
   }
   d.w_ready = 0;
   auv_launch_derive(d, nullptr);
@@ -301,9 +303,9 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
 static int probe_dispatch_order(auv_handle* h) {
   const int np = 512, nc = 8192;
   unsigned int* words = nullptr;
-  HIP_TRY(hipMalloc((void**)&words, (size_t)(np + nc + 1) * sizeof(unsigned int)));
-  HIP_TRY(hipMemset(words, 0, (size_t)(np + nc + 1) * sizeof(unsigned int)));
-  unsigned int* failures = words + np + nc;
+  HIP_TRY(hipMalloc((void**)&words, (size_t)(np + 2 * nc + 1) * sizeof(unsigned int)));
+  HIP_TRY(hipMemset(words, 0, (size_t)(np + 2 * nc + 1) * sizeof(unsigned int)));
+  unsigned int* failures = words + np + 2 * nc;
   unsigned int nf = 0;
   hipError_t e = auv_launch_probe(words, np, nc, 0xA5A5u, failures, auv_step_lds_bytes(h->d), nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -330,6 +332,7 @@ static int recover_from_timeout(auv_handle* h) {
   std::vector<unsigned long long> empty(n ? n : 1, AUV_PAIR_EMPTY);
   HIP_TRY(hipMemcpy(d.pair_word, empty.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.k1_done, 0, sizeof(int32_t)));
   auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);
   HIP_TRY(hipGetLastError());

@@ -84,6 +84,7 @@ struct AuvDev {
   unsigned long long* pair_word; // [N] one-launch step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
   int32_t* pair_error; // [1] one-launch step: set when a navigation wave gave up waiting for its sweep
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
+  unsigned long long* nav_hand; // [N][8] one-launch step: the nearest path segment the navigation role's search hands to the finish role
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position
   int32_t cut_lidar, cut_nav;  // diagnostic build only (-DAUV_CUTS, tools/valu_budget.py): phases from this number on are skipped
   int32_t pair_skew;   // one-launch step, test-hook build only: idle workgroups between the roles (an environment's waves on different XCDs)

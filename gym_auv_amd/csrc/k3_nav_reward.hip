@@ -41,6 +41,25 @@ struct MinIdx {
   int j;
 };
 
+// The tables and settings the navigation's tail and the reward phase touch, under the names AuvDev gives them: those
+// two are written against "a descriptor D" and run on either.  The finish role of the one-launch step fills a StepTabs
+// from the descriptor's device-side copy with scalar loads before its waits (through a generic reference to that copy
+// every table pointer would be a vector load at the point of use, on the launch's critical tail).
+struct StepTabs {
+  struct {
+    double min_cumulative_reward, min_goal_distance, min_path_progress, look_ahead_distance;
+    int32_t max_timesteps, rewarder, test_mode, auto_reset, n_sensors, use_lidar, obs_channels;
+  } cfg;
+  const double *knot_s, *knot_coef;
+  double *info64, *nav64, *obs64, *rew_path, *reward64, *step_info, *episode, *ep_log;
+  unsigned int* ep_log_count;
+  int32_t ep_log_cap;
+  int32_t* world_idx;
+  int4* counters;
+  int32_t ring_slots, ring_slot_host;
+  int32_t* ring_pos;
+};
+
 // SciPy PPoly: interval search + power-basis eval.  The knots are near-uniform, so the interval
 // is guessed from s / L and the knots and coefficient rows around the guess are fetched together
 // (one trip to memory); only a guess that is off by more than one interval walks and re-fetches.
@@ -51,7 +70,8 @@ struct KnotWin {
   bool have;
 };
 
-__device__ __forceinline__ KnotWin knot_window(const AuvDev& d, long long k0, int nk, double x0, double xl, double s,
+template <class D>
+__device__ __forceinline__ KnotWin knot_window(const D& d, long long k0, int nk, double x0, double xl, double s,
                                                double L) {
   KnotWin w;
   w.have = false;
@@ -82,7 +102,8 @@ __device__ __forceinline__ KnotWin knot_window(const AuvDev& d, long long k0, in
 }
 
 // x0 / xl: the first / last knot, fetched by the caller ahead of time.
-__device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk, double x0, double xl, double s,
+template <class D>
+__device__ __forceinline__ void path_eval(const D& d, long long k0, int nk, double x0, double xl, double s,
                                           double L, double xy[2], double dxy[2]) {
   const double* x = d.knot_s + k0;
   const double* cf = d.knot_coef + 8 * k0;
@@ -130,7 +151,8 @@ __device__ __forceinline__ void path_eval(const AuvDev& d, long long k0, int nk,
 }
 
 // path-following term of the reward (rewarder.py:110-118, :196-203)
-__device__ __forceinline__ double reward_path_term(const AuvDev& d, double u, double v, double heading_error,
+template <class D>
+__device__ __forceinline__ double reward_path_term(const D& d, double u, double v, double heading_error,
                                                    double cross_track_error, double progress, double max_progress) {
   const double gamma_y_e = 5.0, max_speed = 2.0;
   const double speed = sqrt(u * u + v * v);
@@ -141,7 +163,8 @@ __device__ __forceinline__ double reward_path_term(const AuvDev& d, double u, do
 }
 
 // the same with the speed sqrt(u u + v v) and cos(heading_error) handed in (the navigation forms them beside its angles)
-__device__ __forceinline__ double reward_path_term_cos(const AuvDev& d, double speed, double cos_heading_error,
+template <class D>
+__device__ __forceinline__ double reward_path_term_cos(const D& d, double speed, double cos_heading_error,
                                                        double cross_track_error, double progress, double max_progress) {
   const double gamma_y_e = 5.0, max_speed = 2.0;
   const double ctp = exp(-gamma_y_e * fabs(cross_track_error));
@@ -425,31 +448,19 @@ struct NavOut {
   double cte100;                    // cross-track error / 100 (NAV64 [5])
 };
 
-// WT: the rows are stored write-through (auv_st), for the one-launch step.  `out`: lane 0's NavOut, or nullptr.
-template <bool WT = false>
-__device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const int lane, int* list,
-                                           float* __restrict__ obs_out, const EnvPre* pre, const NavSpec sp, NavOut* out = nullptr) {
-  const int S = d.cfg.n_sensors;
-  const size_t n = (size_t)d.n;
-  const double px = pre ? pre->s[0] : d.state[0 * n + e], py = pre ? pre->s[1] : d.state[1 * n + e],
-               psi = pre ? pre->s[2] : d.state[2 * n + e];
-  const double u = pre ? pre->s[3] : d.state[3 * n + e], v = pre ? pre->s[4] : d.state[4 * n + e],
-               r = pre ? pre->s[5] : d.state[5 * n + e];
-  AUV_STAMP_DECL
-  const EnvDesc ed = sp.ed;
-  const double L = sp.L;
-  double* inf = d.info64 + 8 * (size_t)e;
-  double* nv = d.nav64 + 8 * (size_t)e;
-  double* ob = d.obs64 + (size_t)e * (6 + S);
-  const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
-  const double knot_first = sp.knot_first, knot_last = sp.knot_last;
-  const double goal_x = sp.goal_x, goal_y = sp.goal_y;
-  const double maxp_in = sp.maxp_in;
+// the nearest segment of the path: its end points and the cumulative arclength at its first vertex (wave-uniform)
+struct NavNear {
+  double2 A, B;
+  double cum;
+};
+
+// exact distances to the listed segments, (distance, first index) minimum over the wave
+__device__ __forceinline__ NavNear nav_nearest(const AuvDev& d, const int e, const int lane, const int* list, const double px,
+                                               const double py, const NavSpec& sp) {
+  const EnvDesc& ed = sp.ed;
   const long long p0 = ed.p0;
   const int P = ed.P;
   const double2* xy = d.poly_xy + p0;
-  AUV_STAMP()
-  AUV_STAMP()
   // ---- exact distances to the listed segments (path.py:84-93): (distance, first index) minimum ----
   MinIdx best;
   best.d = 1.7976931348623157e308;
@@ -457,9 +468,6 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
   double2 bA = make_double2(0.0, 0.0), bB = bA;        // end points of this lane's best segment
   double my_cum = 0.0;
   const int n_act = sp.n_list;
-  // cos / sin of the new heading for the reward's cos(heading error) below
-  double sin_psi, cos_psi;
-  sincos(psi, &sin_psi, &cos_psi);
   if (sp.in_regs) {
 #pragma unroll
     for (int q = 0; q < NAV_SPEC; q++) {
@@ -504,15 +512,50 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
     }
     wmask = __ballot(best.d == dmin && best.j == jm);
   }
-  AUV_STAMP()
-  if (!AUV_RUN_N(d, 3)) return;
   // the winning lane hands over its segment (no second trip to memory)
   const int src = wmask ? __ffsll((long long)wmask) - 1 : 0;
-  double2 A, B;
-  A.x = __shfl(bA.x, src, AUV_WAVE), A.y = __shfl(bA.y, src, AUV_WAVE);
-  B.x = __shfl(bB.x, src, AUV_WAVE), B.y = __shfl(bB.y, src, AUV_WAVE);
-  const double cum = __shfl(my_cum, src, AUV_WAVE);
-  // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure (all lanes, uniform)
+  NavNear nr;
+  nr.A.x = __shfl(bA.x, src, AUV_WAVE), nr.A.y = __shfl(bA.y, src, AUV_WAVE);
+  nr.B.x = __shfl(bB.x, src, AUV_WAVE), nr.B.y = __shfl(bB.y, src, AUV_WAVE);
+  nr.cum = __shfl(my_cum, src, AUV_WAVE);
+  return nr;
+}
+
+// ---- the navigation's scalar tail (vessel.py:471-515, environment.py:276-280, rewarder.py:110-118) ----
+// What the tail needs of one environment: the new state, the nearest segment, the per-world constants.
+struct TailIn {
+  double px, py, psi, u, v, r;
+  NavNear nr;
+  long long kn0;                     // EnvDesc: first knot, number of knots
+  int nk;
+  double L, goal_x, goal_y, knot_first, knot_last, maxp_in;
+};
+
+// A GROUP of GW lanes (GW = 64: the whole wave, one environment per wave; GW = 8: eight environments per wave, the
+// finish role of the one-launch step) evaluates the tail of environment e, c = lane % GW: lane 0 of the group the
+// spline at s, lanes 1 and 2 at the look-ahead arclength, one atan2 serving all three angles; lanes 3 / 4 / 5 take the
+// tail's other square roots and its quotient along in the same instructions.  `e` and `t` are uniform over the group
+// (over the wave for GW = 64: the compiler keeps them in scalar registers then).  The same source for both widths, so
+// the same operations on the same operands: bit-identical whichever shape ran.  Group lane 0 stores the rows and
+// returns the NavOut.
+template <int GW, class Desc>
+__device__ __forceinline__ NavOut nav_tail(const Desc& d, const int e, const int c, const bool live, const TailIn& t,
+                                           float* __restrict__ obs_out) {
+  const int S = d.cfg.n_sensors;
+  const double px = t.px, py = t.py, psi = t.psi, u = t.u, v = t.v, r = t.r;
+  const double L = t.L;
+  double* inf = d.info64 + 8 * (size_t)e;
+  double* nv = d.nav64 + 8 * (size_t)e;
+  double* ob = d.obs64 + (size_t)e * (6 + S);
+  const int D = 6 + (d.cfg.use_lidar ? S * (d.cfg.obs_channels == 3 ? 3 : 1) : 0);   // row stride of obs_out
+  const double2 A = t.nr.A, B = t.nr.B;
+  const double cum = t.nr.cum;
+  NavOut out;
+  out.rew_path = out.reached = out.goal = out.progress = out.u = out.v = out.r = out.cte100 = 0.0;
+  // cos / sin of the new heading for the reward's cos(heading error) below
+  double sin_psi, cos_psi;
+  sincos(psi, &sin_psi, &cos_psi);
+  // measure along the polyline: LengthIndexOfPoint::segmentNearestMeasure (all lanes of the group alike)
   double dx = B.x - A.x, dy = B.y - A.y, len2 = dx * dx + dy * dy;
   double seglen = sqrt(len2);
   double pf = (len2 == 0.0) ? 0.0 : ((px - A.x) * dx + (py - A.y) * dy) / len2;
@@ -523,26 +566,26 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
   // one atan2 then serves all three angles: lane 0 chi, lane 1 the look-ahead direction, lane 2
   // the heading towards the look-ahead point
   double p[2], dp[2];
-  path_eval(d, ed.kn0, ed.nk, knot_first, knot_last, lane == 0 ? s : s_t, L, p, dp);
+  path_eval(d, t.kn0, t.nk, t.knot_first, t.knot_last, c == 0 ? s : s_t, L, p, dp);
   // The wave issues the square root and the division below once whatever the number of busy lanes, so the lanes behind
   // the three angle lanes take the tail's other square roots and its quotient along in the same instructions (VERDICT r2
   // #2: the tail is 19 % of the step's VALU issue cycles): lane 3 the distance to the goal, |goal - p|; lane 4 the speed,
   // |(u, v)|; lane 5 the progress s / L.  Same operands, same operations, so the same bits as when lane 0 formed them.
-  double ang_y = (lane == 2) ? p[1] - py : dp[1], ang_x = (lane == 2) ? p[0] - px : dp[0];
-  if (lane == 3) ang_x = goal_x - px, ang_y = goal_y - py;
-  if (lane == 4) ang_x = u, ang_y = v;
-  if (lane == 5) ang_x = s, ang_y = 0.0;
+  double ang_y = (c == 2) ? p[1] - py : dp[1], ang_x = (c == 2) ? p[0] - px : dp[0];
+  if (c == 3) ang_x = t.goal_x - px, ang_y = t.goal_y - py;
+  if (c == 4) ang_x = u, ang_y = v;
+  if (c == 5) ang_x = s, ang_y = 0.0;
   const double dir = atan2(ang_y, ang_x);
   // unit vector of (ang_x, ang_y): lane 0 cos / sin of chi, lane 2 of the direction to the look-ahead
   // point -- formed beside the atan2, not from it, so that the cross-track error and the reward's
   // cos(heading error) do not wait for the angle (sin(atan2(y, x)) = y / |(x, y)| to rounding)
   const double root = sqrt(ang_x * ang_x + ang_y * ang_y);
-  const double hyp = (lane == 5) ? L : root;
-  const double ux = (hyp > 0.0 || lane == 5) ? ang_x / hyp : 1.0, uy = hyp > 0.0 ? ang_y / hyp : 0.0;   // atan2(0, 0) = 0
-  const double la_dir = __shfl(dir, 1, AUV_WAVE), tgt1 = __shfl(dir, 2, AUV_WAVE);
-  const double tx = __shfl(ux, 2, AUV_WAVE), ty = __shfl(uy, 2, AUV_WAVE);
-  const double goal_l = __shfl(root, 3, AUV_WAVE), speed_l = __shfl(root, 4, AUV_WAVE), progress_l = __shfl(ux, 5, AUV_WAVE);
-  if (lane == 0) {
+  const double hyp = (c == 5) ? L : root;
+  const double ux = (hyp > 0.0 || c == 5) ? ang_x / hyp : 1.0, uy = hyp > 0.0 ? ang_y / hyp : 0.0;   // atan2(0, 0) = 0
+  const double la_dir = __shfl(dir, 1, GW), tgt1 = __shfl(dir, 2, GW);
+  const double tx = __shfl(ux, 2, GW), ty = __shfl(uy, 2, GW);
+  const double goal_l = __shfl(root, 3, GW), speed_l = __shfl(root, 4, GW), progress_l = __shfl(ux, 5, GW);
+  if (c == 0 && live) {
     const double chi = dir;
     double ddx = p[0] - px, ddy = p[1] - py;
     double cte = -uy * ddx + ux * ddy;                         // vessel.py:481-483: -sin(chi) dx + cos(chi) dy
@@ -550,31 +593,27 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
     double he = auv_princip(tgt1 - psi);
     const double cos_he = tx * cos_psi + ty * sin_psi;        // cos(target direction - psi)
     const double progress = progress_l;                        // s / L
-    double maxp = maxp_in;
+    double maxp = t.maxp_in;
     if (progress > maxp) maxp = progress;
     const double goal = goal_l;                                // sqrt(gx gx + gy gy), g = goal - p
     int reached = (goal <= d.cfg.min_goal_distance) || (progress >= d.cfg.min_path_progress);
     // rows are written with 16-byte stores (NAV64 / INFO64 rows are 64-byte records)
     const double cte100 = cte / 100;
     double2* nv2 = (double2*)nv;
-    auv_st<WT>(nv2 + 0, make_double2(u, v)), auv_st<WT>(nv2 + 1, make_double2(r, la)), auv_st<WT>(nv2 + 2, make_double2(he, cte100)),
-        auv_st<WT>(nv2 + 3, make_double2(chi, s_t));
+    nv2[0] = make_double2(u, v), nv2[1] = make_double2(r, la), nv2[2] = make_double2(he, cte100), nv2[3] = make_double2(chi, s_t);
     double2* inf2 = (double2*)inf;
-    auv_st<WT>(inf + 1, (double)reached), auv_st<WT>(inf2 + 1, make_double2(goal, progress)), auv_st<WT>(inf + 5, maxp),
-        auv_st<WT>(inf + 6, s);                                  // ([7]: the episode's running sum of |cross-track error|, kept by the reward phase)
+    inf[1] = (double)reached, inf2[1] = make_double2(goal, progress), inf[5] = maxp,
+    inf[6] = s;                                                // ([7]: the episode's running sum of |cross-track error|, kept by the reward phase)
     // path-following term of the reward: everything it needs is at hand here, so the
     // transcendentals stay out of the reward phase
     const double rew_path = reward_path_term_cos(d, speed_l, cos_he, cte100, progress, maxp);
-    auv_st<WT>(d.rew_path + e, rew_path);
-    if (out) out->rew_path = rew_path, out->reached = reached, out->goal = goal, out->progress = progress, out->u = u, out->v = v, out->r = r, out->cte100 = cte100;
+    d.rew_path[e] = rew_path;
+    out.rew_path = rew_path, out.reached = reached, out.goal = goal, out.progress = progress, out.u = u, out.v = v, out.r = r, out.cte100 = cte100;
     // environment.py:276-280; lane 0 also emits the float32 copies of its own six values.  OBS64 rows
     // start 16-byte aligned when 6 + S is even, float32 rows 8-byte aligned when their stride is even.
     const double c0 = auv_clip(u, -1.0, 1.0), c1 = auv_clip(v, -1.0, 1.0), c2 = auv_clip(r, -1.0, 1.0),
                  c3 = auv_clip(la, -1.0, 1.0), c4 = auv_clip(he, -1.0, 1.0), c5 = auv_clip(cte100, -1.0, 1.0);
-    if (WT) {
-      auv_st<WT>(ob + 0, c0), auv_st<WT>(ob + 1, c1), auv_st<WT>(ob + 2, c2), auv_st<WT>(ob + 3, c3), auv_st<WT>(ob + 4, c4),
-          auv_st<WT>(ob + 5, c5);
-    } else if (((6 + S) & 1) == 0) {
+    if (((6 + S) & 1) == 0) {
       double2* ob2 = (double2*)ob;
       ob2[0] = make_double2(c0, c1), ob2[1] = make_double2(c2, c3), ob2[2] = make_double2(c4, c5);
     } else {
@@ -582,10 +621,7 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
     }
     if (obs_out) {
       float* oo = obs_out + (size_t)e * D;
-      if (WT) {
-        auv_st<WT>(oo + 0, (float)c0), auv_st<WT>(oo + 1, (float)c1), auv_st<WT>(oo + 2, (float)c2), auv_st<WT>(oo + 3, (float)c3),
-            auv_st<WT>(oo + 4, (float)c4), auv_st<WT>(oo + 5, (float)c5);
-      } else if ((D & 1) == 0) {
+      if ((D & 1) == 0) {
         float2* oo2 = (float2*)oo;
         oo2[0] = make_float2((float)c0, (float)c1), oo2[1] = make_float2((float)c2, (float)c3), oo2[2] = make_float2((float)c4, (float)c5);
       } else {
@@ -593,6 +629,26 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
       }
     }
   }
+  return out;
+}
+
+// nearest segment, then the tail by the whole wave.  `out`: lane 0's NavOut, or nullptr.
+__device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const int lane, int* list,
+                                           float* __restrict__ obs_out, const EnvPre* pre, const NavSpec& sp, NavOut* out = nullptr) {
+  const size_t n = (size_t)d.n;
+  TailIn t;
+  t.px = pre ? pre->s[0] : d.state[0 * n + e], t.py = pre ? pre->s[1] : d.state[1 * n + e], t.psi = pre ? pre->s[2] : d.state[2 * n + e];
+  t.u = pre ? pre->s[3] : d.state[3 * n + e], t.v = pre ? pre->s[4] : d.state[4 * n + e], t.r = pre ? pre->s[5] : d.state[5 * n + e];
+  AUV_STAMP_DECL
+  AUV_STAMP()
+  AUV_STAMP()
+  t.nr = nav_nearest(d, e, lane, list, t.px, t.py, sp);
+  AUV_STAMP()
+  if (!AUV_RUN_N(d, 3)) return;
+  t.kn0 = sp.ed.kn0, t.nk = sp.ed.nk;
+  t.L = sp.L, t.goal_x = sp.goal_x, t.goal_y = sp.goal_y, t.knot_first = sp.knot_first, t.knot_last = sp.knot_last, t.maxp_in = sp.maxp_in;
+  const NavOut no = nav_tail<AUV_WAVE>(d, e, lane, true, t, obs_out);
+  if (out && lane == 0) *out = no;
   AUV_STAMP()
   AUV_STAMP_FLUSH(e, 8)   // 8:bounds 9:list 10:scan 11:nav
 }
@@ -600,7 +656,6 @@ __device__ __forceinline__ void nav_finish(const AuvDev& d, const int e, const i
 // the navigation of one environment.  `scratch`: NAV_SCRATCH_BYTES(nch_max) of LDS, 16-byte aligned: the list of
 // surviving chunks.
 #define NAV_SCRATCH_BYTES(nch_max) (((size_t)(nch_max) * sizeof(int) + 15) & ~(size_t)15)
-template <bool WT = false>
 __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const int lane, unsigned char* scratch,
                                            float* __restrict__ obs_out, const EnvPre* pre = nullptr, NavOut* out = nullptr) {
   int* list = (int*)scratch;
@@ -608,7 +663,7 @@ __device__ __forceinline__ void k3_nav_env(const AuvDev& d, const int e, const i
   const NavSpec sp = nav_bounds(d, e, lane, list, pre ? pre->s[0] : d.state[0 * n + e], pre ? pre->s[1] : d.state[1 * n + e],
                                 pre ? pre->ed : nullptr);
   if (!AUV_RUN_N(d, 2)) return;
-  nav_finish<WT>(d, e, lane, list, obs_out, pre, sp, out);
+  nav_finish(d, e, lane, list, obs_out, pre, sp, out);
 }
 
 // ---- reward + done + bookkeeping part; needs K2's ranges/collision and the nav part's outputs ----
@@ -629,7 +684,9 @@ struct RewardIn {
   double cte100, cte_sum;           // NAV64 [5] of this step; INFO64 [7] before it (sum of |cross-track error| so far)
 };
 
-__device__ __forceinline__ int reward_apply(const AuvDev& d, const int e, const int collision, int4& cnt, const RewardIn in,
+// `D`: AuvDev or StepTabs (see there)
+template <class D>
+__device__ __forceinline__ int reward_apply(const D& d, const int e, const int collision, int4& cnt, const RewardIn in,
                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
                                             const bool advance_ring) {
   double* inf = d.info64 + 8 * (size_t)e;

@@ -1,7 +1,7 @@
 // k_step_fused.hip -- the launch shapes of step() that put more than one phase into a launch, built from the very
 // same device functions as the individually launchable kernels (k1_dynamics / k2_lidar / k3_nav / k3_reward), so the
 // per-kernel parity tests cover their arithmetic and tests/test_gpu_parity.py pins the compositions bit for bit:
-//   k_step_roles            ONE launch per step: dynamics, LiDAR sweep, navigation + reward as three roles
+//   k_step_roles            ONE launch per step: dynamics, LiDAR sweep, navigation search, tail + reward as four roles
 //   k23_lidar_nav           K2 and K3-nav side by side in one launch (the fence-free three-launch shape)
 //   k31_reward_dyn          inside a captured graph of several steps: reward phase of step t + dynamics of step t + 1
 // Every launch covers the slice [e0, e0 + ne) of the handle's environments (AuvDev::e0 / ne; the whole batch by
@@ -9,8 +9,10 @@
 // (Measured and removed in round 3, numbers in DESIGN.md: the whole step as one wave per environment, 66.9 M
 // env-steps/s; [K1 + navigation] -> [LiDAR + reward], 73.6 M; navigation forked onto a second stream, 64.5 M; K1 ->
 // [LiDAR | navigation + reward] ("paired"), 98 M; the navigation's tail + reward with lanes <-> environments as a
-// second launch or a fourth role: 20 % fewer VALU instructions but a longer step per chain, 106-112 M against 133 M
-// with four sub-batch chains -- git history and profiles/r03/shapes_sweep*.log.)
+// second launch, 106-112 M against 133 M with four sub-batch chains; the one-launch step with the navigation WAVE of an
+// environment also running its tail and its reward phase -- three roles -- was the shape until late in round 3: 19 %
+// more VALU issue cycles than the four roles below, 130 M against 136 M in the same sweep -- git history and
+// profiles/r03/shapes_sweep*.log.)
 #include <cstdlib>
 #include <hip/hip_ext.h>
 
@@ -36,28 +38,27 @@
 
 namespace {
 
-// ---- the in-launch finish: reward / done / auto-reset by the navigation wave of the one-launch step ----
-// An environment's LiDAR wave and its navigation wave are two one-wave workgroups of the same launch; the
-// navigation wave also runs the reward phase (rewarder.py:78-140, :167-241; environment.py:333-347, :375-384) --
-// no third launch.  What it needs of the sweep is one 64-bit word per environment (the LiDAR term of the reward,
-// or a marker for "collision"): the LiDAR wave stores it last, the navigation wave requests it when it starts
-// (almost always it is there by then: navigation workgroups are dispatched behind all LiDAR workgroups and get
-// their slot when a sweep retires), consumes it at its end and puts the "empty" marker back.
+// ---- the in-launch hand-over of the sweep's result -------------------------------------------------------------
+// An environment's LiDAR wave and the finish wave that runs its reward phase (rewarder.py:78-140, :167-241;
+// environment.py:333-347, :375-384) are workgroups of the same launch -- no third launch.  What the reward phase needs
+// of the sweep is one 64-bit word per environment (the LiDAR term of the reward, or a marker for "collision"): the
+// LiDAR wave stores it last, the finish wave polls for it, consumes it and puts the "empty" marker back.
 //   Coherence without device-scope fences (their L2 write-back per wave is what made round 1's attempt 5x slower):
 //   * the word goes by relaxed agent-scope atomic store / load (sc1: written through and read past the XCD's
 //     L2, which is not coherent with the other seven);
 //   * every row the LiDAR wave writes is stored write-through too (WT = true in k2_front / k2_back), and the wave
-//     waits for the completion of all its stores before it stores the word.  A navigation wave that has seen the
-//     word therefore knows that nothing of its environment is in flight or dirty in another L2: its plain stores
+//     waits for the completion of all its stores before it stores the word.  A finish wave that has seen the
+//     word therefore knows that nothing of that environment is in flight or dirty in another L2: its plain stores
 //     (reward phase; restore_env, which overwrites the sweep's rows when the episode ended) are the last word
 //     whichever XCDs the two ran on.  Rows of other environments share cache lines but not bytes.
-//   * the launch places the two waves of an environment on the same XCD (workgroups go round-robin over the
-//     eight XCDs; the navigation role starts at a multiple of 8), which keeps the word in one L2; correctness
-//     does not depend on it (tests run with the roles skewed onto different XCDs).
-//   * a navigation wave whose sweep is still running (a handful per launch) polls.  Its LiDAR workgroup has a
-//     smaller index in the same launch, so it was dispatched earlier and finishes without needing anything from
-//     anyone; the poll is bounded all the same: when it runs out the wave reports through `pair_error`
-//     (auv_step fails from then on) instead of hanging the device.
+//   * the launch places all waves of an environment on the same XCD (workgroups go round-robin over the eight XCDs;
+//     every role starts at a multiple of 8 and the dynamics / finish waves take the environments of their own
+//     XCD), which keeps the words in one L2; correctness does not depend on it (tests run with the roles skewed
+//     onto different XCDs).
+//   * whoever polls, polls for a word of a workgroup with a SMALLER index in the same launch: that one was
+//     dispatched earlier and finishes without needing anything from a later one.  The polls are bounded all the
+//     same: when one runs out the wave reports through `pair_error` (the next call recovers and reports) instead
+//     of hanging the device.
 #define PAIR_EMPTY AUV_PAIR_EMPTY
 #define PAIR_COLLISION AUV_PAIR_COLLISION
 #define PAIR_POLL_LIMIT (1 << 22)
@@ -69,72 +70,6 @@ __device__ __forceinline__ void pair_publish_lidar(const AuvDev& d, const int e,
   if (lane == 0)
     __hip_atomic_store(d.pair_word + e, collision ? PAIR_COLLISION : (unsigned long long)__double_as_longlong(term),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// what the navigation wave requests before it starts working (one trip, hidden behind the search)
-struct PairPre {
-  unsigned long long word;
-  double cum, cte_sum;
-  int4 cnt;
-  int w;
-};
-__device__ __forceinline__ PairPre pair_prefetch(const AuvDev& d, const int e) {
-  PairPre p;
-  p.word = __hip_atomic_load(d.pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // (written by earlier launches: the dynamics kernel and the previous step's reward phase)
-  p.cum = d.info64[8 * (size_t)e + 4];
-  p.cte_sum = d.info64[8 * (size_t)e + 7];
-  p.cnt = d.counters[e];
-  p.w = d.world_idx[e];
-  return p;
-}
-
-__device__ __forceinline__ unsigned long long pair_uniform(const unsigned long long v) {   // (readfirstlane returns int)
-  return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
-         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
-}
-
-__device__ __forceinline__ void pair_finish_nav(const AuvDev& dk, const int e, const int lane, PairPre p, const NavOut no,
-                                                float* __restrict__ obs_out, float* __restrict__ reward_out,
-                                                uint8_t* __restrict__ done_out) {
-  unsigned long long word = pair_uniform(p.word);
-  const int limit = AUV_HOOK_FAULT(dk) ? (1 << 12) : PAIR_POLL_LIMIT;
-  for (int polls = 0; word == PAIR_EMPTY; polls++) {
-    if (polls == limit) {
-      if (lane == 0) __hip_atomic_store(dk.pair_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
-    }
-    __builtin_amdgcn_s_sleep(8);
-    const unsigned long long t = __hip_atomic_load(dk.pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    word = pair_uniform(t);
-  }
-#ifdef AUV_STAMPS
-  if (lane == 0) dk.stamps[(size_t)e * 16 + 7] = wall_clock64();   // the sweep's word is here: start of the reward phase
-#endif
-  int do_reset = 0;
-  int4 cnt = p.cnt;
-  const AuvDev& d = dk;
-  if (lane == 0) {
-    __hip_atomic_store(d.pair_word + e, PAIR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next step
-    RewardIn in;
-    const int collision = word == PAIR_COLLISION;
-    in.closeness_reward = collision ? 0.0 : __longlong_as_double((long long)word);
-    in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
-    in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
-    in.cum = p.cum;
-    in.cte100 = no.cte100, in.cte_sum = p.cte_sum;
-    d.info64[8 * (size_t)e] = collision;
-    do_reset = reward_apply(d, e, collision, cnt, in, reward_out, done_out, false);
-  }
-  do_reset = __builtin_amdgcn_readfirstlane(do_reset);
-  if (do_reset) {
-    // (rare) the ~25 tables of the copy are read through the device-side copy of `d` (AuvDev::self), addressed as
-    // constant memory: scalar loads at the point of use.  As kernel arguments they would be fetched -- and, the budget
-    // of scalar registers being what it is, spilled -- at the entry of every wave of BOTH roles (1.4 us of the launch).
-    const AuvDev& dc = *(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)d.self;
-    restore_env(dc, e, (int)(((long long)__builtin_amdgcn_readfirstlane(p.w) + d.n) % d.n_worlds), lane,
-                __builtin_amdgcn_readfirstlane(cnt.z), obs_out);
-  }
 }
 
 // K2 and K3-nav of the launch's environments in one launch of one-wave workgroups: workgroups [0, ne) sweep the LiDAR
@@ -194,21 +129,24 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
   }
 }
 
-// ---- ONE launch per step: three roles -------------------------------------------------------------
+// ---- ONE launch per step: four roles --------------------------------------------------------------
 // k_step_roles   workgroups [0, nk) integrate the dynamics (Vessel.step, one wave = eight environments, eight lanes
-//                each: k1_group), workgroups [nk, nk + nb) sweep the LiDAR of one environment each, the rest navigate
-//                one environment each and run its reward phase (the in-launch finish above).  The sweep and the
-//                navigation need the state the dynamics role produces in the same launch: it hands each environment
-//                a 64-byte packet (x, y, psi, u, v, r, the vessel's step counter, a "ready" mark), stored
-//                write-through and completed before the mark is stored; the other two roles poll for the mark (the
-//                dynamics workgroups have the smallest indices, are dispatched first and wait for nobody; the poll
-//                is bounded like the in-launch finish's).  The navigation wave takes the mark away again when it has
-//                finished the environment's step (its sweep wave has read the packet long before: the navigation
-//                wave has consumed the word the sweep stores last), so the next launch finds every mark down.  What
-//                is saved is the dynamics kernel's launch ramp and the kernel boundary behind it.  No launch
-//                argument changes from step to step, so the shape can be captured in a hipGraph; there the dynamics
-//                waves count themselves off and the last one advances the action ring (every one of them has read
-//                the position by then).
+//                each: k1_group); workgroups [nk, nk + nb) sweep the LiDAR of one environment each; workgroups
+//                [nk + nb, nk + 2 nb) search the nearest point of the path for one environment each (the wide part of
+//                Vessel.navigate); the last nk workgroups -- the finish role, eight environments per wave like the
+//                dynamics -- evaluate the navigation's scalar tail and run the reward phase (see there).
+//                The sweep, the search and the finish need the state the dynamics role produces in the same launch:
+//                it hands each environment a 64-byte packet (x, y, psi, u, v, r, the vessel's step counter, a "ready"
+//                mark that is also a checksum), stored write-through and completed before the mark is stored; the
+//                other roles poll for the mark (the dynamics workgroups have the smallest indices, are dispatched
+//                first and wait for nobody; every poll is bounded).  The search leaves its result in a record of the
+//                same kind (NAV_HAND), the sweep its word.  The finish wave takes all three marks away again when it
+//                has finished the environment's step (the environment's other waves are gone by then: it has seen
+//                what each of them stores last), so the next launch finds every mark down.  What is saved against
+//                separate launches is the launch ramps and the kernel boundaries between them.  No launch argument
+//                changes from step to step, so the shape can be captured in a hipGraph; there the dynamics waves
+//                count themselves off and the last one advances the action ring (every one of them has read the
+//                position by then).
 // (Tried and dropped: the sweep waves also running the navigation's search over the chunk circles for the old pose
 // while they wait, handing the survivor list to the navigation wave in one word -- the navigation wave gets 2.5 us
 // shorter, but the extra traffic and issue slots stretch the dynamics role's chain from 6 to 7.5 us and the whole
@@ -269,6 +207,177 @@ __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, c
   for (int i = 0; i < 6; i++) pre.s[i] = pair_lane_value(v, i);
   pre.cnt.y = (int)__builtin_amdgcn_readlane((int)(unsigned)v, 6);   // the vessel's step counter of this launch
   return true;
+}
+
+// ---- the finish role: navigation tail + reward / done / auto-reset, eight environments per wave ----
+// Evaluated by one wave per environment the navigation's scalar tail keeps three to six lanes busy and was 19 % of the
+// step's VALU issue cycles (profiles/r03/valu_budget_polygons50.json).  So the navigation wave only SEARCHES: it leaves
+// the nearest segment (A, B, cumulative arclength) in a 64-byte record of NAV_HAND, checksummed like the state packet,
+// and ends, handing its slot on.  A finish wave -- workgroups behind all others, group g of eight lanes <->
+// environment, the dynamics role's mapping (same XCD as the environment's other waves) -- polls for the state packets
+// and the search records of its eight environments, evaluates their tails (nav_tail<8>: the very code of the
+// whole-wave form, so the same bits), polls for the sweeps' words, runs the reward phase in each group's first lane
+// and takes the three marks down; environments that ended are then restored by the whole wave, one after the other.
+// The tails run while the sweeps are still busy: only the reward phase (0.5-0.7 us) follows the last sweep.
+// (A first version of this role in round 3 waited for all three hand-overs BEFORE the tail and fetched its table
+// pointers with vector loads at the point of use: 38 against 31 us per chain step.  With the tail ahead of the second
+// wait and the tables in scalar registers before the waits: 136 M against 130 M env-steps/s with four chains, 107
+// against 100 M with one -- profiles/r03/shapes_sweep_finish_role.log.)
+__device__ __forceinline__ void roles_publish_search(const AuvDev& d, const int e, const int lane, const NavNear& nr) {
+  unsigned long long* h = d.nav_hand + 8 * (size_t)e;
+  // (wave-uniform values: lane 0 stores the five words one by one -- picking "this lane's word" would make the compiler
+  // build a table in scratch memory; words 5 and 6 of the record stay zero)
+  const unsigned long long w0 = (unsigned long long)__double_as_longlong(nr.A.x), w1 = (unsigned long long)__double_as_longlong(nr.A.y),
+                           w2 = (unsigned long long)__double_as_longlong(nr.B.x), w3 = (unsigned long long)__double_as_longlong(nr.B.y),
+                           w4 = (unsigned long long)__double_as_longlong(nr.cum);
+  if (lane == 0) {
+    __hip_atomic_store(h + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(h + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(h + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h + 4, w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  auv_stores_done();
+  if (lane == 0) __hip_atomic_store(h + 7, roles_mark(w0 ^ w1 ^ w2 ^ w3 ^ w4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// word `src` of the caller's group of eight lanes
+__device__ __forceinline__ unsigned long long roles_group_word(const unsigned long long v, const int src) {
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src, K1_GROUP), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src, K1_GROUP);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double roles_group_value(const unsigned long long v, const int src) {
+  return __longlong_as_double((long long)roles_group_word(v, src));
+}
+// lane c of a group holds word c of a checksummed 64-byte record: does it hold together?
+__device__ __forceinline__ bool roles_record_ok(const unsigned long long v, const int c) {
+  const unsigned long long x = roles_group_xor(c < 7 ? v : 0ull), mark = roles_group_word(v, 7);
+  return mark != 0ull && roles_mark(x) == mark;
+}
+
+__device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f, const int lane, float* __restrict__ obs_out,
+                                                  float* __restrict__ reward_out, uint8_t* __restrict__ done_out) {
+  // This role touches two dozen of the descriptor's tables, mostly while it waits: as kernel arguments they would be
+  // fetched, and spilled, at the entry of every wave of every role.  They are read from the descriptor's device-side
+  // copy (AuvDev::self) instead, through a pointer typed as constant memory -- scalar loads, issued here, before the
+  // waits.  (Through a generic reference to the copy every table pointer is a vector load at its point of use.)  The
+  // launch's own slice comes with the arguments.
+  const __attribute__((address_space(4))) AuvDev* dc = (const __attribute__((address_space(4))) AuvDev*)dk.self;
+  const AuvDev& d = *(const AuvDev*)dc;                           // (restore path, diagnostics)
+  StepTabs st;                                                    // the tail's and the reward phase's tables and settings
+  st.cfg.min_cumulative_reward = dc->cfg.min_cumulative_reward, st.cfg.min_goal_distance = dc->cfg.min_goal_distance;
+  st.cfg.min_path_progress = dc->cfg.min_path_progress, st.cfg.look_ahead_distance = dc->cfg.look_ahead_distance;
+  st.cfg.max_timesteps = dc->cfg.max_timesteps, st.cfg.rewarder = dc->cfg.rewarder, st.cfg.test_mode = dc->cfg.test_mode;
+  st.cfg.auto_reset = dc->cfg.auto_reset, st.cfg.n_sensors = dc->cfg.n_sensors, st.cfg.use_lidar = dc->cfg.use_lidar;
+  st.cfg.obs_channels = dc->cfg.obs_channels;
+  st.knot_s = dc->knot_s, st.knot_coef = dc->knot_coef;
+  st.info64 = dc->info64, st.nav64 = dc->nav64, st.obs64 = dc->obs64, st.rew_path = dc->rew_path, st.reward64 = dc->reward64;
+  st.step_info = dc->step_info, st.episode = dc->episode, st.ep_log = dc->ep_log, st.ep_log_count = dc->ep_log_count;
+  st.ep_log_cap = dc->ep_log_cap, st.world_idx = dc->world_idx, st.counters = dc->counters;
+  st.ring_slots = 1, st.ring_slot_host = 0, st.ring_pos = nullptr;          // (the dynamics role advances a captured graph's ring)
+  unsigned long long* const pair_word = dc->pair_word;
+  unsigned long long* const k1_pkt = dc->k1_pkt;
+  unsigned long long* const nav_hand = dc->nav_hand;
+  const EnvDesc* const env_desc = dc->env_desc;
+  const double* const world_scalar = dc->world_scalar;
+  const int ne = dk.ne, e0 = dk.e0;
+  const int g = lane / K1_GROUP, c = lane % K1_GROUP;
+  const int er = 8 * (8 * (f / 8) + g) + (f % 8);                 // the dynamics role's mapping
+  const bool live = er < ne;
+  const int e = e0 + (live ? er : ne - 1);                        // idle groups look at the last environment, store nothing
+  // what earlier launches left (requested before the polls)
+  int4 cnt = st.counters[e];
+  const int w = st.world_idx[e];
+  const double cum_in = st.info64[8 * (size_t)e + 4], cte_sum_in = st.info64[8 * (size_t)e + 7];
+  const EnvDesc ed = env_desc[e];
+  TailIn t;
+  t.kn0 = ed.kn0, t.nk = ed.nk;
+  {
+    const double* ws = world_scalar + 8 * (size_t)ed.w;
+    t.L = ws[0], t.goal_x = ws[1], t.goal_y = ws[2];
+    t.knot_first = st.knot_s[ed.kn0], t.knot_last = st.knot_s[ed.kn0 + ed.nk - 1];
+    t.maxp_in = st.info64[8 * (size_t)e + 5];
+  }
+  const unsigned long long* pk = k1_pkt + 8 * (size_t)e;
+  unsigned long long* hd = nav_hand + 8 * (size_t)e;
+  const int limit = AUV_HOOK_FAULT(dk) ? (1 << 12) : PAIR_POLL_LIMIT;
+#ifdef AUV_STAMPS
+  if (live && c == 0) d.stamps[(size_t)e * 16 + 10] = wall_clock64();   // the finish wave has its slot
+#endif
+  // ---- the state packet and the search record of every group ----
+  unsigned long long vp = 0ull, vh = 0ull;
+  bool okp = !live, okh = !live;
+  for (int polls = 0;; polls++) {
+    if (!okp) vp = __hip_atomic_load(pk + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // one 64-byte request per group
+    if (!okh) vh = __hip_atomic_load(hd + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    okp = !live || roles_record_ok(vp, c);
+    okh = !live || roles_record_ok(vh, c);
+    if (!__any(!(okp && okh))) break;
+    if (polls == limit) {
+      if (lane == 0) __hip_atomic_store(d.pair_error, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  t.px = roles_group_value(vp, 0), t.py = roles_group_value(vp, 1), t.psi = roles_group_value(vp, 2);
+  t.u = roles_group_value(vp, 3), t.v = roles_group_value(vp, 4), t.r = roles_group_value(vp, 5);
+  cnt.y = (int)(unsigned)roles_group_word(vp, 6);                 // the vessel's step counter of this launch
+  t.nr.A = make_double2(roles_group_value(vh, 0), roles_group_value(vh, 1));
+  t.nr.B = make_double2(roles_group_value(vh, 2), roles_group_value(vh, 3));
+  t.nr.cum = roles_group_value(vh, 4);
+#ifdef AUV_STAMPS
+  if (live && c == 0) d.stamps[(size_t)e * 16 + 9] = wall_clock64();    // state and search result are here
+#endif
+  NavOut no;
+  no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = no.cte100 = 0.0;
+  if (AUV_RUN_N(dk, 3)) no = nav_tail<K1_GROUP>(st, e, c, live, t, obs_out);
+#ifdef AUV_STAMPS
+  if (live && c == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();   // the tail is done
+#endif
+  // ---- the sweeps' words ----
+  unsigned long long word = live ? PAIR_EMPTY : 0ull;
+  for (int polls = 0;; polls++) {
+    if (word == PAIR_EMPTY) word = __hip_atomic_load(pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!__any(word == PAIR_EMPTY)) break;
+    if (polls == limit) {
+      if (lane == 0) __hip_atomic_store(d.pair_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+#ifdef AUV_STAMPS
+  if (live && c == 0) d.stamps[(size_t)e * 16 + 7] = wall_clock64();    // the sweep's word is here: start of the reward phase
+#endif
+  int do_reset = 0;
+  if (live && c == 0) {
+    // the three marks come down for the next launch (the sweep and the search waves of this environment are gone)
+    __hip_atomic_store(pair_word + e, PAIR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(hd + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    RewardIn in;
+    const int collision = word == PAIR_COLLISION;
+    in.closeness_reward = collision ? 0.0 : __longlong_as_double((long long)word);
+    in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
+    in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
+    in.cum = cum_in;
+    in.cte100 = no.cte100, in.cte_sum = cte_sum_in;
+    st.info64[8 * (size_t)e] = collision;
+    do_reset = reward_apply(st, e, collision, cnt, in, reward_out, done_out, false);
+  }
+  unsigned long long m = __ballot(do_reset);
+  if (m) {
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int er2 = auv_uniform(__shfl(e, src, AUV_WAVE));
+      const int wr = auv_uniform(__shfl(w, src, AUV_WAVE)), ep = auv_uniform(__shfl(cnt.z, src, AUV_WAVE));
+      const AuvDev* dp = dk.self;
+      asm volatile("" : "+s"(dp));      // (the copy's tables are fetched inside the loop: hoisted out of it they are spilled, and the
+                                        // spill slots keep 36 B of scratch memory enabled for every wave of the launch)
+      restore_env(*(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)dp, er2, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
+    }
+  }
+#ifdef AUV_STAMPS
+  if (live && c == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();
+#endif
 }
 
 __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvDev dk, const void* __restrict__ actions,
@@ -363,8 +472,8 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 14] = wall_clock64();
 #endif
-  } else {
-    // ---- Vessel.navigate of one environment, then its reward / done / auto-reset ----
+  } else if (b < nk + 2 * nb + AUV_HOOK_SKEW(d)) {
+    // ---- Vessel.navigate of one environment: the nearest-point search ----
     const int el = b - nk - nb - AUV_HOOK_SKEW(d);
     if (el < 0 || el >= ne) return;
     const int e = auv_uniform(d.e0 + el);
@@ -378,20 +487,24 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 5] = wall_clock64();
 #endif
-    PairPre pp = pair_prefetch(d, e);
-    pp.cnt = pre.cnt;
-    NavOut no;
-    no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = no.cte100 = 0.0;
-    if (AUV_RUN_N(d, 1)) k3_nav_env(d, e, lane, smem, obs_out, &pre, &no);
+    // the search only: nearest segment of the path -> NAV_HAND; the finish role takes it from there
+    NavNear nr;
+    nr.A = nr.B = make_double2(0.0, 0.0), nr.cum = 0.0;
+    if (AUV_RUN_N(d, 1)) {
+      int* list = (int*)smem;
+      const NavSpec sp = nav_bounds(d, e, lane, list, pre.s[0], pre.s[1], &ed);
+      if (AUV_RUN_N(d, 2)) nr = nav_nearest(d, e, lane, list, pre.s[0], pre.s[1], sp);
+    }
+    roles_publish_search(d, e, lane, nr);
 #ifdef AUV_STAMPS
-    if (lane == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();
+    if (lane == 0) d.stamps[(size_t)e * 16 + 6] = wall_clock64();     // the search result is out
 #endif
-    pair_finish_nav(d, e, lane, pp, no, obs_out, reward_out, done_out);
-    // the environment's step is complete (and its sweep wave gone): the packet's mark comes down for the next launch
-    if (lane == 0) __hip_atomic_store(d.k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef AUV_STAMPS
-    if (lane == 0) d.stamps[(size_t)e * 16 + 15] = wall_clock64();
-#endif
+  } else {
+    // ---- navigation tail + reward / done / auto-reset of eight environments ----
+    const int f = b - nk - 2 * nb - AUV_HOOK_SKEW(d);
+    if (f < 0 || f >= nk) return;
+    __builtin_amdgcn_s_setprio(2);
+    roles_finish_wave(d, f, lane, obs_out, reward_out, done_out);
   }
 }
 
@@ -430,11 +543,12 @@ __global__ void __launch_bounds__(AUV_WAVE) k31_reward_dyn(AuvDev d, const void*
 // The one-launch shape lets a wave poll for a word that a workgroup with a SMALLER index of the same
 // launch stores.  That terminates if workgroups are dispatched in index order (a poller's producer is resident or
 // done by the time the poller gets a slot) -- what gfx950 does, but HIP does not promise it.  k_probe_order has the
-// step's structure without its arithmetic: `np` producers (a short wait, then an sc1 word each), behind them
-// consumers that poll their producer's word, publish a word of their own and are in turn polled by a second
-// generation -- three generations like dynamics / sweep / navigation, every workgroup one wave with the step's LDS
-// footprint, and several times more workgroups than the chip has slots.  Any poll that runs out (bounded: ~20 ms)
-// counts a failure; the host then keeps the handle on the three-launch shape (auv_capi.hip: probe_dispatch_order).
+// step's structure without its arithmetic: `np` producers (a short wait, then an sc1 word each), behind them `nc`
+// consumers that poll their producer's word and publish a word of their own, a third generation that polls the
+// second's and publishes, and nc / 8 waves of a fourth that poll eight words of each earlier generation -- like
+// dynamics / sweep / search / finish, every workgroup one wave with the step's LDS footprint, and several times more
+// workgroups than the chip has slots.  Any poll that runs out (bounded: ~20 ms) counts a failure; the host then keeps
+// the handle on the three-launch shape (auv_capi.hip: probe_dispatch_order).  `words`: np + 2 nc of them, zeroed.
 __global__ void __launch_bounds__(AUV_WAVE) k_probe_order(unsigned int* __restrict__ words, int np, int nc, unsigned int tag,
                                                           unsigned int* __restrict__ failures) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -442,11 +556,18 @@ __global__ void __launch_bounds__(AUV_WAVE) k_probe_order(unsigned int* __restri
   if (lane == 0) smem[0] = 1;   // (touch the allocation so that it is not optimised away)
   unsigned int* mine = words + b;
   const unsigned int* src = nullptr;
-  if (b >= np + nc) src = words + np + (b - np - nc);          // third generation: its own second-generation wave
+  if (b >= np + 2 * nc) {                                      // fourth generation: eight of each of the others
+    const int q = b - np - 2 * nc;
+    if (lane < 8) src = words + np + nc + 8 * q + lane;
+    else if (lane < 16) src = words + np + 8 * q + (lane - 8);
+    else if (lane < 24) src = words + (8 * q + (lane - 16)) % np;
+  } else if (b >= np + nc) src = words + np + (b - np - nc);   // third generation: its own second-generation wave
   else if (b >= np) src = words + (b - np) % np;               // second generation: one of the producers
-  if (src) {
+  if (b >= np) {
     int polls = 0;
-    while (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+    for (;;) {
+      const bool there = !src || __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
+      if (!__any(!there)) break;
       if (++polls == (1 << 14)) {
         if (lane == 0) atomicAdd(failures, 1u);
         return;
@@ -456,7 +577,7 @@ __global__ void __launch_bounds__(AUV_WAVE) k_probe_order(unsigned int* __restri
   } else {
     __builtin_amdgcn_s_sleep(40), __builtin_amdgcn_s_sleep(40);   // ~2 us, like the dynamics' chain
   }
-  if (lane == 0 && b < np + nc) __hip_atomic_store(mine, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0 && b < np + 2 * nc) __hip_atomic_store(mine, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // a wave that does nothing for `ticks` of the 100 MHz wall clock (auv_streams_overlap: do two streams run side by side?)
@@ -474,7 +595,7 @@ hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int ta
     hipError_t e = hipFuncSetAttribute((const void*)k_probe_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_probe_order, dim3(np + 2 * nc), dim3(AUV_WAVE), lds, st, words, np, nc, tag, failures);
+  hipLaunchKernelGGL(k_probe_order, dim3(np + 2 * nc + nc / 8), dim3(AUV_WAVE), lds, st, words, np, nc, tag, failures);
   return hipGetLastError();
 }
 
@@ -504,7 +625,7 @@ void auv_launch_step_roles(const AuvDev& d0, const void* actions, int dtype, flo
   d.act_f64 = dtype == AUV_F64;
   const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
   const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
-  const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d)), block(AUV_WAVE);
+  const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d) + nk), block(AUV_WAVE);
   hipExtLaunchKernelGGL(k_step_roles, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
 }
 

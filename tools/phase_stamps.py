@@ -54,5 +54,14 @@ for ci, (lo, cnt) in enumerate(env._slices):
     f("nav search + tail duration from state (us)", n1 - ns)
     f("nav finish (wait for the word + reward) (us)", n2 - n1)
     f("nav end offsets (us)", n2 - base)
+    if os.environ.get("FIN"):     # the finish-role shape (FIN=1): search waves stamp 12 / 5 / 6, finish waves 10 / 9 / 13 / 7 / 15
+        f("search: result out (us)", s[:, 6] - base)
+        f("search duration from state (us)", s[:, 6] - ns)
+        f("finish wave: has its slot (us)", s[:, 10] - base)
+        f("finish wave: state + search records seen (us)", s[:, 9] - base)
+        f("finish wave: tail duration (us)", n1 - s[:, 9])
+        f("finish wave: tail done (us)", n1 - base)
+        f("finish wave: wait for the words (us)", s[:, 7] - n1)
+        f("finish wave: reward phase + restores (us)", n2 - s[:, 7])
 bases = [st[lo:lo + cnt, 3].min() for lo, cnt in env._slices]
 print("chain phase offsets of the last step (us):", [round((b - min(bases)) / 100.0, 1) for b in bases])
