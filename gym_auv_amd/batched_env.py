@@ -271,7 +271,8 @@ class BatchedAuvEnv:
 
     def set_step_mode(self, mode: str):
         """"auto" (default): "one_launch" below 16384 environments per launch, "side_by_side" from there on;
-        "one_launch": dynamics, LiDAR sweep and navigation + reward as three roles of ONE launch; "side_by_side": K1 ->
+        "one_launch": dynamics, LiDAR sweep, navigation search and finish (navigation tail + reward phase) as four roles of
+        ONE launch; "side_by_side": K1 ->
         [K2 + K3-nav in one launch] -> K3-reward.  The same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise).
         Where the in-launch hand-overs of the first may not be used (see `health()`) the library steps in
         "side_by_side" whatever is set: `effective_step_mode()` tells."""

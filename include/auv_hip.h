@@ -244,13 +244,15 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 /* How auv_step / auv_step_slice / auv_graph_capture run a step (same results, bit for bit):
  *   AUV_STEP_AUTO (default)          AUV_STEP_ONE_LAUNCH for launches of fewer than 16384 environments,
  *                                    AUV_STEP_SIDE_BY_SIDE from there on (where it is the faster one).
- *   AUV_STEP_ONE_LAUNCH              the whole step in ONE launch of one-wave workgroups with three roles: the
+ *   AUV_STEP_ONE_LAUNCH              the whole step in ONE launch of one-wave workgroups with four roles: the
  *                                    first n / 8 integrate the dynamics (K1, eight environments per wave), the
- *                                    next n sweep the LiDAR of one environment each (K2), the last n navigate one
- *                                    environment each (K3-nav) and run its reward / done / auto-reset (K3-reward).
- *                                    The roles hand their results on inside the launch through per-environment
- *                                    words stored and loaded coherently (csrc/k_step_fused.hip: k_step_roles,
- *                                    pair_finish_nav); waves that need a result poll for it, bounded.
+ *                                    next n sweep the LiDAR of one environment each (K2), the next n search the
+ *                                    nearest point of one environment's path each (the wide part of K3-nav), the
+ *                                    last n / 8 -- eight environments per wave -- evaluate the navigation's scalar
+ *                                    tail and run reward / done / auto-reset (K3-reward).  The roles hand their
+ *                                    results on inside the launch through per-environment words and checksummed
+ *                                    64-byte records stored and loaded coherently (csrc/k_step_fused.hip:
+ *                                    k_step_roles, roles_finish_wave); waves that need a result poll for it, bounded.
  *   AUV_STEP_SIDE_BY_SIDE            K1 -> [K2 and K3-nav side by side in one launch] -> K3-reward: nothing is
  *                                    handed over inside a launch.  Inside a captured graph of several steps
  *                                    K3-reward of step t and K1 of step t + 1 share a launch (also what a graph

@@ -245,7 +245,7 @@ def test_graph_replay_matches_eager():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_step_modes_agree_bitwise(dtype):
-    """every launch shape of the step (one launch with three roles, paired, side-by-side, and the default that picks
+    """every launch shape of the step (one launch with four roles, side-by-side, and the default that picks
     between them by size): bitwise the same."""
     n = 64
     bank = _mixed_bank(32)
@@ -272,9 +272,9 @@ def test_step_modes_agree_bitwise(dtype):
 
 @pytest.mark.parametrize("mode", ["one_launch"])
 def test_one_launch_step_bitwise_with_many_resets(mode):
-    """The in-launch hand-overs of the one-launch step (dynamics role -> sweep and navigation waves; sweep wave ->
-    navigation wave, which runs the reward phase) against the three-launch shape, bit for bit, over short
-    episodes: every environment is restored many times, by whichever of its waves ends last.  Production placement
+    """The in-launch hand-overs of the one-launch step (dynamics role -> sweep, search and finish waves; search and sweep
+    waves -> finish wave, which runs the navigation tail and the reward phase) against the three-launch shape, bit for
+    bit, over short episodes: every environment is restored many times by its finish wave.  Production placement
     (an environment's waves share an XCD); the same with the roles skewed onto different XCDs needs the hook build:
     test_hook_build_cases."""
     n = 1024

@@ -38,7 +38,7 @@ def test_side_by_side_kernel_fits_its_register_budget():
         return [(int(re.search(r"\.vgpr_count:\s+(\d+)", b).group(1)), int(re.search(r"\.vgpr_spill_count:\s+(\d+)", b).group(1)),
                  int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", b).group(1))) for b in blk]
 
-    # (k_step_roles: the one-launch step -- dynamics, LiDAR and navigation + reward roles share its allocation)
+    # (k_step_roles: the one-launch step -- dynamics, LiDAR, navigation search and finish roles share its allocation)
     for vgpr, spill, lds_static in usage("k_step_roles") + usage("k23_lidar_nav"):
         assert vgpr <= 128, "LiDAR kernel needs %d VGPRs: fewer than 4 waves per SIMD" % vgpr
         assert spill <= 4, "LiDAR kernel spills %d VGPRs to scratch" % spill

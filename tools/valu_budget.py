@@ -31,7 +31,7 @@ LEVELS = [
     (0, 1, "+ LiDAR E: returns (sqrt, log, exp)"),
     (0, 2, "+ navigation: chunk circles, hint chunk, survivor list"),
     (0, 3, "+ navigation: exact distances, (distance, index) reduction"),
-    (0, 0, "+ navigation: spline evaluation, atan2, features, path reward  (= everything again)"),
+    (0, 0, "+ navigation tail (finish role, eight environments per wave): spline evaluation, atan2, features, path reward  (= everything again)"),
 ]
 WARMUP = int(os.environ.get("WARMUP", "1900"))
 GROUP = int(os.environ.get("GROUP", "16"))
