@@ -270,7 +270,7 @@ class BatchedAuvEnv:
     _MODE_NAMES = {v: k for k, v in STEP_MODES.items()}
 
     def set_step_mode(self, mode: str):
-        """"auto" (default): "one_launch" below 16384 environments per launch, "side_by_side" from there on;
+        """"auto" (default): "one_launch" below 65536 environments per launch, "side_by_side" from there on;
         "one_launch": dynamics, LiDAR sweep, navigation search and finish (navigation tail + reward phase) as four roles of
         ONE launch; "side_by_side": K1 ->
         [K2 + K3-nav in one launch] -> K3-reward.  The same bits (tests/test_gpu_parity.py::test_step_modes_agree_bitwise).

@@ -81,10 +81,12 @@ struct auv_handle {
   GenOut gen;
 };
 
-// From how many environments per launch on the three-launch shape is used by AUV_STEP_AUTO: with eight rounds of
-// waves per slot nothing is gained by hiding a launch boundary, and the polling costs a little (DESIGN.md section 4:
-// 141 M against 139.6 M env-steps/s at 32768 environments)
-#define AUV_AUTO_THREE_LAUNCHES_FROM 16384
+// From how many environments per launch on the three-launch shape is used by AUV_STEP_AUTO.  With the four-role step
+// the one launch is ahead at every size measured (one chain, tools/auto_threshold.sh: 139.3 against 129.5 M env-steps/s
+// at 8192 environments per launch, 149.1 / 141.4 M at 16384, 149.9 / 145.8 M at 32768): the margin halves with every
+// doubling -- many rounds of waves per slot leave little to gain by hiding a launch boundary -- so beyond what was
+// measured the fence-free shape is the default.  (With three roles the crossover was at 16384.)
+#define AUV_AUTO_THREE_LAUNCHES_FROM 65536
 
 // The shape a step of `ne` environments is actually launched in: the requested one, degraded to the fence-free
 // three-launch shape where the in-launch hand-overs may not be used (probe failed / a poll timed out / no LiDAR).

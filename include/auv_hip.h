@@ -242,8 +242,9 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
 int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
 
 /* How auv_step / auv_step_slice / auv_graph_capture run a step (same results, bit for bit):
- *   AUV_STEP_AUTO (default)          AUV_STEP_ONE_LAUNCH for launches of fewer than 16384 environments,
- *                                    AUV_STEP_SIDE_BY_SIDE from there on (where it is the faster one).
+ *   AUV_STEP_AUTO (default)          AUV_STEP_ONE_LAUNCH for launches of fewer than 65536 environments,
+ *                                    AUV_STEP_SIDE_BY_SIDE from there on (beyond the sizes the one launch was
+ *                                    measured ahead at).
  *   AUV_STEP_ONE_LAUNCH              the whole step in ONE launch of one-wave workgroups with four roles: the
  *                                    first n / 8 integrate the dynamics (K1, eight environments per wave), the
  *                                    next n sweep the LiDAR of one environment each (K2), the next n search the

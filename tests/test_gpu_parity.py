@@ -18,7 +18,7 @@ from helpers import cfg_from_scalars, load, scene_order, scene_world
 pytestmark = pytest.mark.gpu
 
 ATOL = 1e-9
-AUTO_SMALL = "one_launch"    # what AUV_STEP_AUTO picks below 16384 environments per launch
+AUTO_SMALL = "one_launch"    # what AUV_STEP_AUTO picks below 65536 environments per launch
 
 
 def _env(cfg, bank, n, **kw):
@@ -369,7 +369,7 @@ def test_shipped_library_has_no_test_hooks(monkeypatch):
 
 def test_probe_health_and_mode_selection():
     """Every bank load probes the dispatch order the in-launch hand-overs rely on; on this hardware it passes, the
-    default mode then is the one-launch shape below 16384 environments per launch and the three-launch shape from
+    default mode then is the one-launch shape below 65536 environments per launch and the three-launch shape from
     there on; the removed shapes are rejected."""
     import ctypes as C
     from gym_auv_amd.batched_env import _LIB
@@ -377,7 +377,7 @@ def test_probe_health_and_mode_selection():
     env = _env(effective_reference_config(use_lidar=True), bank, 16)
     assert env.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0)
     assert env.step_mode == "auto" and env.effective_step_mode() == AUTO_SMALL
-    assert env.effective_step_mode(16383) == AUTO_SMALL and env.effective_step_mode(16384) == "side_by_side"
+    assert env.effective_step_mode(65535) == AUTO_SMALL and env.effective_step_mode(65536) == "side_by_side"
     for removed in (1, 2, 3, 4, 7, -1):
         assert _LIB.auv_set_step_mode(env._h, removed) != 0
     nol = _env(effective_reference_config(use_lidar=False), bank, 16)      # no sweep, nothing to hand over
