@@ -441,7 +441,10 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     // (The SIMD's arbiter favours its oldest wave: at equal work the sweeps dispatched last take half as long again as
     // the first, 17 against 12 us, and end the launch -- tools/phase_stamps3.py.  A priority graded by workgroup index
     // evens that out and LOSES 1-2 % either way round: the early finishers make room for navigation waves, whose
-    // memory latency then hides behind the late sweeps' arithmetic.)
+    // memory latency then hides behind the late sweeps' arithmetic.  With four roles: a sweep that is behind schedule
+    // raising its own priority -- clock read after the front and after the pair sweep, s_setprio 2 beyond 4 / 8 or
+    // 5.5 / 11 us since the state arrived -- changes nothing, 135.3-135.9 against 135.6-136.4 M with four chains: the
+    // stragglers are not short of issue slots.)
     // while the dynamics role integrates: everything of the sweep that does not need the vessel's new state --
     // descriptor and counters (written by earlier launches), the movers' kinematics, the obstacle records
 #ifdef AUV_STAMPS
