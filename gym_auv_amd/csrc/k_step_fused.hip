@@ -55,6 +55,9 @@ namespace {
 //     every role starts at a multiple of 8 and the dynamics / finish waves take the environments of their own
 //     XCD), which keeps the words in one L2; correctness does not depend on it (tests run with the roles skewed
 //     onto different XCDs).
+//     (Plain stores for the sweep's rows -- complete when the XCD's own L2 has them, which is enough when the
+//     finish wave runs on the same XCD -- were measured: +0.6 % with four chains, +1.3 % with one; not worth making
+//     correctness depend on the workgroup -> XCD mapping.)
 //   * whoever polls, polls for a word of a workgroup with a SMALLER index in the same launch: that one was
 //     dispatched earlier and finishes without needing anything from a later one.  The polls are bounded all the
 //     same: when one runs out the wave reports through `pair_error` (the next call recovers and reports) instead
@@ -468,7 +471,13 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #endif
     int n_act = 0;
     if (AUV_RUN_L(d, 1)) n_act = k2_front<true>(d, e, lane, L, 1, &pre, 1, &kp, true);
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 8] = wall_clock64();      // front (B0, B, C) done
+#endif
     if (AUV_RUN_L(d, 3)) k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
+#ifdef AUV_STAMPS
+    if (lane == 0) d.stamps[(size_t)e * 16 + 11] = wall_clock64();     // staging + pair sweep (S, D) done
+#endif
     double term = 0.0;
     const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term);
 #ifdef AUV_STAMPS
