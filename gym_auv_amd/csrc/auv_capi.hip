@@ -343,7 +343,8 @@ static int recover_from_timeout(auv_handle* h) {
   return fail(AUV_ESTATE, "in-launch hand-over timed out (%s): steps since then were incomplete, so EVERY environment has been put "
                           "back into its reset state; the handle steps in the three-launch shape from now on (no in-launch "
                           "hand-over) and this error is reported once -- carry on with reset observations",
-              code == 2 ? "a wave waited in vain for the dynamics role's state" : "a navigation wave waited in vain for its sweep");
+              code == 2 ? "a sweep or search wave waited in vain for the dynamics role's state"
+                        : (code == 3 ? "a finish wave waited in vain for a state packet or a search record" : "a finish wave waited in vain for a sweep's word"));
 }
 
 extern "C" {
@@ -876,7 +877,7 @@ int auv_diag_cuts(auv_handle_t* h, int32_t cut_lidar, int32_t cut_nav) {
 #ifdef AUV_TEST_HOOKS
 // Only in libauv_hip_hooks.so (make hooks): skew = idle workgroups between the roles of the one-launch
 // shapes (an environment's waves then sit on different XCDs); fault = 1: the sweep of the first environment of every
-// launch never publishes its word, so the navigation wave's poll runs out.
+// launch never publishes its word, so the finish wave's poll runs out.
 int auv_test_hooks(auv_handle_t* h, int32_t skew, int32_t fault) {
   if (!h) return fail(AUV_EINVAL, "null handle");
   h->d.pair_skew = (skew > 0 && skew < 8) ? skew : 0;
