@@ -354,8 +354,13 @@ def main():
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     torch.cuda.synchronize(dev)
-    D.barrier()
+    # every rank reads its clock when ITS steps are complete, then all meet at the closing barrier and the slowest rank's
+    # time counts (max over ranks).  Reading the clock behind the barrier instead would add one RCCL barrier (tens of
+    # microseconds over xGMI) to every rank's time -- a tenth of the driver's 0.7 ms window of 20 steps, and nothing
+    # the step path does: the path has no collective.
     elapsed = time.perf_counter() - t0
+    D.barrier()
+    torch.cuda.synchronize(dev)
     elapsed = D.max_over_ranks(elapsed, dev)
     # the only exchange of the path: episode returns for reporting, RCCL all_gather over xGMI
     stats = D.gather_episode_stats(env.episode_stats())
