@@ -140,10 +140,11 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
 //                dynamics -- evaluate the navigation's scalar tail and run the reward phase (see there).
 //                The sweep, the search and the finish need the state the dynamics role produces in the same launch:
 //                it hands each environment a 64-byte packet (x, y, psi, u, v, r, the vessel's step counter, a "ready"
-//                mark that is also a checksum), stored write-through and completed before the mark is stored; the
-//                other roles poll for the mark (the dynamics workgroups have the smallest indices, are dispatched
-//                first and wait for nobody; every poll is bounded).  The search leaves its result in a record of the
-//                same kind (NAV_HAND), the sweep its word.  The finish wave takes all three marks away again when it
+//                mark that is also a checksum of the rest), written through (sc1) by ONE store instruction -- and that
+//                is all the dynamics role stores: the STATE rows and the vessel's step counter are written from the
+//                packet by the finish wave.  The other roles poll for a mark that matches the payload (the dynamics
+//                workgroups have the smallest indices, are dispatched first and wait for nobody; every poll is
+//                bounded).  The search leaves its result in a record of the same kind (NAV_HAND), the sweep its word.  The finish wave takes all three marks away again when it
 //                has finished the environment's step (the environment's other waves are gone by then: it has seen
 //                what each of them stores last), so the next launch finds every mark down.  What is saved against
 //                separate launches is the launch ramps and the kernel boundaries between them.  No launch argument
@@ -233,13 +234,14 @@ __device__ __forceinline__ void roles_publish_search(const AuvDev& d, const int 
   const unsigned long long w0 = (unsigned long long)__double_as_longlong(nr.A.x), w1 = (unsigned long long)__double_as_longlong(nr.A.y),
                            w2 = (unsigned long long)__double_as_longlong(nr.B.x), w3 = (unsigned long long)__double_as_longlong(nr.B.y),
                            w4 = (unsigned long long)__double_as_longlong(nr.cum);
+  // (the mark goes out right behind the payload, not after its completion: it is a checksum of the payload, so a reader
+  // that sees it ahead of a payload word polls again -- this wave stores nothing else)
   if (lane == 0) {
     __hip_atomic_store(h + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(h + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(h + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(h + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(h + 4, w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h + 7, roles_mark(w0 ^ w1 ^ w2 ^ w3 ^ w4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  auv_stores_done();
-  if (lane == 0) __hip_atomic_store(h + 7, roles_mark(w0 ^ w1 ^ w2 ^ w3 ^ w4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // word `src` of the caller's group of eight lanes
@@ -281,6 +283,8 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
   unsigned long long* const nav_hand = dc->nav_hand;
   const EnvDesc* const env_desc = dc->env_desc;
   const double* const world_scalar = dc->world_scalar;
+  double* const state = dc->state;
+  const int n_envs = dc->n;
   const int ne = dk.ne, e0 = dk.e0;
   const int g = lane / K1_GROUP, c = lane % K1_GROUP;
   const int er = 8 * (8 * (f / 8) + g) + (f % 8);                 // the dynamics role's mapping
@@ -323,6 +327,8 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
   t.px = roles_group_value(vp, 0), t.py = roles_group_value(vp, 1), t.psi = roles_group_value(vp, 2);
   t.u = roles_group_value(vp, 3), t.v = roles_group_value(vp, 4), t.r = roles_group_value(vp, 5);
   cnt.y = (int)(unsigned)roles_group_word(vp, 6);                 // the vessel's step counter of this launch
+  // STATE rows of the new state (the dynamics role leaves only the packet): lane c of a group holds component c
+  if (live && c < 6) state[(size_t)c * (size_t)n_envs + e] = __longlong_as_double((long long)vp);
   t.nr.A = make_double2(roles_group_value(vh, 0), roles_group_value(vh, 1));
   t.nr.B = make_double2(roles_group_value(vh, 2), roles_group_value(vh, 3));
   t.nr.cum = roles_group_value(vh, 4);
@@ -406,17 +412,19 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     const int er = 8 * (8 * (b / 8) + g) + (b % 8);
     const bool live = er < ne;
     const int eg = d.e0 + (live ? er : ne - 1);                     // idle groups compute along, store nothing
-    const size_t n = (size_t)d.n;
     const int y = d.counters[eg].y + 1;                             // Vessel._step_counter (vessel.py:247); requested up front
     const double t = k1_group(d, actions, eg, lane);
     unsigned long long* pk = d.k1_pkt + 8 * (size_t)eg;
     const unsigned long long word = c < 6 ? (unsigned long long)__double_as_longlong(t) : (c == 6 ? (unsigned long long)(unsigned)y : 0ull);
     const unsigned long long mark = roles_mark(roles_group_xor(word));
-    if (live && c < 6) auv_st<true>(&d.state[(size_t)c * n + eg], t);
-    if (live && c < 7) __hip_atomic_store(pk + c, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (live && c == 6) __hip_atomic_store(&d.counters[eg].y, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    auv_stores_done();
-    if (live && c == 7) __hip_atomic_store(pk + 7, mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The packet is ALL this role stores: payload and mark in ONE store instruction, 64 contiguous bytes per group, and
+    // the wave does not wait for it.  The mark is a checksum of the payload, so a reader that sees the mark before all
+    // of the payload (should the request ever be served in pieces) just polls again.  STATE and the vessel's step
+    // counter are written by the finish wave from the packet (roles_finish_wave) -- the wave that may also overwrite
+    // them when the episode ends, so the two stores are ordered by ITS program order, not by a wait here -- and the
+    // 0.5-1 us this wave used to wait for its write-through stores before raising the mark are off the head of the
+    // launch that everybody else waits for.
+    if (live) __hip_atomic_store(pk + c, c < 7 ? word : mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // a captured graph's action ring: every dynamics wave has read the position before it counts itself off, so
     // the last one to do so may move it on
     if (d.ring_slots > 1 && d.ring_slot_host == -1 && lane == 0) {
