@@ -1,7 +1,9 @@
 """One-off long parity soak on the GPU box: E envs x T steps of the mixed world with auto-reset, HIP path against the
 CPU oracle, integer fields bit for bit EVERY step (cull limits, nearby flags, collision, done, world binding), fp64
 fields every 25th step.  Counts what was compared.  usage: python tools/soak.py [envs] [steps] [mode] [sub-batches]
-(sub-batches > 1: the batch is stepped as that many chains on their own streams, BatchedAuvEnv.step_async / step_wait)"""
+(sub-batches > 1: the batch is stepped as that many chains on their own streams, BatchedAuvEnv.step_async / step_wait;
+SKEW=k in the environment + AUV_HIP_LIB=.../libauv_hip_hooks.so: the one-launch step's roles k workgroups apart, i.e. an
+environment's waves on different XCDs)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -27,6 +29,11 @@ env = BatchedAuvEnv(cfg, bank, E, device="cuda:0", auto_reset=True)
 env.set_step_mode(mode)
 if SUB > 1:
     env.set_sub_batches(SUB)
+if os.environ.get("SKEW"):
+    # roles skewed onto different XCDs: needs the hook build (AUV_HIP_LIB=gym_auv_amd/csrc/libauv_hip_hooks.so)
+    from gym_auv_amd.batched_env import _LIB, _check
+    _check(_LIB.auv_test_hooks(env._h, int(os.environ["SKEW"]), 0), "auv_test_hooks")
+    print("roles skewed by %s workgroups (hook build)" % os.environ["SKEW"], flush=True)
 ora = pyoracle.Oracle(make_config(cfg, auto_reset=True), E, bank)
 pyoracle.set_threads(min(16, os.cpu_count() or 1))
 env.reset(), ora.reset()
