@@ -680,7 +680,7 @@ static int enqueue_step(auv_handle_t* h, int mode, int e0, int ne, const void* a
   if (!capturing) d.ring_slots = 1;
   d.e0 = e0, d.ne = ne;
   if (mode == AUV_STEP_ONE_LAUNCH) {
-    // dynamics, LiDAR and navigation + reward as three roles of ONE launch (csrc/k_step_fused.hip: k_step_roles;
+    // dynamics, LiDAR sweep, navigation search and finish as four roles of ONE launch (csrc/k_step_fused.hip: k_step_roles;
     // inside a captured graph its dynamics role advances the action ring)
     auv_launch_step_roles(d, actions, dtype, obs, reward, done, st);
     return AUV_OK;

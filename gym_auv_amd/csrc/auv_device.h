@@ -81,8 +81,8 @@ struct AuvDev {
   unsigned int* ep_log_count;  // [1] episodes logged so far (the ring position is count % cap)
   int32_t ep_log_cap;
   double* step_info;   // [N][4] info of the last step (terminal values survive an auto-reset)
-  unsigned long long* pair_word; // [N] one-launch step: what the LiDAR wave leaves for the navigation wave (k_step_fused.hip)
-  int32_t* pair_error; // [1] one-launch step: set when a navigation wave gave up waiting for its sweep
+  unsigned long long* pair_word; // [N] one-launch step: what the LiDAR wave leaves for the finish wave (k_step_fused.hip)
+  int32_t* pair_error; // [1] one-launch step: set when a wave gave up polling for a hand-over (1 sweep's word, 2 state packet, 3 packet / search record)
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   unsigned long long* nav_hand; // [N][8] one-launch step: the nearest path segment the navigation role's search hands to the finish role
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position

@@ -640,7 +640,7 @@ void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0,
   hipExtLaunchKernelGGL(k23_lidar_nav, dim3(2 * d.ne), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs);
 }
 
-// ---- the one-launch step (needs a LiDAR sweep: its word is what the navigation wave finishes the step on) ----
+// ---- the one-launch step (needs a LiDAR sweep: its word is what the finish wave finishes the step on) ----
 bool auv_roles_ok(const AuvDev& d) { return auv_k23_ok(d) && d.cfg.use_lidar; }
 
 void auv_launch_step_roles(const AuvDev& d0, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,

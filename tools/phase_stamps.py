@@ -42,7 +42,7 @@ for ci, (lo, cnt) in enumerate(env._slices):
     k1, l0, lp, ls, l1, l2 = s[:, 0], s[:, 3], s[:, 1], s[:, 2], s[:, 4], s[:, 14]
     n0, ns, n1, n2 = s[:, 12], s[:, 5], s[:, 13], s[:, 15]
     base = l0.min()
-    print("chain %d: envs [%d, %d), launch span %.1f us (first LiDAR wave start .. last navigation wave end)" % (ci, lo, lo + cnt, (n2.max() - base) / 100.0))
+    print("chain %d: envs [%d, %d), launch span %.1f us (first LiDAR wave start .. last environment finished)" % (ci, lo, lo + cnt, (n2.max() - base) / 100.0))
     f("dynamics: state published (us)", k1 - base)
     f("LiDAR start offsets (us)", l0 - base)
     f("LiDAR pre-work done (us)", lp - base)
