@@ -876,12 +876,12 @@ int auv_diag_cuts(auv_handle_t* h, int32_t cut_lidar, int32_t cut_nav) {
 
 #ifdef AUV_TEST_HOOKS
 // Only in libauv_hip_hooks.so (make hooks): skew = idle workgroups between the roles of the one-launch
-// shapes (an environment's waves then sit on different XCDs); fault = 1: the sweep of the first environment of every
-// launch never publishes its word, so the finish wave's poll runs out.
+// shapes (an environment's waves then sit on different XCDs); fault: the first environment of every launch never gets
+// its sweep's word (1), its state packet (2) or its search record (3), so the polls that wait for them run out.
 int auv_test_hooks(auv_handle_t* h, int32_t skew, int32_t fault) {
   if (!h) return fail(AUV_EINVAL, "null handle");
   h->d.pair_skew = (skew > 0 && skew < 8) ? skew : 0;
-  h->d.pair_fault = fault == 1 ? 1 : 0;
+  h->d.pair_fault = (fault >= 1 && fault <= 3) ? fault : 0;
   if (h->d.self) HIP_TRY(hipMemcpy((void*)h->d.self, &h->d, sizeof(AuvDev), hipMemcpyHostToDevice));
   return AUV_OK;
 }

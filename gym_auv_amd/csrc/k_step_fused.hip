@@ -27,7 +27,9 @@
 
 // Test hooks (tests/test_gpu_parity.py) exist only in the library built with -DAUV_TEST_HOOKS (make hooks ->
 // libauv_hip_hooks.so): idle workgroups between the roles (puts an environment's waves on different XCDs) and a
-// sweep that never publishes its word (the poll must run out and fail loudly).  The shipped library has neither.
+// hand-over that never happens for the first environment of the launch (fault 1: its sweep withholds the word; 2: the
+// dynamics role withholds its state packet; 3: its search withholds the record) -- the polls must run out and fail
+// loudly.  The shipped library has neither.
 #ifdef AUV_TEST_HOOKS
 #define AUV_HOOK_SKEW(d) ((d).pair_skew)
 #define AUV_HOOK_FAULT(d) ((d).pair_fault)
@@ -69,7 +71,7 @@ namespace {
 __device__ __forceinline__ void pair_publish_lidar(const AuvDev& d, const int e, const int lane, const int collision,
                                                    const double term) {
   auv_stores_done();                                       // of every lane of this wave (one counter per wave)
-  if (AUV_HOOK_FAULT(d) && e == d.e0) return;              // (test hook: the poll's time-out)
+  if (AUV_HOOK_FAULT(d) == 1 && e == d.e0) return;         // (test hook: the poll's time-out)
   if (lane == 0)
     __hip_atomic_store(d.pair_word + e, collision ? PAIR_COLLISION : (unsigned long long)__double_as_longlong(term),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -201,7 +203,7 @@ __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, c
       for (int i = 1; i < 7; i++) x ^= roles_lane_word(v, i);
       if (roles_mark(x) == got) break;                       // mark and payload belong together
     }
-    if (polls == PAIR_POLL_LIMIT) {
+    if (polls == (AUV_HOOK_FAULT(d) ? (1 << 12) : PAIR_POLL_LIMIT)) {
       if (lane == 0) __hip_atomic_store(d.pair_error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return false;
     }
@@ -236,6 +238,7 @@ __device__ __forceinline__ void roles_publish_search(const AuvDev& d, const int 
                            w4 = (unsigned long long)__double_as_longlong(nr.cum);
   // (the mark goes out right behind the payload, not after its completion: it is a checksum of the payload, so a reader
   // that sees it ahead of a payload word polls again -- this wave stores nothing else)
+  if (AUV_HOOK_FAULT(d) == 3 && e == d.e0) return;         // (test hook: the finish wave's time-out)
   if (lane == 0) {
     __hip_atomic_store(h + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(h + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(h + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(h + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -425,7 +428,8 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     // them when the episode ends, so the two stores are ordered by ITS program order, not by a wait here -- and the
     // 0.5-1 us this wave used to wait for its write-through stores before raising the mark are off the head of the
     // launch that everybody else waits for.
-    if (live) __hip_atomic_store(pk + c, c < 7 ? word : mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (live && !(AUV_HOOK_FAULT(d) == 2 && eg == d.e0))       // (test hook: nobody gets the first environment's state)
+      __hip_atomic_store(pk + c, c < 7 ? word : mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // a captured graph's action ring: every dynamics wave has read the position before it counts itself off, so
     // the last one to do so may move it on
     if (d.ring_slots > 1 && d.ring_slot_host == -1 && lane == 0) {

@@ -72,10 +72,10 @@ def main():
 
     # ---- a poll that runs out: the launch ENDS, the next call reports it once, every environment is back in its
     # reset state, the handle goes on in the three-launch shape -- bit for bit what a fresh handle does from reset
-    for mode in ("one_launch",):
+    for mode, fault in (("one_launch", 1), ("one_launch", 2), ("one_launch", 3)):   # sweep's word / state packet / search record withheld
         n = 64
         cfg = effective_reference_config(use_lidar=True)
-        env = env_(cfg, n, mode, fault=1)
+        env = env_(cfg, n, mode, fault=fault)
         a = torch.zeros((n, 2), dtype=torch.float32, device="cuda:0")
         h0 = env.health()
         env.step(a)                                  # the faulty launch itself is enqueued normally ...
@@ -96,7 +96,7 @@ def main():
             torch.cuda.synchronize()
             ok = ok and torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1)
         ok = ok and all(torch.equal(ref.read(f), env.read(f)) for f in ("STATE", "LIDAR_D", "OBS64", "NAV64", "MOVER_STATE", "NEARBY", "CULL_LIMITS"))
-        print(json.dumps(dict(case="fault", mode=mode, before=h0, after_launch=h1, after_recovery=h2, message=msg,
+        print(json.dumps(dict(case="fault", mode=mode, fault=fault, before=h0, after_launch=h1, after_recovery=h2, message=msg,
                               reset_state_equal=bool(same_reset), continues_bitwise=bool(ok),
                               effective=env.effective_step_mode())), flush=True)
         ref.close(), env.close()

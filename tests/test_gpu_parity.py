@@ -330,12 +330,13 @@ def hook_cases():
 def test_hook_build_cases(hook_cases):
     """(a) hand-overs across XCDs: with three idle workgroups between the roles an environment's waves sit on
     different XCDs, so the packet, the word and the restore rows cross L2s -- still bit for bit the three-launch shape.
-    (b) the waits inside the one-launch step are bounded: with one sweep withholding its word its navigation
-    wave gives up, the launch ENDS, the next call raises once ("timed out") having put every environment back into
+    (b) the waits inside the one-launch step are bounded: with one sweep withholding its word, the dynamics role one
+    state packet or one search its record, the waves that poll for it give up, the launch ENDS, the next call raises once ("timed out") having put every environment back into
     its reset state, and the handle carries on in the three-launch shape, bit for bit what a fresh handle does."""
     skew = [c for c in hook_cases if c["case"] == "skew"]
     fault = [c for c in hook_cases if c["case"] == "fault"]
     assert {c["mode"] for c in skew} == {"one_launch"} and {c["mode"] for c in fault} == {"one_launch"}
+    assert sorted(c["fault"] for c in fault) == [1, 2, 3]       # the sweep's word, the state packet, the search record withheld
     for c in skew:
         assert c["bitwise"] and c["n_done"] >= 10 * c["n"] and c["effective"] == c["mode"], c
     for c in fault:
