@@ -77,12 +77,26 @@ def parse():
                          "own (auv_step_pipelined); the chains overlap on the GPU -- same envs, same results, bit for bit.  "
                          "0 (default): 4 (the four compute pipes of the chip) when the rank has >= 2048 envs and the step "
                          "is launched eagerly from resident actions, else 1")
+    ap.add_argument("--api", default="auto", choices=["auto", "pipelined", "async", "step"],
+                    help="how the timed loop drives the env.  pipelined: open loop, auv_step_pipelined (the chains are not ordered "
+                         "against each other or a consumer); async: VecEnv step_async + step_wait EVERY step (a full rendezvous of "
+                         "all chains with the caller's stream, scripts/run.py:293-296); step: env.step() on the caller's stream "
+                         "(one chain).  auto: pipelined for resident actions with sub-batches > 1, else step")
+    ap.add_argument("--rendezvous", default="events", choices=["events", "device", "cp"],
+                    help="--api async: how the chains are ordered against the caller's stream (include/auv_hip.h, AUV_RDV_*)")
+    ap.add_argument("--inline-first", type=int, default=0,
+                    help="--api async: 1 = the first sub-batch runs on the caller's stream, only the others on streams of their own")
+    ap.add_argument("--one-graph", type=int, default=0,
+                    help="--graph K with sub-batches > 1: 0 = one linear graph per chain on the chain's stream, 1 = ONE graph with a branch per chain")
     ap.add_argument("--probe-streams", type=int, default=1,
                     help="0: take any K streams for the sub-batch chains instead of K that were measured to run side by side "
                          "(for runs under a counter-collecting profiler, which serialises dispatches)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--procs", type=int, default=0, help="world-generation worker processes (0 = auto)")
-    ap.add_argument("--bank-cache", default="", help="path prefix: save/load the generated world bank (.npz)")
+    ap.add_argument("--bank-cache", default="auto",
+                    help="path prefix: save / load the rank's generated world bank (.npz, keyed by workload, shard and bank size).  "
+                         "'auto' (default): under the system temp directory, so that a repeated run (the driver benches N = 1, 2, 4, 8 "
+                         "back to back) does not regenerate 8192 worlds per rank; '' = never cache")
     ap.add_argument("--rehearse", type=int, default=0,
                     help="1: allow more ranks than visible GPUs (ranks share devices, gloo instead of RCCL); the line "
                          "then reports n_gpus = distinct physical devices, not ranks")
@@ -262,14 +276,33 @@ def main():
         return
     procs = args.procs or max(1, min(16, host_cores() // max(1, world)))
     t0 = time.time()
-    cache = args.bank_cache and "%s.%s.%d.%d.%d.%d.npz" % (args.bank_cache, args.workload, lo, n_local, n_local * world, wpe)
+    cache = ""
+    if args.bank_cache:
+        import hashlib
+        import tempfile
+        # the key names everything the bank depends on: workload, shard, bank size and the generator's own source
+        src = hashlib.sha256()
+        for mod in ("scenarios.py", "world.py", "obstacles.py", "path.py", "worldspec.py", "seeding.py"):
+            src.update(open(os.path.join(ROOT, "gym_auv_amd", mod), "rb").read())
+        prefix = os.path.join(tempfile.gettempdir(), "auv_bench_bank") if args.bank_cache == "auto" else args.bank_cache
+        cache = "%s.%s.%d.%d.%d.%d.%s.npz" % (prefix, args.workload, lo, n_local, n_local * world, wpe, src.hexdigest()[:12])
+    bank, bank_from_cache = None, False
     if cache and os.path.exists(cache):
-        z = np.load(cache)
-        bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
-    else:
+        try:
+            z = np.load(cache)
+            bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
+            bank_from_cache = True
+        except Exception:
+            bank = None                                    # (a torn file of an interrupted run: regenerate)
+    if bank is None:
         bank = build_bank_parallel(gen, seeds, procs=procs, **kwargs)
         if cache:
-            np.savez(cache, **bank)
+            try:
+                tmp = "%s.%d.tmp.npz" % (cache, os.getpid())
+                np.savez(tmp, **bank)
+                os.replace(tmp, cache)                     # (atomic: another rank or run never reads half a file)
+            except OSError:
+                pass
     t_gen = time.time() - t0
 
     from gym_auv_amd import distributed as D
@@ -291,50 +324,81 @@ def main():
     env.reset()
     K = max(0, args.graph)
     sub = args.sub_batches
+    api = args.api
+    if api == "auto":
+        api = "step" if (args.actions == "pilot" and sub <= 1) else "pipelined"
     if sub <= 0:
-        sub = 4 if (n_local >= 2048 and not K and args.actions == "uniform" and
-                    env.effective_step_mode(n_local // 4) == "one_launch") else 1
-    if K:
+        want4 = n_local >= 2048 and env.effective_step_mode(n_local // 4) == "one_launch"
+        sub = 4 if (want4 and api in ("pipelined", "async") and args.actions == "uniform") else 1
+    if api == "step":
         sub = 1
+    t_probe = 0.0
+    if sub > 1:
+        # fewer streams side by side than chains asked for would silently time a different shape: fail instead
+        env.set_sub_batches(sub, probe_streams=bool(args.probe_streams), inline_first=bool(args.inline_first and api == "async"),
+                            strict=bool(args.probe_streams))
+        t_probe = env.stream_probe_s
+    elif api == "async":
+        env.set_sub_batches(1, inline_first=bool(args.inline_first))
+    env.rendezvous = args.rendezvous
+    act = torch.ones((n_local, 2), dtype=torch.float32, device=dev)
+
+    def pilot_all():
+        # look-ahead pilot: full thrust, rudder proportional to the heading error (observation column 4, already clipped
+        # to +-1 rad): a tiny torch kernel per step on the caller's stream, all on the device
+        torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
+
     if K:
         # the 64 pre-generated action batches become the action ring of the captured steps: a replay consumes
         # the next K slots, nothing is copied or re-bound in the timed loop.  Steps beyond a multiple of K are
         # launched eagerly from the pool (eager launches never touch the ring).
         if n_pool % K and K % n_pool:
             raise SystemExit("--graph K: K must divide %d (the action pool) or be a multiple of it" % n_pool)
-        ring = env.capture_graph(torch.float32, slots=n_pool, steps=K)
+        if args.actions != "uniform":
+            raise SystemExit("--graph replays open-loop stretches: --actions uniform")
+        if sub > 1:
+            # captured CHAINS: K steps of every sub-batch per replay, each chain with its own position in the ring
+            ring = env.capture_graph_chains(torch.float32, slots=n_pool, steps=K, one_graph=bool(args.one_graph))
+            if args.steps % K or args.warmup % K:
+                raise SystemExit("--graph K with sub-batches: --steps and --warmup must be multiples of K (every chain keeps "
+                                 "its own ring position; eager steps in between would not advance it)")
+        else:
+            ring = env.capture_graph(torch.float32, slots=n_pool, steps=K)
         ring.copy_(pool)
+        api = "graph"
 
         def run(i0, n):
             for _ in range(n // K):
                 env.step_graph()
             for i in range(n % K):
                 env.step(pool[(i0 + i) % n_pool])
-    elif args.actions == "pilot":
-        act = torch.ones((n_local, 2), dtype=torch.float32, device=dev)
-
-        if sub > 1:
-            env.set_sub_batches(sub, probe_streams=bool(args.probe_streams))
-            sub = env.sub_batches
-
+    elif api == "async":
+        # VecEnv protocol, a FULL rendezvous per step: every chain waits for the caller's stream, the caller's stream for
+        # every chain (scripts/run.py:293-296: SubprocVecEnv.step_async / step_wait)
         def run(i0, n):
-            # look-ahead pilot: full thrust, rudder proportional to the heading error (observation
-            # column 4, already clipped to +-1 rad): a tiny torch kernel per step, all on the device.  With sub-batches the
-            # pilot of a sub-batch runs on that sub-batch's stream, so the chains stay independent of each other (a
-            # per-step step_async / step_wait over all chains costs two cross-stream waits per chain and step: 37 M)
-            for _ in range(n):
-                if sub > 1:
-                    for i, (lo, cnt) in enumerate(env._slices):
-                        with torch.cuda.stream(env._sub_streams[i]):
-                            torch.mul(env.obs[lo:lo + cnt, 4], 0.15, out=act[lo:lo + cnt, 1])
-                        env.step_slice(i, act)
+            for i in range(n):
+                if args.actions == "pilot":
+                    pilot_all()
+                    env.step_async(act)
                 else:
-                    torch.mul(env.obs[:, 4], 0.15, out=act[:, 1])
-                    env.step(act)
+                    env.step_async(pool[(i0 + i) % n_pool])
+                env.step_wait()
+    elif args.actions == "pilot" and sub > 1:
+        def run(i0, n):
+            # the pilot of a sub-batch runs on that sub-batch's stream, so the chains stay independent of each other: a
+            # caller restructured around the chains (examples/ppo.py), NOT the VecEnv protocol
+            for _ in range(n):
+                for i, (lo, cnt) in enumerate(env._slices):
+                    with torch.cuda.stream(env._sub_streams[i]):
+                        torch.mul(env.obs[lo:lo + cnt, 4], 0.15, out=act[lo:lo + cnt, 1])
+                    env.step_slice(i, act)
+        api = "per_chain_pilot"
+    elif args.actions == "pilot":
+        def run(i0, n):
+            for _ in range(n):
+                pilot_all()
+                env.step(act)
     elif sub > 1:
-        env.set_sub_batches(sub, probe_streams=bool(args.probe_streams))
-        sub = env.sub_batches          # (fewer if the device does not run that many streams side by side)
-
         def run(i0, n):
             # K independent launch chains: sub-batch s of step i goes to stream s; nothing orders the chains against
             # each other (the actions are resident), the synchronize() around the timed region waits for all of them
@@ -346,6 +410,7 @@ def main():
         def run(i0, n):
             for i in range(n):
                 env.step(pool[(i0 + i) % n_pool])
+    sub = env.sub_batches if env._slices is not None else 1
 
     run(0, args.warmup)
     torch.cuda.synchronize(dev)
@@ -366,6 +431,10 @@ def main():
     stats = D.gather_episode_stats(env.episode_stats())
     total_envs = n_local * world
     value = total_envs * args.steps / elapsed
+    if api == "pipelined" and sub == 1:
+        api = "step"
+    per_rank = D.gather_floats([t_gen, t_probe, float(bank_from_cache), float(sub)], dev)
+
     world_of_env = env.read("WORLD_IDX").cpu().numpy()
     nearby = env.read("NEARBY").cpu().numpy()
 
@@ -373,7 +442,7 @@ def main():
     n_prof = min(max(args.steps, 20), 100)
     alg = algorithmic_bytes(bank, S, world_of_env, nearby)
     step_bytes = sum(alg[ph] for ph in ("k1", "lidar", "nav", "reward"))
-    pipelined = sub > 1 and args.actions == "uniform" and env.effective_step_mode(max(1, n_local // sub)) == "one_launch"
+    pipelined = sub > 1 and env.effective_step_mode(max(1, n_local // sub)) == "one_launch"
     if pipelined:
         # every sub-batch launch stamped on its own stream while the other chains run beside it
         lms = np.zeros(env.sub_batches)
@@ -414,6 +483,40 @@ def main():
     else:
         achieved = per_kernel[dom]["achieved_GBs"]
     hbm_frac = round(achieved / HBM_PEAK_GBS, 4)
+
+    # ---- the same envs through the OTHER ways of driving them, beside the headline (rank 0 at N = 1; short, outside
+    # the timed region): the headline loop is open-loop chain throughput, a VecEnv consumer that waits for every step
+    # sees the rendezvous figure
+    comparison = None
+    if rank == 0 and world == 1 and args.actions == "uniform" and not K and args.steps >= 20:
+        n_cmp = 300
+
+        def rate(fn):
+            fn(40)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            fn(n_cmp)
+            torch.cuda.synchronize(dev)
+            return round(n_local * n_cmp / (time.perf_counter() - t1), 1)
+
+        def loop_step(n):
+            for i in range(n):
+                env.step(pool[i % n_pool])
+
+        def loop_async(n):
+            for i in range(n):
+                env.step_async(pool[i % n_pool])
+                env.step_wait()
+
+        comparison = dict(steps=n_cmp, one_chain_step=rate(loop_step))
+        if env._slices is None:
+            env.set_sub_batches(1, inline_first=True)
+        comparison["step_async_wait_%s_sub%d" % (env.rendezvous, env.sub_batches)] = rate(loop_async)
+        if sub > 1:
+            def loop_pipe(n):
+                for i in range(n):
+                    env.step_pipelined(pool[i % n_pool])
+            comparison["pipelined_sub%d" % sub] = rate(loop_pipe)
 
     lib_sha = library_sha256()
     cfg_key = "%s/sub%d" % (args.workload, sub)
@@ -458,19 +561,34 @@ def main():
                     step_bytes=int(step_bytes), concurrent_launches=sub if pipelined else 1, kernels=per_kernel,
                     lib_sha256=lib_sha)
 
+    loops = {"pipelined": "open loop: %d chains, no ordering between them or with a consumer (auv_step_pipelined)" % sub,
+             "step": "env.step() on the caller's stream, one launch per step",
+             "async": "VecEnv step_async + step_wait every step: a full rendezvous of %d chain(s) with the caller's stream (%s%s)"
+                      % (sub, args.rendezvous, ", first chain on the caller's stream" if args.inline_first else ""),
+             "graph": "open loop: %d captured step(s) per replay, %d chain(s)%s" % (K, sub, ", one graph" if (args.one_graph and sub > 1) else ""),
+             "per_chain_pilot": "closed loop PER CHAIN: %d chains, each with its pilot on its own stream (no rendezvous)" % sub}
+    shape = env.effective_step_mode(max(1, n_local // sub))
+    if K > 1 and sub == 1:
+        # a captured graph of several steps over the whole batch replays the three-launch shape with its fused
+        # reward + dynamics launch whatever the handle's mode is (include/auv_hip.h)
+        shape = "side_by_side+k31 (captured, %d steps per graph)" % K
+    cfg_out = dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
+                   parallelism="env-shard x%d (no step-path collective)" % world, ranks=world,
+                   hipgraph_steps=K, sub_batches=sub, api=api, loop=loops[api],
+                   step_mode=shape, roofline_step_mode=env.effective_step_mode(max(1, n_local // sub)), actions=args.actions,
+                   worlds_per_env=wpe, world_gen_s=round(t_gen, 1),
+                   # first contact with an 8-GPU node: what every rank spent before the timed region, and on what
+                   per_rank=dict(world_gen_s=[round(r[0], 1) for r in per_rank], stream_probe_s=[round(r[1], 2) for r in per_rank],
+                                 bank_from_cache=[int(r[2]) for r in per_rank], sub_batches=[int(r[3]) for r in per_rank]),
+                   collective_backend=D.backend_name(),
+                   episodes_finished=int(stats["episodes"].sum().item()))
+    if os.environ.get("AUV_HIP_LIB"):
+        cfg_out["lib_override"] = os.environ["AUV_HIP_LIB"]      # (the loader's A/B hook: say so when it is in use)
     out = dict(metric="env-steps/sec", value=round(value, 1), unit="env-steps/s", n_gpus=n_devices_used, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
-                           parallelism="env-shard x%d (no step-path collective)" % world, ranks=world,
-                           hipgraph_steps=K, sub_batches=sub,
-                           # the shape the TIMED loop ran: a captured graph of several steps replays the three-launch shape with
-                           # its fused reward + dynamics launch whatever the handle's mode is (include/auv_hip.h)
-                           step_mode=("side_by_side+k31 (captured, %d steps per graph)" % K) if K > 1 else env.effective_step_mode(max(1, n_local // sub)),
-                           roofline_step_mode=env.effective_step_mode(max(1, n_local // sub)), actions=args.actions,
-                           worlds_per_env=wpe, world_gen_s=round(t_gen, 1),
-                           episodes_finished=int(stats["episodes"].sum().item())),
-               roofline=roofline)
+               scaling="weak", vs_baseline=None, dtype="f64", data="synthetic", config=cfg_out, roofline=roofline)
+    if comparison:
+        out["comparison"] = comparison
 
     if rank == 0 and world == 1 and args.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, bank, n_local)

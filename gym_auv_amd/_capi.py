@@ -14,11 +14,12 @@ from .config import Config
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libauv_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 AUV_REWARD_COLAV, AUV_REWARD_PATHFOLLOW = 0, 1
 AUV_CULL_REFERENCE, AUV_CULL_EXACT = 0, 1
 AUV_F32, AUV_F64 = 0, 1
+AUV_RDV_EVENTS, AUV_RDV_DEVICE, AUV_RDV_CP = 0, 1, 2
 
 FIELDS = dict(STATE=0, LIDAR_D=1, OBS64=2, REWARD64=3, INFO64=4, WORLD_IDX=5, COUNTERS=6,
               MOVER_STATE=7, NEARBY=8, EPISODE=9, CULL_LIMITS=10, NAV64=11, COLLISION=12, STAMPS=13, STEP_INFO=14)
@@ -135,9 +136,14 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
         "auv_step_slice": (C.c_int, [vp, i32, i32, vp, i32, vp, vp, vp, vp]),
         "auv_step_pipelined": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp]),
+        "auv_step_async": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp, vp, i32]),
+        "auv_step_wait": (C.c_int, [vp, vp]),
+        "auv_set_rendezvous_limit": (C.c_int, [vp, C.c_double]),
+        "auv_graph_capture_chains": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, vp, vp, i32, i32]),
+        "auv_graph_launch_chains": (C.c_int, [vp, i32, C.POINTER(vp)]),
         "auv_step_pipelined_timed": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp, C.POINTER(C.c_float)]),
         "auv_streams_overlap": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float)]),
-        "auv_episode_log": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.POINTER(C.c_int64), vp]),
+        "auv_episode_log": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),
         "auv_health": (C.c_int, [vp, C.POINTER(i32)]),
         "auv_effective_step_mode": (C.c_int, [vp, i32]),
         "auv_step_dynamics": (C.c_int, [vp, vp, i32, vp]),
@@ -174,7 +180,8 @@ def load_library(path: str = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset", "auv_step", "auv_step_slice",
-                    "auv_step_pipelined", "auv_step_pipelined_timed", "auv_streams_overlap", "auv_episode_log", "auv_health", "auv_effective_step_mode",
+                    "auv_step_pipelined", "auv_step_async", "auv_step_wait", "auv_set_rendezvous_limit", "auv_graph_capture_chains",
+                    "auv_graph_launch_chains", "auv_step_pipelined_timed", "auv_streams_overlap", "auv_episode_log", "auv_health", "auv_effective_step_mode",
                     "auv_step_dynamics", "auv_lidar", "auv_nav_reward", "auv_read", "auv_write",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",

@@ -11,6 +11,7 @@ The HIP extension is mandatory: importing this module dlopens gym_auv_amd/csrc/l
 and raises `AuvLibraryError` if it is missing.  There is no CPU or eager-PyTorch fallback.
 """
 import ctypes as C
+import time
 from typing import Dict, Optional, Sequence, Union
 
 import numpy as np
@@ -87,6 +88,9 @@ class BatchedAuvEnv:
         self.step_mode = "auto"
         self._slices = None
         self.sub_batches = 1
+        self.rendezvous = "events"      # how step_async / step_wait order the chains against the caller's stream
+        self.stream_probe_s = 0.0
+        self._chain_graph = None
 
     # ------------------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -156,7 +160,7 @@ class BatchedAuvEnv:
         return self.obs, self.reward, self.done, self._lazy_info()
 
     # ------------------------------------------------------------------------------ sub-batches
-    def _concurrent_streams(self, k: int):
+    def _concurrent_streams(self, k: int, first: Optional[torch.cuda.Stream] = None):
         """k streams whose kernels really run side by side.  HIP multiplexes streams onto a few hardware queues (four
         by default, GPU_MAX_HW_QUEUES) and two streams on the same queue serialise, so candidates are tested pairwise
         (auv_streams_overlap: a 300 us do-nothing wave on each) and a set that overlaps mutually is chosen.  Returns
@@ -172,6 +176,8 @@ class BatchedAuvEnv:
                 if ratio.value < 1.5:
                     return True
             return False
+        if first is not None:
+            cands = [first] + cands      # (the caller's stream is chain 0: the others must run side by side with IT)
         chosen = [cands[0]]
         for c in cands[1:]:
             if len(chosen) == k:
@@ -180,23 +186,33 @@ class BatchedAuvEnv:
                 chosen.append(c)
         return chosen
 
-    def set_sub_batches(self, k: int, probe_streams: bool = True):
+    RENDEZVOUS = {"events": _capi.AUV_RDV_EVENTS, "device": _capi.AUV_RDV_DEVICE, "cp": _capi.AUV_RDV_CP}
+
+    def set_sub_batches(self, k: int, probe_streams: bool = True, inline_first: bool = False, strict: bool = False):
         """Split the batch into `k` contiguous sub-batches, each with a stream of its own.  `step_pipelined` /
         `step_async` then step them as k independent launch chains that overlap on the GPU (one sub-batch's sweeps run
         under another's dynamics chain and navigation tail); results are bit-identical to `step`.  k = 1 restores the
         single launch.  Slice boundaries are multiples of 64 environments; if the device runs fewer than k streams
-        side by side (see _concurrent_streams) the batch is split into that many."""
+        side by side (see _concurrent_streams) the batch is split into that many -- or, with `strict`, the call raises.
+        `inline_first`: the first sub-batch runs on the CALLER's current stream (the one this method is called on) and
+        only the others get streams of their own, chosen to run side by side with it: a step_async / step_wait then
+        orders k - 1 chains against the caller's stream instead of k."""
         k = int(k)
         if k < 1 or k > 64:
             raise ValueError("sub-batches must be in [1, 64]")
         n = self.n_envs
         torch.cuda.synchronize(self.device)
+        cur = torch.cuda.current_stream(self.device)
+        t0 = time.perf_counter()
         # (probe_streams = False: any k streams -- under a counter-collecting profiler dispatches are serialised, the
         # probe would find no two streams side by side and the batch would not be split at all)
         if k > 1 and probe_streams:
-            streams = self._concurrent_streams(k)
+            streams = self._concurrent_streams(k, first=cur if inline_first else None)
         else:
-            streams = [torch.cuda.Stream(device=self.device) for _ in range(k)]
+            streams = ([cur] if inline_first else []) + [torch.cuda.Stream(device=self.device) for _ in range(k - int(inline_first))]
+        self.stream_probe_s = time.perf_counter() - t0
+        if len(streams) < k and strict:
+            raise RuntimeError("set_sub_batches(%d): the device runs only %d streams side by side" % (k, len(streams)))
         k = min(k, len(streams))
         per = -(-n // k)
         per = -(-per // 64) * 64
@@ -206,24 +222,40 @@ class BatchedAuvEnv:
         self._bounds_c = (C.c_int32 * (self.sub_batches + 1))(*([lo for lo, _ in self._slices] + [n]))
         self._streams_c = (C.c_void_p * self.sub_batches)(*[st.cuda_stream for st in self._sub_streams])
         self._async_pending = False
+        self._chain_graph = None
         return self._slices
 
     def step_slice(self, i: int, actions: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
         """Enqueue one step of sub-batch `i` (see set_sub_batches) on `stream` (default: the sub-batch's own).
         `actions` is the full [N, 2] tensor; only the slice's rows are read, and only the slice's rows of
-        obs / reward / done are written."""
-        a, dt = self._act(actions)
+        obs / reward / done are written.  Ordering against the producer of `actions` is the caller's (stream order,
+        events): pass a device tensor of the env's device, float32 / float64, contiguous -- anything else is converted
+        on the CURRENT stream and the chain's stream is made to wait for that conversion."""
         lo, cnt = self._slices[i]
         st = self._sub_streams[i] if stream is None else stream
+        a, dt = self._act_for(actions, [st])
         _check(_LIB.auv_step_slice(self._h, lo, cnt, C.c_void_p(a.data_ptr()), dt, C.c_void_p(self.obs.data_ptr()),
                                    C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
                                    C.c_void_p(st.cuda_stream)), "auv_step_slice")
+
+    def _act_for(self, actions: torch.Tensor, streams):
+        """_act for launches on OTHER streams than the current one.  A conversion (device, dtype, layout) is enqueued on
+        the current stream and yields a temporary: the consuming streams must wait for it, and the caching allocator
+        must not hand its memory to somebody else while they still read it."""
+        a, dt = self._act(actions)
+        if a is not actions:
+            cur = torch.cuda.current_stream(self.device)
+            for st in streams:
+                if st != cur:
+                    st.wait_stream(cur)
+                    a.record_stream(st)
+        return a, dt
 
     def step_pipelined(self, actions: torch.Tensor):
         """One step of the whole batch as `sub_batches` independent launch chains, one C call (auv_step_pipelined):
         sub-batch i goes to its own stream.  Nothing orders the chains against the caller's stream -- for open-loop
         stretches (actions already resident); `step_async` / `step_wait` add that ordering."""
-        a, dt = self._act(actions)
+        a, dt = self._act_for(actions, self._sub_streams)
         _check(_LIB.auv_step_pipelined(self._h, self.sub_batches, self._bounds_c, self._streams_c, C.c_void_p(a.data_ptr()), dt,
                                        C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
                                        C.c_void_p(self.done.data_ptr())), "auv_step_pipelined")
@@ -231,37 +263,45 @@ class BatchedAuvEnv:
     def step_pipelined_timed(self, actions: torch.Tensor):
         """step_pipelined with every sub-batch's launch stamped by its own HIP events: ms per sub-batch launch
         (its own duration while the other chains run beside it)."""
-        a, dt = self._act(actions)
+        a, dt = self._act_for(actions, self._sub_streams)
         ms = (C.c_float * self.sub_batches)()
         _check(_LIB.auv_step_pipelined_timed(self._h, self.sub_batches, self._bounds_c, self._streams_c, C.c_void_p(a.data_ptr()), dt,
                                              C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
                                              C.c_void_p(self.done.data_ptr()), ms), "auv_step_pipelined_timed")
         return [float(x) for x in ms]
 
-    def step_async(self, actions: torch.Tensor):
+    def step_async(self, actions: torch.Tensor, rendezvous: Optional[str] = None):
         """VecEnv.step_async (what SubprocVecEnv does with its workers, scripts/run.py:293-296): enqueue the step of
-        every sub-batch on its own stream and return at once.  The sub-batch streams first wait for the caller's
-        current stream (the actions were produced there)."""
+        every sub-batch on its stream, behind whatever produced `actions` on the caller's current stream, and return at
+        once -- ONE C call (auv_step_async); `rendezvous` ("events" | "device" | "cp", default `self.rendezvous`) picks
+        how the chains on other streams are ordered against the caller's (include/auv_hip.h, AUV_RDV_*).  The actions
+        are converted (device / dtype / layout) FIRST, on the caller's stream, so the chains wait for the conversion
+        too, and the converted tensor lives until step_wait."""
         if self._slices is None:
-            self.set_sub_batches(1)
+            self.set_sub_batches(1, inline_first=True)
+        a, dt = self._act(actions)                       # (on the caller's stream, BEFORE the chains are ordered behind it)
         cur = torch.cuda.current_stream(self.device)
-        for st in self._sub_streams:
-            st.wait_stream(cur)
-        self.step_pipelined(actions)
-        self._async_actions = actions    # keep the buffer alive until step_wait
+        mode = self.RENDEZVOUS[rendezvous or self.rendezvous]
+        _check(_LIB.auv_step_async(self._h, self.sub_batches, self._bounds_c, self._streams_c, C.c_void_p(a.data_ptr()), dt,
+                                   C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
+                                   C.c_void_p(self.done.data_ptr()), C.c_void_p(cur.cuda_stream), mode), "auv_step_async")
+        self._async_actions = a                          # the CONVERTED buffer the chains read, alive until step_wait
         self._async_pending = True
 
     def step_wait(self):
-        """VecEnv.step_wait: make the caller's current stream wait for every sub-batch's step and return
-        (obs, reward, done, info) -- device tensors, no host synchronisation."""
+        """VecEnv.step_wait: make the caller's current stream wait for every sub-batch's step (auv_step_wait) and
+        return (obs, reward, done, info) -- device tensors, no host synchronisation."""
         if not getattr(self, "_async_pending", False):
             raise RuntimeError("step_wait() without step_async()")
         cur = torch.cuda.current_stream(self.device)
-        for st in self._sub_streams:
-            cur.wait_stream(st)
+        _check(_LIB.auv_step_wait(self._h, C.c_void_p(cur.cuda_stream)), "auv_step_wait")
         self._async_pending = False
-        self._async_actions = None
+        self._async_actions = None                       # (the caller's stream is ordered behind its last reader now)
         return self.obs, self.reward, self.done, self._lazy_info()
+
+    def set_rendezvous_limit(self, seconds: float):
+        """How long a rendezvous kernel of step_async / step_wait ("device") waits before it gives up and reports."""
+        _check(_LIB.auv_set_rendezvous_limit(self._h, float(seconds)), "auv_set_rendezvous_limit")
 
     def _lazy_info(self):
         return _LazyInfo(self)
@@ -313,12 +353,32 @@ class BatchedAuvEnv:
         the returned [slots, N, 2] tensor is the action ring: replayed step k consumes slot k % slots."""
         self._graph_actions = torch.zeros((slots, self.n_envs, 2), dtype=dtype, device=self.device)
         self._graph_steps = int(steps)
+        self._chain_graph = None
         dt = _capi.AUV_F64 if dtype == torch.float64 else _capi.AUV_F32
         torch.cuda.synchronize(self.device)
         _check(_LIB.auv_set_action_ring(self._h, int(slots)), "auv_set_action_ring")
         _check(_LIB.auv_graph_capture_steps(self._h, C.c_void_p(self._graph_actions.data_ptr()), dt,
                                             C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
                                             C.c_void_p(self.done.data_ptr()), int(steps), self._stream()), "auv_graph_capture_steps")
+        return self._graph_actions if slots > 1 else self._graph_actions[0]
+
+    def capture_graph_chains(self, dtype=torch.float32, slots: int = 1, steps: int = 1, one_graph: bool = False):
+        """Capture `steps` consecutive steps of EVERY sub-batch (set_sub_batches) as captured chains (auv_graph_capture_chains):
+        by default one linear hipGraph per sub-batch, replayed by step_graph() on the sub-batch's own stream, so that a
+        replay keeps `sub_batches` launches in flight like the eager chains do; `one_graph`: one hipGraph with a branch
+        per sub-batch, replayed on the caller's stream.  Every chain walks the [slots, N, 2] action ring from slot 0 with
+        a position of its own.  Returns the ring."""
+        if self._slices is None:
+            self.set_sub_batches(1)
+        self._graph_actions = torch.zeros((slots, self.n_envs, 2), dtype=dtype, device=self.device)
+        self._graph_steps = int(steps)
+        dt = _capi.AUV_F64 if dtype == torch.float64 else _capi.AUV_F32
+        torch.cuda.synchronize(self.device)
+        _check(_LIB.auv_set_action_ring(self._h, int(slots)), "auv_set_action_ring")
+        _check(_LIB.auv_graph_capture_chains(self._h, self.sub_batches, self._bounds_c, C.c_void_p(self._graph_actions.data_ptr()), dt,
+                                             C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
+                                             C.c_void_p(self.done.data_ptr()), int(steps), int(bool(one_graph))), "auv_graph_capture_chains")
+        self._chain_graph = "one" if one_graph else "per_chain"
         return self._graph_actions if slots > 1 else self._graph_actions[0]
 
     def step_graph(self, actions: Optional[torch.Tensor] = None):
@@ -328,7 +388,11 @@ class BatchedAuvEnv:
             if self._graph_actions.shape[0] != 1:
                 raise ValueError("with an action ring write the slots directly")
             self._graph_actions[0].copy_(actions)
-        _check(_LIB.auv_graph_launch(self._h, self._stream()), "auv_graph_launch")
+        if self._chain_graph == "per_chain":
+            # (nothing orders the chains' streams against the caller's: open-loop stretches, like step_pipelined)
+            _check(_LIB.auv_graph_launch_chains(self._h, self.sub_batches, self._streams_c), "auv_graph_launch_chains")
+        else:
+            _check(_LIB.auv_graph_launch(self._h, self._stream()), "auv_graph_launch")
         return self.obs, self.reward, self.done, self._lazy_info()
 
     def step_timed(self, actions: torch.Tensor):
@@ -439,15 +503,22 @@ class BatchedAuvEnv:
     def episode_log(self, max_rows: int = 1 << 20) -> torch.Tensor:
         """Episodes that ended since the last call (or since the bank was loaded), in completion order: [k, 8] float64 on
         the device, columns EPISODE_LOG_COLUMNS -- what the reference appends to `env.history` in save_latest_episode
-        (environment.py:466-489), for the whole batch.  One small host synchronisation per call."""
-        total = C.c_int64()
+        (environment.py:466-489), for the whole batch.  One small host synchronisation per call.  The device keeps the
+        newest >= max(65536, 4 N) rows: if more episodes than that ended between two calls the oldest are lost, the call
+        returns the rows still held and `episode_log_dropped` counts the loss (it never raises for falling behind)."""
+        total, start = C.c_int64(), C.c_int64()
         first = getattr(self, "_log_first", 0)
-        _check(_LIB.auv_episode_log(self._h, None, 0, first, C.byref(total), self._stream()), "auv_episode_log")
-        k = min(int(total.value) - first, int(max_rows))
-        rows = torch.empty((max(k, 0), 8), dtype=torch.float64, device=self.device)
+        _check(_LIB.auv_episode_log(self._h, None, 0, first, C.byref(total), C.byref(start), self._stream()), "auv_episode_log")
+        first = int(start.value)                                      # (> the cursor when the ring has lapped it)
+        k = max(0, min(int(total.value) - first, int(max_rows)))
+        rows = torch.empty((k, 8), dtype=torch.float64, device=self.device)
         if k > 0:
-            _check(_LIB.auv_episode_log(self._h, C.c_void_p(rows.data_ptr()), k, first, C.byref(total), self._stream()), "auv_episode_log")
-            self._log_first = first + k
+            _check(_LIB.auv_episode_log(self._h, C.c_void_p(rows.data_ptr()), k, first, C.byref(total), C.byref(start),
+                                        self._stream()), "auv_episode_log")
+            first = int(start.value)                                  # (lapped again between the two reads: the k rows copied
+                                                                      # start there -- the ring then holds cap >= k of them)
+        self.episode_log_dropped = getattr(self, "episode_log_dropped", 0) + (first - getattr(self, "_log_first", 0))
+        self._log_first = first + k
         return rows
 
     def episode_stats(self) -> Dict[str, torch.Tensor]:

@@ -38,6 +38,9 @@ void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, floa
                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st);
 void auv_launch_spin(unsigned long long ticks, hipStream_t st);
+void auv_launch_rdv_publish(unsigned long long* word, unsigned long long seq, hipStream_t st);
+void auv_launch_rdv_arrive(unsigned long long* word, hipStream_t st);
+void auv_launch_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, double limit_s, hipStream_t st);
 hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
                    float* out_closeness, hipStream_t st);
@@ -76,6 +79,20 @@ struct auv_handle {
   int handover_timeouts;         // polls that ran out over the life of the handle (each one disables the hand-overs)
   hipEvent_t ev[6];
   std::vector<hipEvent_t> slice_ev;   // auv_step_pipelined_timed: start / stop event per sub-batch launch
+  // auv_step_async / auv_step_wait: the chains of the pending step that do NOT run on the caller's stream, and how
+  // they are ordered against it (0: no step pending, else 1 + AUV_RDV_*)
+  int async_pending;
+  std::vector<hipStream_t> async_streams;
+  hipEvent_t ev_actions;              // AUV_RDV_EVENTS: recorded on the caller's stream behind the actions
+  std::vector<hipEvent_t> ev_chain;   //                 recorded behind each chain's launch
+  unsigned long long* rdv;            // AUV_RDV_DEVICE / _CP: words in device (signal) memory, one 128-byte line each:
+                                      //   [0] actions-ready sequence, [16] chains-arrived count, [32 + 16 j] chain j's sequence
+  unsigned long long rdv_seq, rdv_target;
+  double rdv_limit_s;                 // how long a rendezvous kernel waits before it gives up (pair_error 4 / 5)
+  // captured chains (auv_graph_capture_chains): one linear graph per sub-batch, replayed on the sub-batch's stream
+  std::vector<hipGraph_t> chain_graph;
+  std::vector<hipGraphExec_t> chain_exec;
+  std::vector<hipStream_t> fork_streams;   // side streams of the one-graph (fork / join) form
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
   GenOut gen;
@@ -87,6 +104,9 @@ struct auv_handle {
 // doubling -- many rounds of waves per slot leave little to gain by hiding a launch boundary -- so beyond what was
 // measured the fence-free shape is the default.  (With three roles the crossover was at 16384.)
 #define AUV_AUTO_THREE_LAUNCHES_FROM 65536
+#define AUV_MAX_CHAINS 64      // sub-batch chains per handle (BatchedAuvEnv.set_sub_batches allows up to 64)
+#define AUV_RDV_WORDS (32 + 16 * AUV_MAX_CHAINS)       // rendezvous words, one 128-byte line each (auv_handle::rdv)
+#define AUV_RDV_BYTES (AUV_RDV_WORDS * sizeof(unsigned long long))
 
 // The shape a step of `ne` environments is actually launched in: the requested one, degraded to the fence-free
 // three-launch shape where the in-launch hand-overs may not be used (probe failed / a poll timed out / no LiDAR).
@@ -97,19 +117,45 @@ static int effective_mode(const auv_handle* h, int ne) {
   return m;
 }
 
+// every captured graph of the handle has launch arguments of the current bank / mode / ring baked in
+static void drop_graphs(auv_handle* h) {
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  h->graph_exec = nullptr;
+  for (auto& g : h->chain_exec) (void)hipGraphExecDestroy(g);
+  for (auto& g : h->chain_graph) (void)hipGraphDestroy(g);
+  h->chain_exec.clear(), h->chain_graph.clear();
+}
+
 static int recover_from_timeout(auv_handle* h);
 static int probe_dispatch_order(auv_handle* h);
 
 // A wave of the one-launch step that gave up polling has left its environment's step unfinished.  The
 // next call on the handle notices (mapped host word), repairs the handle -- hand-over words cleared, EVERY
 // environment put back into its reset state, three-launch shape from now on -- and reports AUV_ESTATE once.
-#define PAIR_CHECK(h)                                                            \
+#define PAIR_CHECK(h) PAIR_CHECK_ON(h, nullptr, false)
+// `st`: the stream the call will enqueue on.  While that stream is being CAPTURED (a torch CUDAGraph around auv_step /
+// auv_step_slice, examples/ppo.py) the recovery -- device synchronisation, copies, a reset launch on the null stream --
+// would be illegal and would surface as a HIP capture error: the call then only reports AUV_ESTATE; the first call
+// outside a capture recovers.
+#define PAIR_CHECK_ON(h, st, have_st)                                            \
   do {                                                                           \
     if ((h)->pair_error_host && *(volatile int32_t*)(h)->pair_error_host) {      \
+      if ((have_st) && stream_capturing((hipStream_t)(st)))                      \
+        return fail(AUV_ESTATE, "a hand-over time-out is pending and this stream is being captured: nothing was enqueued; " \
+                                "the next call outside a capture recovers and reports");      \
       int _rc = recover_from_timeout(h);                                         \
       if (_rc) return _rc;                                                       \
     }                                                                            \
   } while (0)
+
+static bool stream_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return cs == hipStreamCaptureStatusActive;
+}
 
 template <typename T>
 static int dev_alloc(std::vector<void*>& pool, T** out, size_t count) {
@@ -197,17 +243,18 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.limits, n * k_max);
   rc |= dev_alloc(ep, &d.collision, n);
   rc |= dev_alloc(ep, &d.step_info, n * 4);
-  d.ep_log_cap = (int32_t)(4 * n > 65536 ? 4 * n : 65536);
+  d.ep_log_cap = 65536;                                        // >= max(65536, 4 n), a power of two (the kernels mask)
+  while ((size_t)d.ep_log_cap < 4 * n) d.ep_log_cap *= 2;
   rc |= dev_alloc(ep, &d.ep_log, 8 * (size_t)d.ep_log_cap);
-  rc |= dev_alloc(ep, &d.ep_log_count, 4);
+  rc |= dev_alloc(ep, &d.ep_log_count, 1);
   rc |= dev_alloc(ep, &d.pair_word, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
   rc |= dev_alloc(ep, &d.nav_hand, 8 * n);
-  rc |= dev_alloc(ep, &d.k1_done, 4);
+  rc |= dev_alloc(ep, &d.k1_done, AUV_MAX_CHAINS);      // (one per captured chain)
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
   rc |= dev_alloc(ep, &d.stamps, n * 16);
-  rc |= dev_alloc(ep, &d.ring_pos, 4);
+  rc |= dev_alloc(ep, &d.ring_pos, AUV_MAX_CHAINS);     // (one per captured chain)
   rc |= dev_alloc(ep, &d.rew_path, n);
   rc |= dev_alloc(ep, &d.rew_lidar, n);
   {
@@ -230,11 +277,11 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.w_collision, (size_t)W);
   if (rc) return AUV_EHIP;
   }
-  HIP_TRY(hipMemset(d.ep_log_count, 0, sizeof(unsigned int)));   // the episode log restarts with every bank
+  HIP_TRY(hipMemset(d.ep_log_count, 0, sizeof(unsigned long long)));   // the episode log restarts with every bank
   // a new bank starts with a plain action buffer (a captured graph, and with it the ring, is gone)
   d.ring_slots = 1;
   d.ring_slot_host = -1;
-  HIP_TRY(hipMemset(d.ring_pos, 0, sizeof(int32_t)));
+  HIP_TRY(hipMemset(d.ring_pos, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
   {
     // one-launch step: no sweep has left a word yet
     std::vector<unsigned long long> empty(n ? n : 1, AUV_PAIR_EMPTY);
@@ -247,7 +294,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     *h->pair_error_host = 0;   // (a new bank starts with a clean slate; see PAIR_CHECK)
     HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(d.k1_done, 0, sizeof(int32_t)));
+    HIP_TRY(hipMemset(d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
     if (((uintptr_t)d.k1_pkt & 63) != 0 || ((uintptr_t)d.nav_hand & 63) != 0) return fail(AUV_EHIP, "hand-over records are not 64-byte aligned");
   }
   d.w_ready = 0;
@@ -261,10 +308,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     if (rc_p) return rc_p;
   }
   if ((size_t)AUV_ENVS_PER_BLOCK * (d.nch_max * 4 + 512) > 64 * 1024) return fail(AUV_EINVAL, "path too long for K3's chunk list");
-  if (h->graph_exec) {
-    (void)hipGraphExecDestroy(h->graph_exec);
-    h->graph_exec = nullptr;
-  }
+  drop_graphs(h);
   // ---- reset rows: the first observation of every world (navigate + perceive at its initial
   // pose) is a constant of the world; compute it once, N worlds at a time, with the step's own
   // kernels (reset state -> K2 -> K3 on the fresh list), and keep the rows per world.
@@ -326,16 +370,16 @@ static int recover_from_timeout(auv_handle* h) {
   HIP_TRY(hipDeviceSynchronize());
   h->handover_timeouts += 1;
   h->handover_ok = false;
-  if (h->graph_exec) {
-    (void)hipGraphExecDestroy(h->graph_exec);
-    h->graph_exec = nullptr;
-  }
+  drop_graphs(h);
   const size_t n = (size_t)d.n;
   std::vector<unsigned long long> empty(n ? n : 1, AUV_PAIR_EMPTY);
   HIP_TRY(hipMemcpy(d.pair_word, empty.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(d.k1_done, 0, sizeof(int32_t)));
+  HIP_TRY(hipMemset(d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
+  if (h->rdv) HIP_TRY(hipMemset(h->rdv, 0, AUV_RDV_BYTES));
+  h->rdv_seq = h->rdv_target = 0;
+  h->async_pending = 0;
   auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
@@ -344,7 +388,10 @@ static int recover_from_timeout(auv_handle* h) {
                           "back into its reset state; the handle steps in the three-launch shape from now on (no in-launch "
                           "hand-over) and this error is reported once -- carry on with reset observations",
               code == 2 ? "a sweep or search wave waited in vain for the dynamics role's state"
-                        : (code == 3 ? "a finish wave waited in vain for a state packet or a search record" : "a finish wave waited in vain for a sweep's word"));
+                        : (code == 3 ? "a finish wave waited in vain for a state packet or a search record"
+                        : (code == 4 ? "a chain waited in vain for the caller's stream to publish the actions (auv_step_async)"
+                        : (code == 5 ? "the caller's stream waited in vain for the chains to arrive (auv_step_wait)"
+                                     : "a finish wave waited in vain for a sweep's word"))));
 }
 
 extern "C" {
@@ -378,6 +425,11 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->probe_failures = -1;
   h->handover_timeouts = 0;
   for (auto& e : h->ev) e = nullptr;
+  h->async_pending = 0;
+  h->ev_actions = nullptr;
+  h->rdv = nullptr;
+  h->rdv_seq = h->rdv_target = 0;
+  h->rdv_limit_s = 30.0;
   *out = h;
   return AUV_OK;
 }
@@ -386,12 +438,18 @@ int auv_destroy(auv_handle_t* h) {
   if (!h) return AUV_OK;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
-  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  drop_graphs(h);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : h->slice_ev) (void)hipEventDestroy(e);
+  for (auto& e : h->ev_chain) (void)hipEventDestroy(e);
+  if (h->ev_actions) (void)hipEventDestroy(h->ev_actions);
+  if (h->rdv) (void)hipFree(h->rdv);
+  for (auto& g : h->chain_exec) (void)hipGraphExecDestroy(g);
+  for (auto& g : h->chain_graph) (void)hipGraphDestroy(g);
+  for (auto& st : h->fork_streams) (void)hipStreamDestroy(st);
   free_pool(h->env_allocs);
   free_pool(h->bank_allocs);
   if (h->pair_error_host) (void)hipHostFree(h->pair_error_host);
@@ -671,14 +729,16 @@ int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx
 // and under stream capture.
 // `skip_k1`: the dynamics of this step were done by the previous step's fused kernel; `fuse_next`: this step's
 // reward phase also runs the dynamics of the NEXT step (both only inside a captured graph of several steps)
+// `chain`: inside a captured chain (auv_graph_capture_chains) the launch uses the ring position / count-off word of its chain
 static int enqueue_step(auv_handle_t* h, int mode, int e0, int ne, const void* actions, int32_t dtype, float* obs, float* reward,
-                        uint8_t* done, hipStream_t st, bool capturing, bool skip_k1 = false, bool fuse_next = false) {
+                        uint8_t* done, hipStream_t st, bool capturing, bool skip_k1 = false, bool fuse_next = false, int chain = 0) {
   // The action ring belongs to captured graphs only: an eager step reads `actions` as ONE plain
   // [N][2] buffer and neither reads nor advances the ring position (a caller that launches
   // eagerly can pass a different pointer every step).
   AuvDev d = h->d;
   if (!capturing) d.ring_slots = 1;
   d.e0 = e0, d.ne = ne;
+  d.ring_pos += chain, d.k1_done += chain;
   if (mode == AUV_STEP_ONE_LAUNCH) {
     // dynamics, LiDAR sweep, navigation search and finish as four roles of ONE launch (csrc/k_step_fused.hip: k_step_roles;
     // inside a captured graph its dynamics role advances the action ring)
@@ -696,6 +756,14 @@ static int enqueue_step(auv_handle_t* h, int mode, int e0, int ne, const void* a
   return AUV_OK;
 }
 
+static int check_slices(const auv_handle_t* h, int32_t n_slices, const int32_t* bounds, const void* streams, const char* who) {
+  if (n_slices < 1 || n_slices > AUV_MAX_CHAINS || !bounds || !streams) return fail(AUV_EINVAL, "%s: bad arguments (1 .. %d slices)", who, AUV_MAX_CHAINS);
+  if (bounds[0] != 0 || bounds[n_slices] != h->d.n) return fail(AUV_EINVAL, "%s: bounds must run from 0 to %d", who, h->d.n);
+  for (int i = 0; i < n_slices; i++)
+    if (bounds[i + 1] <= bounds[i]) return fail(AUV_EINVAL, "%s: empty or reversed slice %d", who, i);
+  return AUV_OK;
+}
+
 static int check_actions(const void* actions_dev, int32_t action_dtype, const char* who) {
   if (!actions_dev) return fail(AUV_EINVAL, "%s: null actions", who);
   if (action_dtype != AUV_F32 && action_dtype != AUV_F64) return fail(AUV_EINVAL, "%s: bad action dtype", who);
@@ -710,7 +778,7 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
   REQUIRE_READY(h);
   int rc = check_actions(actions_dev, action_dtype, "auv_step");
   if (rc) return rc;
-  PAIR_CHECK(h);
+  PAIR_CHECK_ON(h, stream, true);
   rc = enqueue_step(h, effective_mode(h, h->d.n), 0, h->d.n, actions_dev, action_dtype, obs_dev, reward_dev, done_dev,
                     (hipStream_t)stream, false);
   if (rc) return rc;
@@ -724,7 +792,7 @@ int auv_step_slice(auv_handle_t* h, int32_t e0, int32_t ne, const void* actions_
   int rc = check_actions(actions_dev, action_dtype, "auv_step_slice");
   if (rc) return rc;
   if (e0 < 0 || ne < 1 || (int64_t)e0 + ne > h->d.n) return fail(AUV_EINVAL, "auv_step_slice: slice [%d, %d) outside [0, %d)", e0, e0 + ne, h->d.n);
-  PAIR_CHECK(h);
+  PAIR_CHECK_ON(h, stream, true);
   rc = enqueue_step(h, effective_mode(h, ne), e0, ne, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream, false);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -736,16 +804,188 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
   REQUIRE_READY(h);
   int rc = check_actions(actions_dev, action_dtype, "auv_step_pipelined");
   if (rc) return rc;
-  if (n_slices < 1 || !bounds || !streams) return fail(AUV_EINVAL, "auv_step_pipelined: bad arguments");
-  if (bounds[0] != 0 || bounds[n_slices] != h->d.n) return fail(AUV_EINVAL, "auv_step_pipelined: bounds must run from 0 to %d", h->d.n);
-  for (int i = 0; i < n_slices; i++)
-    if (bounds[i + 1] <= bounds[i]) return fail(AUV_EINVAL, "auv_step_pipelined: empty or reversed slice %d", i);
+  rc = check_slices(h, n_slices, bounds, streams, "auv_step_pipelined");
+  if (rc) return rc;
   PAIR_CHECK(h);
   for (int i = 0; i < n_slices && rc == AUV_OK; i++)
     rc = enqueue_step(h, effective_mode(h, bounds[i + 1] - bounds[i]), bounds[i], bounds[i + 1] - bounds[i], actions_dev, action_dtype,
                       obs_dev, reward_dev, done_dev, (hipStream_t)streams[i], false);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_step_async(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, const void* actions_dev,
+                   int32_t action_dtype, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* caller_stream, int32_t rendezvous) {
+  REQUIRE_READY(h);
+  int rc = check_actions(actions_dev, action_dtype, "auv_step_async");
+  if (rc) return rc;
+  rc = check_slices(h, n_slices, bounds, streams, "auv_step_async");
+  if (rc) return rc;
+  if (rendezvous != AUV_RDV_EVENTS && rendezvous != AUV_RDV_DEVICE && rendezvous != AUV_RDV_CP)
+    return fail(AUV_EINVAL, "auv_step_async: rendezvous must be one of AUV_RDV_*");
+  if (h->async_pending) return fail(AUV_ESTATE, "auv_step_async: the previous step has not been waited for (auv_step_wait)");
+  PAIR_CHECK(h);
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t cs = (hipStream_t)caller_stream;
+  h->async_streams.clear();
+  for (int i = 0; i < n_slices; i++)
+    if ((hipStream_t)streams[i] != cs) h->async_streams.push_back((hipStream_t)streams[i]);
+  const size_t nr = h->async_streams.size();         // chains on streams of their own: the others are in stream order already
+  if (nr && rendezvous != AUV_RDV_EVENTS && !h->rdv) {
+    // (signal memory: what hipStreamWaitValue64 / WriteValue64 accept; an ordinary device allocation to the kernels)
+    if (hipExtMallocWithFlags((void**)&h->rdv, AUV_RDV_BYTES, hipMallocSignalMemory) != hipSuccess) {
+      (void)hipGetLastError();
+      h->rdv = nullptr;
+      HIP_TRY(hipMalloc((void**)&h->rdv, AUV_RDV_BYTES));
+    }
+    HIP_TRY(hipMemset(h->rdv, 0, AUV_RDV_BYTES));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  if (nr && rendezvous == AUV_RDV_EVENTS) {
+    if (!h->ev_actions) HIP_TRY(hipEventCreateWithFlags(&h->ev_actions, hipEventDisableTiming));
+    while (h->ev_chain.size() < nr) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->ev_chain.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(h->ev_actions, cs));                                    // behind whatever produced the actions
+  } else if (nr) {
+    h->rdv_seq += 1;
+    if (rendezvous == AUV_RDV_DEVICE) auv_launch_rdv_publish(h->rdv, h->rdv_seq, cs);
+    else HIP_TRY(hipStreamWriteValue64(cs, h->rdv, h->rdv_seq, 0));
+  }
+  size_t j = 0;
+  for (int i = 0; i < n_slices && rc == AUV_OK; i++) {
+    hipStream_t st = (hipStream_t)streams[i];
+    const bool remote = st != cs;
+    if (remote) {
+      if (rendezvous == AUV_RDV_EVENTS) HIP_TRY(hipStreamWaitEvent(st, h->ev_actions, 0));
+      else if (rendezvous == AUV_RDV_DEVICE) auv_launch_rdv_wait(h->rdv, h->rdv_seq, h->d.pair_error, 4, h->rdv_limit_s, st);
+      else HIP_TRY(hipStreamWaitValue64(st, h->rdv, h->rdv_seq, hipStreamWaitValueGte, ~0ull));
+    }
+    rc = enqueue_step(h, effective_mode(h, bounds[i + 1] - bounds[i]), bounds[i], bounds[i + 1] - bounds[i], actions_dev, action_dtype,
+                      obs_dev, reward_dev, done_dev, st, false);
+    if (remote && rc == AUV_OK) {
+      if (rendezvous == AUV_RDV_EVENTS) HIP_TRY(hipEventRecord(h->ev_chain[j], st));
+      else if (rendezvous == AUV_RDV_DEVICE) auv_launch_rdv_arrive(h->rdv + 16, st);
+      else HIP_TRY(hipStreamWriteValue64(st, h->rdv + 32 + 16 * j, h->rdv_seq, 0));
+      j++;
+    }
+  }
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  if (rendezvous == AUV_RDV_DEVICE) h->rdv_target += nr;
+  h->async_pending = 1 + rendezvous;
+  return AUV_OK;
+}
+
+int auv_step_wait(auv_handle_t* h, void* caller_stream) {
+  REQUIRE_READY(h);
+  if (!h->async_pending) return fail(AUV_ESTATE, "auv_step_wait: no step pending (auv_step_async)");
+  const int rendezvous = h->async_pending - 1;
+  hipStream_t cs = (hipStream_t)caller_stream;
+  const size_t nr = h->async_streams.size();
+  h->async_pending = 0;
+  if (nr) {
+    if (rendezvous == AUV_RDV_EVENTS) {
+      for (size_t j = 0; j < nr; j++) HIP_TRY(hipStreamWaitEvent(cs, h->ev_chain[j], 0));
+    } else if (rendezvous == AUV_RDV_DEVICE) {
+      auv_launch_rdv_wait(h->rdv + 16, h->rdv_target, h->d.pair_error, 5, h->rdv_limit_s, cs);   // ONE wait for all chains
+      HIP_TRY(hipGetLastError());
+    } else {
+      for (size_t j = 0; j < nr; j++) HIP_TRY(hipStreamWaitValue64(cs, h->rdv + 32 + 16 * j, h->rdv_seq, hipStreamWaitValueGte, ~0ull));
+    }
+  }
+  return AUV_OK;
+}
+
+int auv_set_rendezvous_limit(auv_handle_t* h, double seconds) {
+  if (!h || !(seconds > 0.0) || seconds > 3600.0) return fail(AUV_EINVAL, "auv_set_rendezvous_limit: seconds must be in (0, 3600]");
+  h->rdv_limit_s = seconds;
+  return AUV_OK;
+}
+
+int auv_graph_capture_chains(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, const void* actions_dev, int32_t action_dtype,
+                             float* obs_dev, float* reward_dev, uint8_t* done_dev, int32_t n_steps, int32_t one_graph) {
+  REQUIRE_READY(h);
+  int rc = check_actions(actions_dev, action_dtype, "auv_graph_capture_chains");
+  if (rc) return rc;
+  rc = check_slices(h, n_slices, bounds, bounds, "auv_graph_capture_chains");   // (the chains' streams are named at replay)
+  if (rc) return rc;
+  if (n_steps < 1 || n_steps > 4096) return fail(AUV_EINVAL, "auv_graph_capture_chains: n_steps must be in [1, 4096]");
+  PAIR_CHECK(h);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  drop_graphs(h);
+  if (h->graph) {
+    HIP_TRY(hipGraphDestroy(h->graph));
+    h->graph = nullptr;
+  }
+  if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+  // every chain starts at slot 0 of the ring and keeps a position of its own (advanced by its own dynamics waves)
+  HIP_TRY(hipMemset(h->d.ring_pos, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
+  HIP_TRY(hipMemset(h->d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
+  if (!one_graph) {
+    // K linear graphs, replayed on K streams of the caller's choice (auv_graph_launch_chains): which hardware queue a
+    // chain runs on stays the caller's decision, as for eager chains
+    for (int i = 0; i < n_slices; i++) {
+      const int ne = bounds[i + 1] - bounds[i];
+      HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+      for (int32_t k = 0; k < n_steps && rc == AUV_OK; k++)
+        rc = enqueue_step(h, effective_mode(h, ne), bounds[i], ne, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, h->cap_stream,
+                          true, false, false, i);
+      hipGraph_t g = nullptr;
+      hipError_t ce = hipStreamEndCapture(h->cap_stream, &g);
+      if (rc) return rc;
+      HIP_TRY(ce);
+      h->chain_graph.push_back(g);
+      hipGraphExec_t ge = nullptr;
+      HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      h->chain_exec.push_back(ge);
+    }
+    return AUV_OK;
+  }
+  // ONE graph whose K branches are the chains (fork behind the root, join at the end): replayed with auv_graph_launch,
+  // the runtime picks the streams of the branches
+  while ((int)h->fork_streams.size() < n_slices - 1) {
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    h->fork_streams.push_back(st);
+  }
+  while ((int)h->ev_chain.size() < n_slices) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->ev_chain.push_back(e);
+  }
+  HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+  hipError_t fe = hipEventRecord(h->ev_chain[0], h->cap_stream);
+  for (int i = 1; i < n_slices && fe == hipSuccess; i++) fe = hipStreamWaitEvent(h->fork_streams[i - 1], h->ev_chain[0], 0);
+  for (int i = 0; i < n_slices && rc == AUV_OK && fe == hipSuccess; i++) {
+    const int ne = bounds[i + 1] - bounds[i];
+    hipStream_t st = i == 0 ? h->cap_stream : h->fork_streams[i - 1];
+    for (int32_t k = 0; k < n_steps && rc == AUV_OK; k++)
+      rc = enqueue_step(h, effective_mode(h, ne), bounds[i], ne, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, st, true, false,
+                        false, i);
+  }
+  for (int i = 1; i < n_slices && fe == hipSuccess; i++) {
+    fe = hipEventRecord(h->ev_chain[i], h->fork_streams[i - 1]);
+    if (fe == hipSuccess) fe = hipStreamWaitEvent(h->cap_stream, h->ev_chain[i], 0);
+  }
+  hipError_t ce = hipStreamEndCapture(h->cap_stream, &h->graph);
+  if (rc) return rc;
+  HIP_TRY(fe);
+  HIP_TRY(ce);
+  HIP_TRY(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+  return AUV_OK;
+}
+
+int auv_graph_launch_chains(auv_handle_t* h, int32_t n_slices, void* const* streams) {
+  REQUIRE_READY(h);
+  if (!streams || n_slices != (int32_t)h->chain_exec.size() || n_slices < 1)
+    return fail(AUV_ESTATE, "auv_graph_launch_chains: %d streams for %d captured chains", n_slices, (int)h->chain_exec.size());
+  PAIR_CHECK(h);
+  for (int i = 0; i < n_slices; i++) HIP_TRY(hipGraphLaunch(h->chain_exec[i], (hipStream_t)streams[i]));
   return AUV_OK;
 }
 
@@ -780,24 +1020,28 @@ int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* b
   return AUV_OK;
 }
 
-int auv_episode_log(auv_handle_t* h, double* dst_dev, int64_t max_rows, int64_t first, int64_t* out_total, void* stream) {
+int auv_episode_log(auv_handle_t* h, double* dst_dev, int64_t max_rows, int64_t first, int64_t* out_total, int64_t* out_first,
+                    void* stream) {
   REQUIRE_READY(h);
   if (!out_total || (max_rows > 0 && !dst_dev) || max_rows < 0 || first < 0) return fail(AUV_EINVAL, "auv_episode_log: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  unsigned int total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, h->d.ep_log_count, sizeof(total), hipMemcpyDeviceToHost, st));
+  unsigned long long total_u = 0;
+  HIP_TRY(hipMemcpyAsync(&total_u, h->d.ep_log_count, sizeof(total_u), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  *out_total = (int64_t)total;
+  const int64_t total = (int64_t)total_u;
+  *out_total = total;
   const int64_t cap = h->d.ep_log_cap;
-  if (first > (int64_t)total) return fail(AUV_EINVAL, "auv_episode_log: first = %lld beyond the %u episodes logged", (long long)first, total);
-  if ((int64_t)total - first > cap) return fail(AUV_ESTATE, "auv_episode_log: %lld episodes since row %lld, the ring holds %lld -- read more often",
-                                                (long long)((int64_t)total - first), (long long)first, (long long)cap);
-  int64_t nrow = (int64_t)total - first;
+  if (first > total) return fail(AUV_EINVAL, "auv_episode_log: first = %lld beyond the %lld episodes logged", (long long)first, (long long)total);
+  // rows the ring has overwritten since `first` are gone: the read starts at the oldest row still held and says so
+  // (out_first - first rows were dropped) instead of failing -- a reader that fell behind catches up with this call
+  if (total - first > cap) first = total - cap;
+  if (out_first) *out_first = first;
+  int64_t nrow = total - first;
   if (nrow > max_rows) nrow = max_rows;
   // rows first .. first + nrow of the ring, in at most two pieces
   int64_t done = 0;
   while (done < nrow) {
-    const int64_t pos = (first + done) % cap;
+    const int64_t pos = (first + done) & (cap - 1);
     const int64_t piece = (nrow - done < cap - pos) ? nrow - done : cap - pos;
     HIP_TRY(hipMemcpyAsync(dst_dev + 8 * done, h->d.ep_log + 8 * pos, (size_t)piece * 64, hipMemcpyDeviceToDevice, st));
     done += piece;
@@ -843,12 +1087,9 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots) {
   REQUIRE_READY(h);
   if (n_slots < 1) return fail(AUV_EINVAL, "auv_set_action_ring: n_slots must be >= 1");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(h->d.ring_pos, 0, sizeof(int32_t)));
+  HIP_TRY(hipMemset(h->d.ring_pos, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
   h->d.ring_slots = n_slots;
-  if (h->graph_exec) {   // a captured graph has the old value baked into its kernel arguments
-    HIP_TRY(hipGraphExecDestroy(h->graph_exec));
-    h->graph_exec = nullptr;
-  }
+  drop_graphs(h);
   return AUV_OK;
 }
 
@@ -857,10 +1098,7 @@ int auv_set_step_mode(auv_handle_t* h, int32_t mode) {
   if (mode != AUV_STEP_SIDE_BY_SIDE && mode != AUV_STEP_ONE_LAUNCH && mode != AUV_STEP_AUTO)
     return fail(AUV_EINVAL, "auv_set_step_mode: mode must be one of AUV_STEP_*");
   h->step_mode = mode;
-  if (h->graph_exec) {
-    (void)hipGraphExecDestroy(h->graph_exec);
-    h->graph_exec = nullptr;
-  }
+  drop_graphs(h);
   return AUV_OK;
 }
 
@@ -989,10 +1227,7 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
   }
   PAIR_CHECK(h);
   if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-  if (h->graph_exec) {
-    HIP_TRY(hipGraphExecDestroy(h->graph_exec));
-    h->graph_exec = nullptr;
-  }
+  drop_graphs(h);
   if (h->graph) {
     HIP_TRY(hipGraphDestroy(h->graph));
     h->graph = nullptr;

@@ -78,8 +78,8 @@ struct AuvDev {
   int2* limits;        // [N][Kmax]
   uint8_t* collision;  // [N]
   double* ep_log;      // [ep_log_cap][8] finished episodes in completion order (reward phase; auv_episode_log)
-  unsigned int* ep_log_count;  // [1] episodes logged so far (the ring position is count % cap)
-  int32_t ep_log_cap;
+  unsigned long long* ep_log_count;  // [1] episodes logged so far, 64-bit (the ring position is count & (cap - 1))
+  int32_t ep_log_cap;  // a power of two
   double* step_info;   // [N][4] info of the last step (terminal values survive an auto-reset)
   unsigned long long* pair_word; // [N] one-launch step: what the LiDAR wave leaves for the finish wave (k_step_fused.hip)
   int32_t* pair_error; // [1] one-launch step: set when a wave gave up polling for a hand-over (1 sweep's word, 2 state packet, 3 packet / search record)

@@ -52,7 +52,7 @@ struct StepTabs {
   } cfg;
   const double *knot_s, *knot_coef;
   double *info64, *nav64, *obs64, *rew_path, *reward64, *step_info, *episode, *ep_log;
-  unsigned int* ep_log_count;
+  unsigned long long* ep_log_count;
   int32_t ep_log_cap;
   int32_t* world_idx;
   int4* counters;
@@ -737,8 +737,8 @@ __device__ __forceinline__ int reward_apply(const D& d, const int e, const int c
     // episode log (environment.py:466-489 save_latest_episode: what the reference appends to env.history), a ring of
     // 64-byte records filled in completion order: env, return, timesteps, collision, reached_goal, progress,
     // mean |cross-track error|, world
-    const unsigned int slot = atomicAdd(d.ep_log_count, 1u);
-    double2* row = (double2*)(d.ep_log + 8 * (size_t)(slot % (unsigned int)d.ep_log_cap));
+    const unsigned long long slot = atomicAdd(d.ep_log_count, 1ull);        // (64-bit: never wraps; cap is a power of two)
+    double2* row = (double2*)(d.ep_log + 8 * (size_t)(slot & (unsigned long long)(d.ep_log_cap - 1)));
     row[0] = make_double2((double)e, cum), row[1] = make_double2(t_step + 1, collision), row[2] = make_double2(reached_in, progress_in);
     row[3] = make_double2(cte_sum / (double)(t_step + 1), (double)d.world_idx[e]);
   }

@@ -614,7 +614,47 @@ __global__ void k_spin(unsigned long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// ---- rendezvous of the sub-batch chains with the caller's stream, on the device (auv_step_async / auv_step_wait,
+// AUV_RDV_DEVICE) ----------------------------------------------------------------------------------------------------
+// VecEnv.step_async / step_wait (scripts/run.py:293-296) order K chains on K streams against the stream the actions
+// come from and the results go to.  With HIP events that is a record + K waits before the step and K records + K waits
+// behind it, each hop a barrier packet the command processors resolve in ~8 us.  Here the hops are one-wave kernels
+// and two words in device memory:
+//   caller's stream   k_rdv_publish(ready, t)   behind whatever produced the actions: "the actions of step t are there"
+//   chain i's stream  k_rdv_wait(ready, t)      in front of its launch of step t (holds ONE wave slot, not a launch's)
+//                     k_rdv_arrive(done)        behind it: "chain i has finished a step"
+//   caller's stream   k_rdv_wait(done, target)  in step_wait: all chains have arrived
+// Visibility rides on the kernel boundaries: the producer's kernel has ended (release) before the publish kernel
+// starts, the waiting kernel ends before the chain's step starts (acquire); likewise behind the step.  Every waiter
+// waits for something that was SUBMITTED before it, so streams sharing a hardware queue (FIFO) cannot deadlock; the
+// waits are bounded by the wall clock all the same and report through pair_error (4: actions, 5: chains).
+__global__ void k_rdv_publish(unsigned long long* word, unsigned long long seq) {
+  if (threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_rdv_arrive(unsigned long long* word) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, unsigned long long limit_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();                    // 100 MHz
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    if (wall_clock64() - t0 > limit_ticks) {
+      __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
 }  // namespace
+
+void auv_launch_rdv_publish(unsigned long long* word, unsigned long long seq, hipStream_t st) {
+  hipLaunchKernelGGL(k_rdv_publish, dim3(1), dim3(AUV_WAVE), 0, st, word, seq);
+}
+void auv_launch_rdv_arrive(unsigned long long* word, hipStream_t st) { hipLaunchKernelGGL(k_rdv_arrive, dim3(1), dim3(AUV_WAVE), 0, st, word); }
+void auv_launch_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, double limit_s, hipStream_t st) {
+  hipLaunchKernelGGL(k_rdv_wait, dim3(1), dim3(AUV_WAVE), 0, st, word, target, err, code, (unsigned long long)(limit_s * 1e8));
+}
 
 void auv_launch_spin(unsigned long long ticks, hipStream_t st) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(AUV_WAVE), 0, st, ticks); }
 

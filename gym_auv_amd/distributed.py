@@ -80,6 +80,21 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def gather_floats(values, device) -> list:
+    """Every rank's list of floats, in rank order ([[...] per rank]); reporting only."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [list(map(float, values))]
+    t = torch.tensor(list(map(float, values)), dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu()] for o in out]
+
+
+def backend_name() -> str:
+    """The collective backend in use ("nccl" is RCCL on ROCm), or "none" for a single process."""
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else "none"
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

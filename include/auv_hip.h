@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AUV_ABI_VERSION 2
+#define AUV_ABI_VERSION 3
 
 enum {
   AUV_OK = 0,
@@ -178,6 +178,28 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
                        const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
                        uint8_t* done_dev);
 
+/* VecEnv.step_async / step_wait (scripts/run.py:293-296: SubprocVecEnv sends the actions to its workers and collects their
+ * results) with the ordering between the caller's stream and the chains done INSIDE the library, one call each:
+ *   auv_step_async  the actions were produced on `caller_stream`; slice i is stepped on streams[i] behind them.  A slice whose
+ *                   stream IS caller_stream is simply enqueued there (stream order, no hand-over at all).
+ *   auv_step_wait   work enqueued on `caller_stream` after this call sees obs / reward / done of every slice.
+ * Neither call blocks the host.  `rendezvous` picks the mechanism for the slices on other streams:
+ *   AUV_RDV_EVENTS  one hipEventRecord behind the actions + one hipStreamWaitEvent per chain; one record + wait per chain back.
+ *   AUV_RDV_DEVICE  one-wave kernels and two words in device memory: the caller's stream publishes "actions of step t ready",
+ *                   a one-wave kernel in front of each chain's launch polls for it (bounded), a one-wave kernel behind it counts
+ *                   the chain off, ONE polling kernel on the caller's stream waits for all of them (csrc/k_step_fused.hip:
+ *                   k_rdv_*).  Every waiter waits for something submitted before it; a wait that runs out
+ *                   (auv_set_rendezvous_limit, default 30 s) is reported like a hand-over time-out (auv_health).
+ *   AUV_RDV_CP      the same words written and awaited by the command processors (hipStreamWriteValue64 / WaitValue64).
+ * Results are bit-identical to auv_step.  What a full rendezvous per step costs, and why K chains cannot beat ONE launch
+ * when every step waits for all of them, is in DESIGN.md section 4.                                                      */
+enum { AUV_RDV_EVENTS = 0, AUV_RDV_DEVICE = 1, AUV_RDV_CP = 2 };
+int auv_step_async(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, const void* actions_dev,
+                   int32_t action_dtype, float* obs_dev, float* reward_dev, uint8_t* done_dev, void* caller_stream,
+                   int32_t rendezvous);
+int auv_step_wait(auv_handle_t* h, void* caller_stream);
+int auv_set_rendezvous_limit(auv_handle_t* h, double seconds);
+
 /* The same with every sub-batch's launch stamped with its own start / stop HIP event on ITS stream (the kernel's own
  * duration while the other chains run beside it, as a kernel trace reports it): out_ms[n_slices].  Waits for the
  * step's launches (not for earlier work on other streams).  One-launch shape only.                            */
@@ -190,9 +212,13 @@ int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* b
  * return (cumulative reward), timesteps, collision, reached_goal, progress, mean |cross-track error| in metres over the
  * episode's steps (_save_latest_step, environment.py:460-464), world index.  Copies rows [first, first + max_rows) of
  * the log (as far as they exist) to dst_dev on `stream` and returns the number of episodes logged so far in
- * *out_total (this read synchronises `stream`).  The device keeps the last max(65536, 4 N) rows; asking for older
- * ones fails with AUV_ESTATE.  The log restarts (count 0) whenever a bank is loaded or generated.                 */
-int auv_episode_log(auv_handle_t* h, double* dst_dev, int64_t max_rows, int64_t first, int64_t* out_total, void* stream);
+ * *out_total (this read synchronises `stream`; the count is 64-bit and never wraps).  The device keeps the newest
+ * 2^k >= max(65536, 4 N) rows.  A reader that has fallen further behind than that is not refused: the copy starts at the
+ * oldest row still held, *out_first (nullable) tells which row that is (= first when nothing was lost; *out_first - first
+ * rows were overwritten before they were read), and the caller carries on from *out_first + rows copied.  The log
+ * restarts (count 0) whenever a bank is loaded or generated.                                                        */
+int auv_episode_log(auv_handle_t* h, double* dst_dev, int64_t max_rows, int64_t first, int64_t* out_total,
+                    int64_t* out_first, void* stream);
 
 /* Do kernels on these two streams run side by side?  HIP multiplexes streams onto a few hardware queues (four by
  * default); two streams that land on the same one run their kernels one after the other, and sub-batch chains on them
@@ -230,6 +256,19 @@ int auv_graph_launch(auv_handle_t* h, void* stream);
  * hold the LAST step's values after a replay; per-env episode statistics keep accumulating.          */
 int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, float* obs_dev,
                             float* reward_dev, uint8_t* done_dev, int32_t n_steps, void* stream);
+
+/* Captured CHAINS (BASELINE configs[4] names a hipGraph-captured step): n_steps consecutive steps of every slice in the
+ * one-launch shape, each slice a chain with a position of its own in the action ring (so the chains may drift apart like
+ * eager chains do; all of them read the one ring of auv_set_action_ring).
+ *   one_graph = 0   one LINEAR graph per slice; auv_graph_launch_chains replays slice i's graph on streams[i] -- which
+ *                   hardware queue a chain runs on stays the caller's choice (auv_streams_overlap), as for eager chains.
+ *   one_graph = 1   ONE graph whose n_slices branches are the chains (fork behind the root, join at the end), replayed
+ *                   with auv_graph_launch; the runtime places the branches.
+ * obs / reward / done hold the last step's values after a replay.  Needs the one-launch shape for every slice.        */
+int auv_graph_capture_chains(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, const void* actions_dev,
+                             int32_t action_dtype, float* obs_dev, float* reward_dev, uint8_t* done_dev, int32_t n_steps,
+                             int32_t one_graph);
+int auv_graph_launch_chains(auv_handle_t* h, int32_t n_slices, void* const* streams);
 
 /* Action ring (captured graphs only): after this call `actions_dev` of auv_graph_capture is a ring
  * of n_slots consecutive [N][2] buffers; replayed step k reads slot k % n_slots (the position lives

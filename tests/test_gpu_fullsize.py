@@ -183,3 +183,109 @@ def test_config4_shard_graph_captured_8192x256():
     assert n_done >= n                                     # every env turned over at least once
     for e in (eager, g1, g5):
         e.close()
+
+
+@pytest.mark.parametrize("interleave", [False, True])
+def test_bench_launch_shape_4x1024_polygons50(interleave):
+    """The launch configuration bench.py times: 4096 x 180, 50 polygons, the bench's own bank of two
+    worlds per environment (world_seeds), the batch stepped OPEN-LOOP as four chains of 1024 on probe-selected streams
+    (set_sub_batches(4) + step_pipelined), in stretches of several steps without any synchronisation in between so that
+    the chains drift apart as they do in the timed loop; >= 60 steps with forced episode turnover.  Against (a) ONE chain
+    over the same environments, bit for bit after every stretch, and (b) the CPU oracle on a 64-environment subset, every
+    step.  `interleave`: a torch kernel is launched on every chain's stream between its steps (the PPO / pilot
+    situation: foreign kernels beside the one-launch step's in-launch hand-overs)."""
+    import bench
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    from gym_auv_amd.world import build_bank_parallel
+    from oracle.pyoracle import Oracle
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = 9, 20
+    cfg.episode.max_timesteps = 23                          # force episode turnover at full batch size
+    seeds = bench.world_seeds(0, N, N, 2)
+    bank = build_bank_parallel("polygon_world", seeds, procs=min(16, bench.host_cores()), n_polygons=50)
+    W = int(bank["n_worlds"])
+    assert W == 2 * N
+    one = BatchedAuvEnv(cfg, bank, N, device="cuda:0", auto_reset=True)
+    four = BatchedAuvEnv(cfg, bank, N, device="cuda:0", auto_reset=True)
+    slices = four.set_sub_batches(4, strict=True)
+    assert [c for _, c in slices] == [1024] * 4 and four.effective_step_mode(1024) == "one_launch"
+    rs = np.random.RandomState(17)
+    sub = np.sort(np.concatenate([lo + rs.choice(cnt, 16, replace=False) for lo, cnt in slices]))   # 16 of every chain
+    ora = Oracle(make_config(cfg, auto_reset=False), len(sub), bank)
+    w_now = (sub % W).astype(np.int32)
+    one.reset(), four.reset()
+    ora.reset(world_idx=w_now)
+    n_steps, pool_n = 66, 16
+    pool = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (pool_n, N, 2)), dtype=torch.float32, device="cuda:0")
+    a_np = _np(pool).astype(np.float64)
+    scratch = torch.zeros(N, device="cuda:0")
+    fields = ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "EPISODE", "COUNTERS", "NEARBY", "STEP_INFO", "WORLD_IDX",
+              "CULL_LIMITS", "COLLISION", "REWARD64")
+    t, n_done, stretch = 0, 0, 0
+    while t < n_steps:
+        L = min(n_steps - t, 1 + (stretch * 5) % 7)         # stretches of 1, 6, 4, 2, 7, 5, 3, ... steps
+        stretch += 1
+        torch.cuda.synchronize()
+        for j in range(L):
+            four.step_pipelined(pool[(t + j) % pool_n])
+            if interleave:
+                for i, (lo, cnt) in enumerate(slices):
+                    with torch.cuda.stream(four._sub_streams[i]):
+                        torch.mul(four.obs[lo:lo + cnt, 4], 0.15, out=scratch[lo:lo + cnt])
+        for j in range(L):
+            obs, rew, done, _ = one.step(pool[(t + j) % pool_n])
+            o_obs, o_rew, o_done = ora.step(a_np[(t + j) % pool_n][sub])
+            g_done = _np(done)
+            np.testing.assert_array_equal(g_done[sub], o_done)
+            if o_done.any():
+                w_now = np.where(o_done > 0, (w_now + N) % W, w_now).astype(np.int32)
+                o_obs_r = ora.reset(mask=o_done, world_idx=w_now)
+                o_obs = np.where(o_done[:, None] > 0, o_obs_r, o_obs)
+            np.testing.assert_allclose(_np(obs)[sub], o_obs, rtol=0, atol=1e-6, err_msg="obs step %d" % (t + j))
+            np.testing.assert_allclose(_np(rew)[sub], o_rew, rtol=1e-6, atol=1e-4)
+            n_done += int(g_done.sum())
+        t += L
+        torch.cuda.synchronize()
+        assert torch.equal(one.obs, four.obs) and torch.equal(one.reward, four.reward) and torch.equal(one.done, four.done), t
+        for f in fields:
+            assert torch.equal(one.read(f), four.read(f)), (t, f)
+    np.testing.assert_allclose(_np(four.read("STATE"))[:, sub], ora.read("STATE"), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(_np(four.read("LIDAR_D"))[sub], ora.read("LIDAR_D"), rtol=0, atol=1e-9)
+    assert n_done >= 2 * N                                  # every environment turned over, most of them twice
+    assert four.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0)
+    one.close(), four.close()
+
+
+@pytest.mark.parametrize("one_graph", [False, True])
+def test_config4_shard_captured_chains_8192x256(one_graph):
+    """BASELINE configs[4] names a hipGraph-captured step: the 8192 x 256 mixed shard stepped by CAPTURED CHAINS -- five steps
+    of each of four sub-batches per replay, as four linear graphs on the sub-batches' streams or as one graph with four
+    branches -- bit for bit what eager launches compute over 40 steps with auto-reset (every chain walks the action ring
+    with a position of its own)."""
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    n, ns, nps, steps, ring, per = 8192, 16, 16, 40, 10, 5
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
+    cfg.episode.max_timesteps = 17
+    bank = _bank("mixed47", 64)
+    rs = np.random.RandomState(11)
+    acts = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (ring, n, 2)), dtype=torch.float32, device="cuda:0")
+    eager = BatchedAuvEnv(cfg, bank, n, device="cuda:0", auto_reset=True)
+    chains = BatchedAuvEnv(cfg, bank, n, device="cuda:0", auto_reset=True)
+    eager.reset(), chains.reset()
+    chains.set_sub_batches(4, strict=True)
+    chains.capture_graph_chains(torch.float32, slots=ring, steps=per, one_graph=one_graph).copy_(acts)
+    for t in range(steps):
+        obs, rew, done, _ = eager.step(acts[t % ring])
+        if t % per == per - 1:
+            o, r, d, _ = chains.step_graph()
+            if t % (2 * per) == per - 1:
+                continue                                     # (two replays back to back: the chains run ten steps unsynchronised)
+            torch.cuda.synchronize()
+            assert torch.equal(obs, o) and torch.equal(rew, r) and torch.equal(done, d), "captured chains, step %d" % t
+    torch.cuda.synchronize()
+    for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE", "COUNTERS", "NEARBY", "WORLD_IDX"):
+        assert torch.equal(eager.read(f), chains.read(f)), f
+    assert int(eager.read("COUNTERS")[:, 2].sum()) >= n     # every env turned over at least once
+    assert chains.health()["timeouts"] == 0
+    eager.close(), chains.close()

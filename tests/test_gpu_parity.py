@@ -429,6 +429,134 @@ def test_sub_batches_bitwise(mode, n, k):
         asy.step_wait()                                        # nothing pending
 
 
+def _cp_waits_supported():
+    """hipStreamWaitValue64 on this stack?  (AUV_RDV_CP; the other two mechanisms need nothing special)"""
+    bank = _mixed_bank(4)
+    e = _env(effective_reference_config(use_lidar=True), bank, 128)
+    e.reset()
+    e.set_sub_batches(2, probe_streams=False)
+    try:
+        e.step_async(torch.zeros((128, 2), device="cuda:0"), rendezvous="cp")
+        e.step_wait()
+        torch.cuda.synchronize()
+        return True
+    except RuntimeError:
+        return False
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("rendezvous", ["events", "device", "cp"])
+@pytest.mark.parametrize("inline_first", [False, True])
+def test_step_async_rendezvous_closed_loop_bitwise(rendezvous, inline_first):
+    """VecEnv step_async / step_wait (scripts/run.py:293-296) with the chains ordered against the caller's stream by each
+    of the library's three mechanisms (AUV_RDV_*), the first chain on its own stream or on the caller's: a CLOSED loop --
+    the next action is computed by a torch kernel on the caller's stream from the observation step_wait has just
+    returned -- against the same loop through plain step(), bit for bit, with auto-reset; results consumed on the
+    caller's stream without any host synchronisation in between (a missing ordering shows as a difference)."""
+    if rendezvous == "cp" and not _cp_waits_supported():
+        pytest.skip("hipStreamWaitValue64 / WriteValue64 not available on this stack")
+    n, k = 1000, 4
+    bank = _mixed_bank(32)
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.episode.max_timesteps = 9
+    ref, asy = _env(cfg, bank, n), _env(cfg, bank, n)
+    side = torch.cuda.Stream(device="cuda:0")              # the caller's stream is not the default stream
+    with torch.cuda.stream(side):
+        ref.reset(), asy.reset()
+        asy.set_sub_batches(k, inline_first=inline_first)
+        asy.rendezvous = rendezvous
+        asy.set_rendezvous_limit(3.0)                      # (a broken ordering must fail this test, not hang the box)
+        a_ref = torch.zeros((n, 2), device="cuda:0")
+        a_asy = torch.zeros((n, 2), device="cuda:0")
+        a_ref[:, 0] = a_asy[:, 0] = 1.0
+        trace_ref, trace_asy = [], []
+        for t in range(60):
+            # the pilot of bench.py --actions pilot, plus a dependence on the reward so that every output is consumed
+            o, r, d, _ = ref.step(a_ref)
+            torch.mul(o[:, 4], 0.15, out=a_ref[:, 1])
+            a_ref[:, 0] = torch.where(r < -10.0, 0.5, 1.0)
+            trace_ref.append((o.sum(dtype=torch.float64), r.sum(dtype=torch.float64), d.sum()))
+            asy.step_async(a_asy)
+            o, r, d, _ = asy.step_wait()
+            torch.mul(o[:, 4], 0.15, out=a_asy[:, 1])
+            a_asy[:, 0] = torch.where(r < -10.0, 0.5, 1.0)
+            trace_asy.append((o.sum(dtype=torch.float64), r.sum(dtype=torch.float64), d.sum()))
+    torch.cuda.synchronize()
+    for t, (x, y) in enumerate(zip(trace_ref, trace_asy)):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), (t, u, v)
+    for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "EPISODE", "COUNTERS", "WORLD_IDX", "REWARD64"):
+        assert torch.equal(ref.read(f), asy.read(f)), f
+    assert int(ref.read("COUNTERS")[:, 2].sum()) > n       # episodes turned over
+    assert asy.health()["timeouts"] == 0 and asy.health()["pending"] == 0
+
+
+@pytest.mark.parametrize("kind", ["cpu", "f16", "strided", "int"])
+def test_step_async_converts_actions_before_ordering(kind):
+    """actions that need a conversion (host tensor, half precision, non-contiguous view, integers) are converted
+    on the caller's stream BEFORE the chains are ordered behind it, and the converted buffer lives until step_wait --
+    bit-identical to step() with the same values."""
+    n, k = 512, 4
+    bank = _mixed_bank(16)
+    cfg = effective_reference_config(use_lidar=True)
+    ref, asy, pip = _env(cfg, bank, n), _env(cfg, bank, n), _env(cfg, bank, n)
+    for e in (ref, asy, pip):
+        e.reset()
+    asy.set_sub_batches(k), pip.set_sub_batches(k)
+    rs = np.random.RandomState(5)
+    for t in range(12):
+        base = rs.uniform([-1, -0.15], [1, 0.15], (n, 2)).astype(np.float32)
+        if kind == "cpu":
+            a = torch.as_tensor(base)                                           # host memory
+        elif kind == "f16":
+            a = torch.as_tensor(base, device="cuda:0").half()
+        elif kind == "int":
+            a = torch.as_tensor(np.round(base * 3), device="cuda:0").to(torch.int32)
+        else:
+            wide = torch.zeros((n, 4), device="cuda:0")
+            wide[:, ::2] = torch.as_tensor(base, device="cuda:0")
+            a = wide[:, ::2]                                                    # a non-contiguous view
+        exact = a.to(device="cuda:0", dtype=torch.float32).contiguous()
+        o0, r0, d0, _ = ref.step(exact)
+        asy.step_async(a)
+        # churn the caching allocator while the chains may still be reading the converted temporary
+        junk = [torch.full((n, 2), float("nan"), device="cuda:0") for _ in range(8)]
+        o1, r1, d1, _ = asy.step_wait()
+        pip.step_pipelined(a)
+        junk += [torch.full((n, 2), float("nan"), device="cuda:0") for _ in range(8)]
+        torch.cuda.synchronize()
+        del junk
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1), t
+        assert torch.equal(o0, pip.obs) and torch.equal(r0, pip.reward) and torch.equal(d0, pip.done), t
+
+
+def test_episode_log_overflow_is_not_fatal():
+    """a reader that falls behind the episode log's ring (more episodes than it holds between two reads) gets
+    the newest rows and a count of the lost ones; later reads work."""
+    n = 256
+    bank = _mixed_bank(8)
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.episode.max_timesteps = 2                           # every environment ends an episode every other step
+    env = _env(cfg, bank, n)
+    env.reset()
+    a = torch.zeros((n, 2), device="cuda:0")
+    cap = 65536                                             # max(65536, 4 n)
+    steps = 2 * (cap // n) + 40                             # > cap episodes without a read
+    for _ in range(steps):
+        env.step(a)
+    rows = env.episode_log()
+    total = int(env.read("COUNTERS")[:, 2].sum())
+    assert total > cap
+    assert rows.shape[0] == cap and env.episode_log_dropped == total - cap
+    assert (rows[:, 2] == 2).all()                          # every logged episode is two steps long
+    for _ in range(4):
+        env.step(a)
+    rows2 = env.episode_log()
+    assert rows2.shape[0] == 2 * n and env.episode_log_dropped == total - cap
+    assert env.episode_log().shape[0] == 0
+
+
 def test_action_ring_graph_and_eager_after_capture():
     """The action ring belongs to captured graphs: replay k consumes slot k % n.  An eager step() on
     an env whose ring is on (after capture_graph(slots > 1)) reads its [N, 2] tensor as a plain
