@@ -82,7 +82,7 @@ def parse():
                          "against each other or a consumer); async: VecEnv step_async + step_wait EVERY step (a full rendezvous of "
                          "all chains with the caller's stream, scripts/run.py:293-296); step: env.step() on the caller's stream "
                          "(one chain).  auto: pipelined for resident actions with sub-batches > 1, else step")
-    ap.add_argument("--rendezvous", default="events", choices=["events", "device", "cp"],
+    ap.add_argument("--rendezvous", default="device", choices=["events", "device", "cp"],
                     help="--api async: how the chains are ordered against the caller's stream (include/auv_hip.h, AUV_RDV_*)")
     ap.add_argument("--inline-first", type=int, default=0,
                     help="--api async: 1 = the first sub-batch runs on the caller's stream, only the others on streams of their own")

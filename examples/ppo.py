@@ -68,10 +68,23 @@ class ActorCritic(nn.Module):
         return (0.5 + LOG_SQRT_2PI + self.log_std).sum()
 
 
-def clip_grad_norm(params, max_norm):
-    """Global-norm gradient clipping in plain tensor operations (no host synchronisation)."""
+def clip_grad_norm(params, max_norm, stacked=False):
+    """Global-norm gradient clipping in plain tensor operations (no host synchronisation), safe inside a captured graph.
+    The norm is accumulated with 0-d additions, NOT torch.stack / torch.cat: on ROCm those stage the table of their inputs'
+    addresses through pinned host memory with an asynchronous copy, a stream capture records that copy with the HOST
+    address, the caching host allocator recycles the buffer, and a replay then uploads somebody else's bytes as the table --
+    the "gradient norm" comes out as inf although every gradient element is finite, the clip scales the gradients to
+    zero and the policy freezes silently (what round 2 / 3's --graph-update did; `stacked` keeps the
+    old form for profiles/r04/ppo_graph_update_*stacked.log)."""
     grads = [p.grad for p in params if p.grad is not None]
-    total = torch.sqrt(torch.stack([(g * g).sum() for g in grads]).sum())
+    if stacked:
+        total = torch.sqrt(torch.stack([(g * g).sum() for g in grads]).sum())
+    else:
+        sq = None
+        for g in grads:
+            s = (g * g).sum()
+            sq = s if sq is None else sq + s
+        total = torch.sqrt(sq)
     coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
     for g in grads:
         g.mul_(coef)
@@ -95,7 +108,8 @@ def average_gradients(params, world):
 
 def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=0, log_every=1,
           task="colav", step_mode=None, graph_rollout=False, sub_batches=4, minibatches=32,
-          reward_scale=0.01, reward_clip=0.0, min_cumulative_reward=None, act_space="raw", ret_norm=False, orthogonal=False, ent_coef=0.01, log_std=-0.5, lr=2e-4):
+          reward_scale=0.01, reward_clip=0.0, min_cumulative_reward=None, act_space="raw", ret_norm=False, orthogonal=False, ent_coef=0.01, log_std=-0.5, lr=2e-4,
+          fused_policy=True, graph_update=False):
     from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
@@ -138,7 +152,18 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     if world > 1:   # data parallel over GPUs: same initial weights, gradients averaged over RCCL
         for prm in params:
             torch.distributed.broadcast(prm.data, 0)
-    opt = torch.optim.Adam(params, lr=lr)
+    graph_update = int(graph_update) if world == 1 else 0      # (the gradient all-reduce of data parallelism stays eager)
+    # (graph_update == 2: the captured update with round 3's torch.stack-based gradient norm; 3: that, a stack-built record and
+    # per-update concatenations outside the graph -- the configuration that froze the weights, kept to SHOW the failure)
+    opt = torch.optim.Adam(params, lr=lr, capturable=bool(graph_update))
+    # --graph-update: a device-side record of every minibatch step (the two gradient norms before clipping, the loss, the
+    # largest |advantage| and probability ratio, counts of non-finite inputs and gradient elements), written by the step
+    # itself -- also inside a captured graph, where nothing can be printed -- and read once per update
+    DIAG = 8192
+    diag = torch.zeros((DIAG, 8), device=device)
+    diag_pos = torch.zeros(1, dtype=torch.int64, device=device)
+    diag_row = torch.zeros((1, 8), device=device)
+    upd_graph, upd_in, upd_loss = None, None, None
     gamma, lam, clip, epochs, n_mb = 0.999, 0.98, 0.2, 4, int(minibatches)
     ret_mean, ret_std = torch.zeros((), device=device), torch.ones((), device=device)
     T, Dobs = int(rollout), env.obs_dim
@@ -174,6 +199,15 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             b["Dn"].index_copy_(0, b["t"], env.done[lo:lo + cnt].float().unsqueeze(0))
             b["t"] += 1
 
+    fused = None
+    if fused_policy:
+        # the policy in the loop as ONE HIP launch per chain and step (gym_auv_amd/policy.py, csrc/k6_policy.hip): actor and
+        # critic on the matrix cores in f32, sampling / log-probability / transition stores in its epilogue; a whole rollout
+        # of every chain is one C call.  The torch modules stay the owners of the weights (refresh() after each update).
+        from gym_auv_amd.policy import FusedActorCritic
+        fused = FusedActorCritic(net, env, rollout=T, reward_scale=reward_scale, reward_clip=reward_clip, act_mid=a_mid.tolist(),
+                                 act_half=a_half.tolist(), clip_lo=c_lo.tolist(), clip_hi=c_hi.tolist(), seed=1000 * seed + rank)
+        graph_rollout = False
     graphs = None
     if graph_rollout:
         # every chain's step as ONE captured device graph (replayed on the chain's stream)
@@ -202,36 +236,60 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             env.reset()
         t0 = time.time()
         cur = torch.cuda.current_stream(device)
-        for i in range(K):
-            buf[i]["t"].zero_()                           # (on the caller's stream, BEFORE the chain is told to wait for it)
-            streams[i].wait_stream(cur)                   # (the update of the previous round wrote the weights there)
-        for _ in range(T):
+        if fused is not None:
+            fused.refresh()                               # (the update of the previous round moved the weights)
             for i in range(K):
-                with torch.cuda.stream(streams[i]):
-                    if graphs is not None:
-                        graphs[i].replay()
-                    else:
-                        chain_step(i)
-        for i in range(K):
-            cur.wait_stream(streams[i])
+                streams[i].wait_stream(cur)
+            fused.begin_rollout()
+            fused.rollout(T)                              # T x K x (policy launch + environment step), one C call
+            for i in range(K):
+                cur.wait_stream(streams[i])
+        else:
+            for i in range(K):
+                buf[i]["t"].zero_()                       # (on the caller's stream, BEFORE the chain is told to wait for it)
+                streams[i].wait_stream(cur)               # (the update of the previous round wrote the weights there)
+            for _ in range(T):
+                for i in range(K):
+                    with torch.cuda.stream(streams[i]):
+                        if graphs is not None:
+                            graphs[i].replay()
+                        else:
+                            chain_step(i)
+            for i in range(K):
+                cur.wait_stream(streams[i])
+        torch.cuda.synchronize()
+        t_roll_only = time.time() - t0                   # the rollout proper: policy in the loop, environment steps, transition stores
         if env.health()["pending"]:                      # (a replayed step is not checked by the library: ADVICE r2)
             raise RuntimeError("in-launch hand-over timed out during the rollout; env.step() will recover and report")
         with torch.no_grad():
-            O = torch.cat([b["O"] for b in buf], 1)
-            A = torch.cat([b["A"] for b in buf], 1)
-            LP = torch.cat([b["LP"] for b in buf], 1)
-            V = torch.cat([b["V"] for b in buf], 1) * ret_std + ret_mean        # value head predicts normalised returns
-            R = torch.cat([b["R"] for b in buf], 1)
-            Dn = torch.cat([b["Dn"] for b in buf], 1)
+            if fused is not None:
+                O, A, LP, V, R, Dn = fused.buffers()
+                V = V * ret_std + ret_mean
+                if graph_update == 3:
+                    # (the configuration that froze in profiles/r04/ppo_graph_update_colav_stacked_frozen.log: stack-based
+                    # norms inside the captured update AND concatenations of the chains' buffers outside it, every update)
+                    for x in (O, A, LP, R, Dn, fused.V):
+                        torch.cat([x[:, lo:lo + cnt] for lo, cnt in slices], 1)
+            else:
+                O = torch.cat([b["O"] for b in buf], 1)
+                A = torch.cat([b["A"] for b in buf], 1)
+                LP = torch.cat([b["LP"] for b in buf], 1)
+                V = torch.cat([b["V"] for b in buf], 1) * ret_std + ret_mean        # value head predicts normalised returns
+                R = torch.cat([b["R"] for b in buf], 1)
+                Dn = torch.cat([b["Dn"] for b in buf], 1)
             last_v = net.v(env.obs).squeeze(-1) * ret_std + ret_mean
-            adv = torch.zeros_like(R)
-            gae = torch.zeros(envs, device=device)
-            for t in reversed(range(T)):
-                nv = last_v if t == T - 1 else V[t + 1]
-                delta = R[t] + gamma * nv * (1 - Dn[t]) - V[t]
-                gae = delta + gamma * lam * (1 - Dn[t]) * gae
-                adv[t] = gae
-            RET = adv + V
+            if fused is not None:
+                adv, RET = fused.gae(V, last_v, gamma, lam)            # one launch (auv_gae) instead of T x 6 small ones
+            else:
+                adv = torch.zeros_like(R)
+                gae = torch.zeros(envs, device=device)
+                for t in reversed(range(T)):
+                    nv = last_v if t == T - 1 else V[t + 1]
+                    delta = R[t] + gamma * nv * (1 - Dn[t]) - V[t]
+                    gae = delta + gamma * lam * (1 - Dn[t]) * gae
+                    adv[t] = gae
+            if fused is None:
+                RET = adv + V
             # running statistics of the returns (one pass of exponential averaging per update)
             m, s = RET.mean(), RET.std()
             if world > 1:
@@ -257,24 +315,55 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             pg = -torch.min(ratio * advn, ratio.clamp(1 - clip, 1 + clip) * advn).mean()
             vf = 0.5 * (net.v(o).squeeze(-1) - retn).pow(2).mean()
             loss = pg + 0.5 * vf - ent_coef * net.entropy()
-            opt.zero_grad(set_to_none=True)
+            opt.zero_grad(set_to_none=not graph_update)
             loss.backward()
             average_gradients(params, world)
             # (policy and value net are separate networks: clipped separately, so that a value loss swollen by a rare
             # -5000 collision return cannot scale the policy's gradient away under a shared norm)
-            clip_grad_norm(pi_params, 0.5)
-            clip_grad_norm(v_params, 0.5)
+            bad_in = sum((~torch.isfinite(x)).sum() for x in (o, a, lp, advn, retn))
+            bad_g = sum((~torch.isfinite(q.grad)).sum() for q in params if q.grad is not None)
+            n_pi = clip_grad_norm(pi_params, 0.5, stacked=graph_update >= 2)
+            n_v = clip_grad_norm(v_params, 0.5, stacked=graph_update >= 2)
+            # (the record is filled element by element: no stack / cat inside a region that may be captured, see clip_grad_norm)
+            if graph_update == 3:
+                diag_row.copy_(torch.stack([n_pi, n_v, loss.detach(), advn.abs().max(), ratio.detach().max(), bad_in.float(), bad_g.float(),
+                                            torch.ones((), device=device)]).unsqueeze(0))
+            else:
+                for j, x in enumerate((n_pi, n_v, loss.detach(), advn.abs().max(), ratio.detach().max(), bad_in, bad_g)):
+                    diag_row[0, j].copy_(x)
+            diag.index_copy_(0, diag_pos % DIAG, diag_row)
+            diag_pos.add_(1)
             opt.step()
             return loss
 
-        # (The minibatch step as ONE captured device graph -- round 2's --graph-update -- is gone: on this stack the replayed
-        # graph intermittently read its own gradient norm as inf, which zeroes the clipped gradients and silently freezes the
-        # policy; round 2's Colav runs "learnt thrust only" for that reason.  The same construct in isolation replays
-        # correctly (tools/dbg_graph.py); the cause inside this loop was not found, so the update is eager.)
+        # --graph-update: a minibatch's forward, backward, clipping and Adam step as ONE captured device graph with static input
+        # buffers, refilled by gathers before every replay.  Round 3 removed this path because a replayed graph "read its own
+        # gradient norm as inf" and froze the weights without the cause having been found; it is back with the record
+        # above, so that a freeze names its cause: see DESIGN.md section 8 for what the record showed.
+        d0 = int(diag_pos.item())
+        mb_size = n_total // n_mb
         for _ in range(epochs):
             perm = torch.randperm(n_total, device=device)
             for mb in perm.chunk(n_mb):
-                loss = minibatch_step(O[mb], A[mb], LP[mb], ADV[mb], RETn[mb])
+                if not graph_update or mb.numel() != mb_size:      # (a ragged last chunk would RESIZE the static buffers)
+                    loss = minibatch_step(O[mb], A[mb], LP[mb], ADV[mb], RETn[mb])
+                    continue
+                if upd_in is None:
+                    upd_in = [O[mb].clone(), A[mb].clone(), LP[mb].clone(), ADV[mb].clone(), RETn[mb].clone()]
+                    side = torch.cuda.Stream(device=device)
+                    side.wait_stream(torch.cuda.current_stream(device))
+                    with torch.cuda.stream(side):                  # (warm-up off the capture, as torch asks: three real steps)
+                        for _w in range(3):
+                            minibatch_step(*upd_in)
+                    torch.cuda.current_stream(device).wait_stream(side)
+                    upd_graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(upd_graph):
+                        upd_loss = minibatch_step(*upd_in)
+                    continue
+                for dst, src in zip(upd_in, (O, A, LP, ADV, RETn)):
+                    torch.index_select(src, 0, mb, out=dst)
+                upd_graph.replay()
+                loss = upd_loss
         torch.cuda.synchronize()
         dt_all = time.time() - t0
         # ---- what happened: step rewards of the rollout, and the episodes that ended during it (library's episode log)
@@ -286,16 +375,25 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
         else:
             col = goal = ep_ret = ep_len = ep_prog = float("nan")
         surge, he, cte = float(O[:, 0].mean()), float(O[:, 4].abs().mean()), float(O[:, 5].abs().mean()) * 100
-        history.append(dict(update=upd, mean_step_reward=mean_r, loss=float(loss.item()), surge=surge, heading_error=he,
+        d1 = int(diag_pos.item())
+        rows = diag[torch.arange(d0, d1, device=device) % DIAG] if d1 - d0 <= DIAG else diag
+        steps_bad = int((~torch.isfinite(rows[:, :3])).any(1).sum()) + int((rows[:, 5:7] > 0).any(1).sum())
+        history.append(dict(update=upd, minibatch_steps=d1 - d0, minibatch_steps_nonfinite=steps_bad,
+                            grad_norm_pi=float(rows[:, 0].mean()), grad_norm_v=float(rows[:, 1].mean()), max_ratio=float(rows[:, 4].max()),
+                            mean_step_reward=mean_r, loss=float(loss.item()), surge=surge, heading_error=he,
                             weight_l1=float(sum(p_.detach().abs().sum() for p_ in pi_params)),
                             cross_track=cte, episodes=int(ep.shape[0]), goal_rate=goal, collision_rate=col, ep_return=ep_ret,
-                            ep_len=ep_len, ep_progress=ep_prog, rollout_sps=world * n_total / t_roll, sps=world * n_total / dt_all))
+                            ep_len=ep_len, ep_progress=ep_prog, rollout_sps=world * n_total / t_roll_only, rollout_gae_sps=world * n_total / t_roll, sps=world * n_total / dt_all))
         if rank == 0 and (upd % log_every == 0 or upd == updates - 1):
+            if steps_bad:
+                bad = rows[(~torch.isfinite(rows[:, :3])).any(1) | (rows[:, 5:7] > 0).any(1)][:4]
+                log("update %4d: %d of %d minibatch steps non-finite; first rows [|g_pi|, |g_v|, loss, max|adv|, max ratio, bad inputs, bad grads]: %s"
+                    % (upd, steps_bad, d1 - d0, bad[:, :7].tolist()))
             log("update %4d  loss %9.4f  |w| %.4f  step reward %7.3f  surge %.3f  |he| %.2f  |cte| %6.1f m  std %s | episodes %5d: goal %.3f collision %.3f "
                 "other %.3f  return %8.1f  length %6.1f  progress %.3f | rollout %.2e env-steps/s (policy in the loop), %.2e incl. learning"
                 % (upd, float(loss.item()), float(sum(p_.detach().abs().sum() for p_ in pi_params)), mean_r, surge, he, cte,
                    ["%.3f" % x for x in net.log_std.exp().tolist()], ep.shape[0], goal, col,
-                   1.0 - goal - col if ep.shape[0] else float("nan"), ep_ret, ep_len, ep_prog, world * n_total / t_roll, world * n_total / dt_all))
+                   1.0 - goal - col if ep.shape[0] else float("nan"), ep_ret, ep_len, ep_prog, world * n_total / t_roll_only, world * n_total / dt_all))
     # the one collective of the environment side: finished-episode statistics of all ranks
     stats = D.gather_episode_stats(env.episode_stats())
     if rank == 0 and history:
@@ -328,7 +426,11 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--sub-batches", type=int, default=4, help="rollout chains (BatchedAuvEnv.set_sub_batches)")
     ap.add_argument("--minibatches", type=int, default=32)
-    ap.add_argument("--graph-rollout", type=int, default=0, help="1: one captured device graph per chain and rollout step")
+    ap.add_argument("--graph-rollout", type=int, default=0, help="1: one captured device graph per chain and rollout step (torch-module policy only)")
+    ap.add_argument("--graph-update", type=int, default=0,
+                    help="1: a minibatch's forward, backward, clipping and Adam step as one captured device graph (single rank)")
+    ap.add_argument("--fused-policy", type=int, default=1,
+                    help="1 (default): the policy in the loop is ONE HIP launch per chain and step (gym_auv_amd/policy.py); 0: the torch modules")
     ap.add_argument("--step-mode", default=None, help="launch shape of a step (BatchedAuvEnv.STEP_MODES); default: the library's")
     ap.add_argument("--act-space", default="raw", choices=["raw", "normalized"])
     ap.add_argument("--ret-norm", type=int, default=0)
@@ -343,7 +445,7 @@ if __name__ == "__main__":
     from gym_auv_amd import distributed as D
     _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
     train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, seed=a.seed, worlds=a.worlds, regen=a.regen, log_every=a.log_every,
-          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout),
+          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout), fused_policy=bool(a.fused_policy), graph_update=a.graph_update,
           sub_batches=a.sub_batches, minibatches=a.minibatches, act_space=a.act_space, ret_norm=bool(a.ret_norm),
           orthogonal=bool(a.orthogonal), ent_coef=a.ent_coef, log_std=a.log_std, lr=a.lr, reward_clip=a.reward_clip,
           min_cumulative_reward=a.min_cumulative_reward)

@@ -22,11 +22,11 @@ AUV_F32, AUV_F64 = 0, 1
 AUV_RDV_EVENTS, AUV_RDV_DEVICE, AUV_RDV_CP = 0, 1, 2
 
 FIELDS = dict(STATE=0, LIDAR_D=1, OBS64=2, REWARD64=3, INFO64=4, WORLD_IDX=5, COUNTERS=6,
-              MOVER_STATE=7, NEARBY=8, EPISODE=9, CULL_LIMITS=10, NAV64=11, COLLISION=12, STAMPS=13, STEP_INFO=14)
+              MOVER_STATE=7, NEARBY=8, EPISODE=9, CULL_LIMITS=10, NAV64=11, COLLISION=12, STAMPS=13, STEP_INFO=14, BROKEN=15)
 FIELD_DTYPES = dict(STATE=np.float64, LIDAR_D=np.float64, OBS64=np.float64, REWARD64=np.float64,
                     INFO64=np.float64, WORLD_IDX=np.int32, COUNTERS=np.int32, MOVER_STATE=np.float64,
                     NEARBY=np.uint8, EPISODE=np.float64, CULL_LIMITS=np.int32, NAV64=np.float64,
-                    COLLISION=np.uint8, STAMPS=np.int64, STEP_INFO=np.float64)
+                    COLLISION=np.uint8, STAMPS=np.int64, STEP_INFO=np.float64, BROKEN=np.uint8)
 
 
 class AuvLibraryError(RuntimeError):
@@ -105,6 +105,18 @@ def make_bank_struct(bank: Dict[str, np.ndarray]) -> Tuple[AuvWorldBank, list]:
     return s, keep
 
 
+class AuvPolicyIO(C.Structure):
+    """== auv_policy_io_t (include/auv_hip.h): the buffers of one sub-batch's policy launch"""
+    _fields_ = [
+        ("obs", C.c_void_p), ("params", C.c_void_p), ("ctr", C.c_void_p), ("reward_in", C.c_void_p), ("done_in", C.c_void_p),
+        ("actions_out", C.c_void_p), ("O", C.c_void_p), ("A", C.c_void_p), ("LP", C.c_void_p), ("V", C.c_void_p),
+        ("R", C.c_void_p), ("Dn", C.c_void_p), ("mu_out", C.c_void_p), ("eps_out", C.c_void_p),
+        ("seed", C.c_uint64), ("obs_dim", C.c_int32), ("T", C.c_int32), ("ld", C.c_int32), ("env_base", C.c_int32),
+        ("act_mid", C.c_float * 2), ("act_half", C.c_float * 2), ("clip_lo", C.c_float * 2), ("clip_hi", C.c_float * 2),
+        ("reward_scale", C.c_float), ("reward_clip", C.c_float),
+    ]
+
+
 _lib = None
 
 
@@ -141,10 +153,15 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_set_rendezvous_limit": (C.c_int, [vp, C.c_double]),
         "auv_graph_capture_chains": (C.c_int, [vp, i32, C.POINTER(i32), vp, i32, vp, vp, vp, i32, i32]),
         "auv_graph_launch_chains": (C.c_int, [vp, i32, C.POINTER(vp)]),
+        "auv_policy_param_floats": (sz, [i32]),
+        "auv_policy_act": (C.c_int, [vp, i32, i32, C.POINTER(AuvPolicyIO), vp]),
+        "auv_gae": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, vp]),
+        "auv_policy_rollout": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(AuvPolicyIO), vp, vp, vp, i32, i32]),
         "auv_step_pipelined_timed": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp, C.POINTER(C.c_float)]),
         "auv_streams_overlap": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float)]),
         "auv_episode_log": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),
         "auv_health": (C.c_int, [vp, C.POINTER(i32)]),
+        "auv_probe_streams": (C.c_int, [vp, i32, C.POINTER(vp)]),
         "auv_effective_step_mode": (C.c_int, [vp, i32]),
         "auv_step_dynamics": (C.c_int, [vp, vp, i32, vp]),
         "auv_lidar": (C.c_int, [vp, i32, vp]),
@@ -181,7 +198,7 @@ def load_library(path: str = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset", "auv_step", "auv_step_slice",
                     "auv_step_pipelined", "auv_step_async", "auv_step_wait", "auv_set_rendezvous_limit", "auv_graph_capture_chains",
-                    "auv_graph_launch_chains", "auv_step_pipelined_timed", "auv_streams_overlap", "auv_episode_log", "auv_health", "auv_effective_step_mode",
+                    "auv_graph_launch_chains", "auv_policy_param_floats", "auv_policy_act", "auv_gae", "auv_policy_rollout", "auv_step_pipelined_timed", "auv_streams_overlap", "auv_episode_log", "auv_health", "auv_probe_streams", "auv_effective_step_mode",
                     "auv_step_dynamics", "auv_lidar", "auv_nav_reward", "auv_read", "auv_write",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",

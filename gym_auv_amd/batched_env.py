@@ -88,7 +88,10 @@ class BatchedAuvEnv:
         self.step_mode = "auto"
         self._slices = None
         self.sub_batches = 1
-        self.rendezvous = "events"      # how step_async / step_wait order the chains against the caller's stream
+        # how step_async / step_wait order chains on other streams against the caller's: "device" (one-wave kernels and two
+        # words in device memory) beats "cp" (command-processor waits) beats "events" at every chain count measured
+        # (4096 x 180: 80 / 68 / 40 M env-steps/s with four chains, 100 / 92 / 56 M with two; profiles/r04/sweep_api*.jsonl)
+        self.rendezvous = "device"
         self.stream_probe_s = 0.0
         self._chain_graph = None
 
@@ -223,6 +226,8 @@ class BatchedAuvEnv:
         self._streams_c = (C.c_void_p * self.sub_batches)(*[st.cuda_stream for st in self._sub_streams])
         self._async_pending = False
         self._chain_graph = None
+        if self.sub_batches > 1 and self.effective_step_mode(per) == "one_launch":
+            self.probe_streams()        # the hand-overs' dispatch-order assumption, probed in the shape production runs
         return self._slices
 
     def step_slice(self, i: int, actions: torch.Tensor, stream: Optional[torch.cuda.Stream] = None):
@@ -325,12 +330,29 @@ class BatchedAuvEnv:
 
     def health(self) -> Dict[str, int]:
         """State of the in-launch hand-overs (auv_health; reads host memory only, no synchronisation): `handover_ok`,
-        `probe_failures` of the load-time dispatch-order probe, `timeouts` so far, `pending` = a time-out the next
-        step call will recover from (every environment reset, three-launch shape from then on, one RuntimeError).
+        `probe_failures` of the last dispatch-order probe, `timeouts` so far, `pending` = a time-out the next step call will
+        recover from (the environments the waves that gave up left unfinished are reset, three-launch shape from then on,
+        one RuntimeError).  After a recovery `last_timeout()` names the launch that reported and how many were reset.
         A loop that replays a captured step (torch CUDAGraph around `step`) should look at `pending` once per rollout."""
-        out = (C.c_int32 * 4)()
+        out = (C.c_int32 * 8)()
         _check(_LIB.auv_health(self._h, out), "auv_health")
+        self._health_raw = [int(x) for x in out]
         return dict(handover_ok=int(out[0]), probe_failures=int(out[1]), timeouts=int(out[2]), pending=int(out[3]))
+
+    def last_timeout(self) -> Dict[str, int]:
+        """The last hand-over time-out this handle recovered from: the slice [e0, e0 + ne) of the launch that reported it
+        and the number of environments the recovery reset (e0 = -1: none so far)."""
+        self.health()
+        return dict(e0=self._health_raw[4], ne=self._health_raw[5], reset_envs=self._health_raw[6])
+
+    def probe_streams(self, streams=None) -> int:
+        """Run the dispatch-order probe on the sub-batch streams (auv_probe_streams: one probe launch per stream, all in
+        flight together, a foreign kernel behind each); returns the number of polls that ran out (0: the in-launch
+        hand-overs stay in use).  set_sub_batches calls it."""
+        sts = self._sub_streams if streams is None else streams
+        arr = (C.c_void_p * len(sts))(*[st.cuda_stream for st in sts])
+        _check(_LIB.auv_probe_streams(self._h, len(sts), arr), "auv_probe_streams")
+        return self.health()["probe_failures"]
 
     # per-kernel entry points (parity tests)
     def step_dynamics(self, actions: torch.Tensor):
@@ -474,7 +496,7 @@ class BatchedAuvEnv:
         n, S = self.n_envs, self.n_sensors
         return dict(STATE=(6, n), LIDAR_D=(n, S), OBS64=(n, 6 + S), REWARD64=(n,), INFO64=(n, 8),
                     WORLD_IDX=(n,), COUNTERS=(n, 4), MOVER_STATE=(n, self.m_max, 4), NEARBY=(n, self.k_max),
-                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,), STAMPS=(n, 16), STEP_INFO=(n, 4))[name]
+                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,), STAMPS=(n, 16), STEP_INFO=(n, 4), BROKEN=(n,))[name]
 
     def read(self, name: str) -> torch.Tensor:
         t = torch.empty(self.field_shape(name), dtype=_TORCH_DTYPES[FIELD_DTYPES[name]], device=self.device)

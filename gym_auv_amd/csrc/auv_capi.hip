@@ -42,6 +42,12 @@ void auv_launch_rdv_publish(unsigned long long* word, unsigned long long seq, hi
 void auv_launch_rdv_arrive(unsigned long long* word, hipStream_t st);
 void auv_launch_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, double limit_s, hipStream_t st);
 hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st);
+size_t auv_policy_param_floats_impl(int obs_dim);
+size_t auv_policy_lds_bytes(int obs_dim);
+hipError_t auv_policy_prepare(int obs_dim);
+void auv_launch_policy(const auv_policy_io_t& io, int e0, int ne, hipStream_t st);
+void auv_launch_gae(const float* R, const float* V, const float* Dn, const float* last_v, float gamma, float lam, float* adv, float* ret,
+                    int T, int N, hipStream_t st);
 void auv_launch_k4(const AuvDev& d, const int32_t* sector_start, int n_sectors, double width, double* out_dist,
                    float* out_closeness, hipStream_t st);
 
@@ -77,6 +83,8 @@ struct auv_handle {
   bool handover_ok;
   int probe_failures;            // of the last probe (0 = the dispatch order is what the hand-overs rely on)
   int handover_timeouts;         // polls that ran out over the life of the handle (each one disables the hand-overs)
+  int last_timeout_e0, last_timeout_ne, last_reset_envs;   // the launch that reported the last time-out; environments its recovery reset
+  float* last_obs;               // the caller's observation buffer of the last step call (a recovery writes the reset rows there)
   hipEvent_t ev[6];
   std::vector<hipEvent_t> slice_ev;   // auv_step_pipelined_timed: start / stop event per sub-batch launch
   // auv_step_async / auv_step_wait: the chains of the pending step that do NOT run on the caller's stream, and how
@@ -248,6 +256,8 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.ep_log, 8 * (size_t)d.ep_log_cap);
   rc |= dev_alloc(ep, &d.ep_log_count, 1);
   rc |= dev_alloc(ep, &d.pair_word, n);
+  rc |= dev_alloc(ep, &d.abort_flag, 4);
+  rc |= dev_alloc(ep, &d.broken, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
   rc |= dev_alloc(ep, &d.nav_hand, 8 * n);
   rc |= dev_alloc(ep, &d.k1_done, AUV_MAX_CHAINS);      // (one per captured chain)
@@ -287,11 +297,13 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     std::vector<unsigned long long> empty(n ? n : 1, AUV_PAIR_EMPTY);
     HIP_TRY(hipMemcpy(d.pair_word, empty.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
     if (!h->pair_error_host) {
-      HIP_TRY(hipHostMalloc((void**)&h->pair_error_host, sizeof(int32_t), hipHostMallocMapped));
-      *h->pair_error_host = 0;
+      HIP_TRY(hipHostMalloc((void**)&h->pair_error_host, 4 * sizeof(int32_t), hipHostMallocMapped));
+      memset(h->pair_error_host, 0, 4 * sizeof(int32_t));
       HIP_TRY(hipHostGetDevicePointer((void**)&d.pair_error, h->pair_error_host, 0));
     }
     *h->pair_error_host = 0;   // (a new bank starts with a clean slate; see PAIR_CHECK)
+    HIP_TRY(hipMemset(d.abort_flag, 0, sizeof(int32_t)));
+    HIP_TRY(hipMemset(d.broken, 0, n));
     HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
@@ -346,16 +358,31 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
 // One launch with the step's structure and LDS footprint and several times more one-wave workgroups than the chip has
 // slots (k_step_fused.hip: k_probe_order): do consumers always find their lower-indexed producers?  Sets
 // handover_ok; a failure is not an error -- the handle then simply steps in the three-launch shape.
-static int probe_dispatch_order(auv_handle* h) {
+static int probe_streams(auv_handle* h, int n_streams, hipStream_t const* streams, bool foreign) {
   const int np = 512, nc = 8192;
+  const size_t per = (size_t)(np + 2 * nc + 1);
+  if (n_streams < 1) return fail(AUV_EINVAL, "dispatch-order probe: no stream");
   unsigned int* words = nullptr;
-  HIP_TRY(hipMalloc((void**)&words, (size_t)(np + 2 * nc + 1) * sizeof(unsigned int)));
-  HIP_TRY(hipMemset(words, 0, (size_t)(np + 2 * nc + 1) * sizeof(unsigned int)));
-  unsigned int* failures = words + np + 2 * nc;
-  unsigned int nf = 0;
-  hipError_t e = auv_launch_probe(words, np, nc, 0xA5A5u, failures, auv_step_lds_bytes(h->d), nullptr);
+  HIP_TRY(hipMalloc((void**)&words, (size_t)n_streams * per * sizeof(unsigned int)));
+  HIP_TRY(hipMemset(words, 0, (size_t)n_streams * per * sizeof(unsigned int)));
+  HIP_TRY(hipDeviceSynchronize());
+  hipError_t e = hipSuccess;
+  // what production runs: one probe launch per chain stream, all in flight together, with a foreign kernel on each
+  // stream in between (a policy's kernels sit between a chain's steps) -- twice, so that the second round's launches
+  // queue behind live ones
+  for (int round = 0; round < 2 && e == hipSuccess; round++)
+    for (int i = 0; i < n_streams && e == hipSuccess; i++) {
+      unsigned int* w = words + (size_t)i * per;
+      e = auv_launch_probe(w, np, nc, 0xA5A5u + (unsigned)round, w + np + 2 * nc, auv_step_lds_bytes(h->d), streams[i]);
+      if (foreign && e == hipSuccess) auv_launch_spin(300, streams[i]);          // 3 us of somebody else's kernel
+    }
   if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = hipMemcpy(&nf, failures, sizeof(nf), hipMemcpyDeviceToHost);
+  unsigned int nf = 0;
+  for (int i = 0; i < n_streams && e == hipSuccess; i++) {
+    unsigned int f = 0;
+    e = hipMemcpy(&f, words + (size_t)i * per + np + 2 * nc, sizeof(f), hipMemcpyDeviceToHost);
+    nf += f;
+  }
   (void)hipFree(words);
   if (e != hipSuccess) return fail(AUV_EHIP, "dispatch-order probe: %s", hipGetErrorString(e));
   h->probe_failures = (int)nf;
@@ -363,35 +390,60 @@ static int probe_dispatch_order(auv_handle* h) {
   return AUV_OK;
 }
 
+static int probe_dispatch_order(auv_handle* h) {
+  hipStream_t null_stream = nullptr;
+  return probe_streams(h, 1, &null_stream, false);
+}
+
 static int recover_from_timeout(auv_handle* h) {
   AuvDev& d = h->d;
   const int code = *(volatile int32_t*)h->pair_error_host;
+  const int fe0 = ((volatile int32_t*)h->pair_error_host)[1], fne = ((volatile int32_t*)h->pair_error_host)[2];
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
-  h->handover_timeouts += 1;
-  h->handover_ok = false;
   drop_graphs(h);
   const size_t n = (size_t)d.n;
+  h->async_pending = 0;
+  if (h->rdv) HIP_TRY(hipMemset(h->rdv, 0, AUV_RDV_BYTES));
+  h->rdv_seq = h->rdv_target = 0;
+  if (code == 4 || code == 5) {
+    // a rendezvous kernel of auv_step_async / auv_step_wait gave up: the ordering between the caller's stream and the
+    // chains was lost for that step (a chain may have read actions that were not ready), no environment is left
+    // half-stepped and the in-launch hand-overs have nothing to do with it
+    memset(h->pair_error_host, 0, 4 * sizeof(int32_t));
+    return fail(AUV_ESTATE, "step_async / step_wait rendezvous timed out (%s): the step's ordering against the caller's stream "
+                            "was lost; environments keep their state -- reported once, carry on",
+                code == 4 ? "a chain waited in vain for the caller's stream to publish the actions"
+                          : "the caller's stream waited in vain for the chains to arrive");
+  }
+  h->handover_timeouts += 1;
+  h->handover_ok = false;
+  // which environments did the waves that gave up leave unfinished?  Exactly those are reset; every other environment is
+  // consistent: it completed the steps of the launches that ran, and launches queued behind the time-out did nothing
+  // (ABORT packets, k_step_roles)
+  std::vector<uint8_t> broken(n ? n : 1, 0);
+  HIP_TRY(hipMemcpy(broken.data(), d.broken, n, hipMemcpyDeviceToHost));
+  int n_broken = 0;
+  for (size_t e = 0; e < n; e++) n_broken += broken[e] != 0;
   std::vector<unsigned long long> empty(n ? n : 1, AUV_PAIR_EMPTY);
   HIP_TRY(hipMemcpy(d.pair_word, empty.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
-  if (h->rdv) HIP_TRY(hipMemset(h->rdv, 0, AUV_RDV_BYTES));
-  h->rdv_seq = h->rdv_target = 0;
-  h->async_pending = 0;
-  auv_launch_reset(d, nullptr, nullptr, nullptr, nullptr);
+  if (n_broken) auv_launch_reset(d, d.broken, nullptr, h->last_obs, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
-  *h->pair_error_host = 0;
-  return fail(AUV_ESTATE, "in-launch hand-over timed out (%s): steps since then were incomplete, so EVERY environment has been put "
-                          "back into its reset state; the handle steps in the three-launch shape from now on (no in-launch "
-                          "hand-over) and this error is reported once -- carry on with reset observations",
+  HIP_TRY(hipMemset(d.broken, 0, n));
+  HIP_TRY(hipMemset(d.abort_flag, 0, sizeof(int32_t)));
+  memset(h->pair_error_host, 0, 4 * sizeof(int32_t));
+  h->last_timeout_e0 = fe0, h->last_timeout_ne = fne, h->last_reset_envs = n_broken;
+  return fail(AUV_ESTATE, "in-launch hand-over timed out (%s) in the launch over environments [%d, %d): the %d environment(s) whose step "
+                          "was left unfinished are back in their reset state (reset observation written to the caller's buffer); all "
+                          "others keep their state, but steps enqueued behind the time-out were not executed.  The handle steps in "
+                          "the three-launch shape from now on (no in-launch hand-over); this error is reported once",
               code == 2 ? "a sweep or search wave waited in vain for the dynamics role's state"
-                        : (code == 3 ? "a finish wave waited in vain for a state packet or a search record"
-                        : (code == 4 ? "a chain waited in vain for the caller's stream to publish the actions (auv_step_async)"
-                        : (code == 5 ? "the caller's stream waited in vain for the chains to arrive (auv_step_wait)"
-                                     : "a finish wave waited in vain for a sweep's word"))));
+                        : (code == 3 ? "a finish wave waited in vain for a state packet or a search record" : "a finish wave waited in vain for a sweep's word"),
+              fe0, fe0 + fne, n_broken);
 }
 
 extern "C" {
@@ -424,6 +476,8 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->handover_ok = false;
   h->probe_failures = -1;
   h->handover_timeouts = 0;
+  h->last_timeout_e0 = h->last_timeout_ne = -1, h->last_reset_envs = 0;
+  h->last_obs = nullptr;
   for (auto& e : h->ev) e = nullptr;
   h->async_pending = 0;
   h->ev_actions = nullptr;
@@ -739,6 +793,7 @@ static int enqueue_step(auv_handle_t* h, int mode, int e0, int ne, const void* a
   if (!capturing) d.ring_slots = 1;
   d.e0 = e0, d.ne = ne;
   d.ring_pos += chain, d.k1_done += chain;
+  h->last_obs = obs;
   if (mode == AUV_STEP_ONE_LAUNCH) {
     // dynamics, LiDAR sweep, navigation search and finish as four roles of ONE launch (csrc/k_step_fused.hip: k_step_roles;
     // inside a captured graph its dynamics role advances the action ring)
@@ -1069,13 +1124,24 @@ int auv_streams_overlap(auv_handle_t* h, void* stream_a, void* stream_b, float* 
   return AUV_OK;
 }
 
-int auv_health(auv_handle_t* h, int32_t* out4) {
-  if (!h || !out4) return fail(AUV_EINVAL, "auv_health: bad arguments");
-  out4[0] = h->handover_ok ? 1 : 0;
-  out4[1] = h->probe_failures;
-  out4[2] = h->handover_timeouts;
-  out4[3] = (h->pair_error_host && *(volatile int32_t*)h->pair_error_host) ? 1 : 0;   // a time-out not yet recovered from
+int auv_health(auv_handle_t* h, int32_t* out8) {
+  if (!h || !out8) return fail(AUV_EINVAL, "auv_health: bad arguments");
+  out8[0] = h->handover_ok ? 1 : 0;
+  out8[1] = h->probe_failures;
+  out8[2] = h->handover_timeouts;
+  out8[3] = (h->pair_error_host && *(volatile int32_t*)h->pair_error_host) ? 1 : 0;   // a time-out not yet recovered from
+  out8[4] = h->last_timeout_e0, out8[5] = h->last_timeout_ne, out8[6] = h->last_reset_envs;
+  out8[7] = 0;
   return AUV_OK;
+}
+
+int auv_probe_streams(auv_handle_t* h, int32_t n_streams, void* const* streams) {
+  REQUIRE_READY(h);
+  if (n_streams < 1 || n_streams > AUV_MAX_CHAINS || !streams) return fail(AUV_EINVAL, "auv_probe_streams: 1 .. %d streams", AUV_MAX_CHAINS);
+  HIP_TRY(hipSetDevice(h->device));
+  std::vector<hipStream_t> st(n_streams);
+  for (int i = 0; i < n_streams; i++) st[i] = (hipStream_t)streams[i];
+  return probe_streams(h, n_streams, st.data(), true);
 }
 
 int auv_effective_step_mode(auv_handle_t* h, int32_t n_envs_per_launch) {
@@ -1170,6 +1236,7 @@ static void* field_ptr(const auv_handle_t* h, int32_t field, size_t* bytes) {
     case AUV_FIELD_COLLISION: *bytes = n; return d.collision;
     case AUV_FIELD_STAMPS: *bytes = 8 * 16 * n; return d.stamps;
     case AUV_FIELD_STEP_INFO: *bytes = 8 * 4 * n; return d.step_info;
+    case AUV_FIELD_BROKEN: *bytes = n; return d.broken;
   }
   *bytes = 0;
   return nullptr;
@@ -1207,6 +1274,73 @@ int auv_feasibility_pooling(auv_handle_t* h, const int32_t* sector_start_dev, in
   if (!sector_start_dev || n_sectors < 1 || n_sectors > h->d.cfg.n_sensors || !(width >= 0.0))
     return fail(AUV_EINVAL, "auv_feasibility_pooling: bad arguments");
   auv_launch_k4(h->d, sector_start_dev, n_sectors, width, out_dist_dev, out_closeness_dev, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+size_t auv_policy_param_floats(int32_t obs_dim) { return obs_dim > 0 ? auv_policy_param_floats_impl(obs_dim) : 0; }
+
+static int check_policy_io(const auv_handle_t* h, int32_t e0, int32_t ne, const auv_policy_io_t* io, const char* who) {
+  if (!io) return fail(AUV_EINVAL, "%s: null io", who);
+  const auv_config_t& c = h->d.cfg;
+  const int D = 6 + (c.use_lidar ? c.n_sensors * (c.obs_channels == 3 ? 3 : 1) : 0);
+  if (io->obs_dim != D) return fail(AUV_EINVAL, "%s: obs_dim %d, the handle's observation has %d columns", who, io->obs_dim, D);
+  if (e0 < 0 || ne < 1 || (int64_t)e0 + ne > h->d.n) return fail(AUV_EINVAL, "%s: slice [%d, %d) outside [0, %d)", who, e0, e0 + ne, h->d.n);
+  if (io->T < 1) return fail(AUV_EINVAL, "%s: T must be >= 1", who);
+  if (io->env_base < 0 || io->env_base > e0 || (int64_t)e0 + ne - io->env_base > io->ld)
+    return fail(AUV_EINVAL, "%s: slice [%d, %d) does not fit a rollout row of %d environments starting at environment %d", who, e0, e0 + ne, io->ld, io->env_base);
+  if (!io->obs || !io->params || !io->ctr || !io->reward_in || !io->done_in || !io->actions_out || !io->A || !io->LP || !io->V || !io->R || !io->Dn)
+    return fail(AUV_EINVAL, "%s: null buffer", who);
+  if (((uintptr_t)io->params & 15) || ((uintptr_t)io->actions_out & 7) || ((uintptr_t)io->ctr & 7))
+    return fail(AUV_EINVAL, "%s: params must be 16-byte, actions_out and ctr 8-byte aligned", who);
+  if (auv_policy_lds_bytes(io->obs_dim) > 160 * 1024) return fail(AUV_EINVAL, "%s: observation too wide for the policy kernel's LDS tile", who);
+  return AUV_OK;
+}
+
+int auv_policy_act(auv_handle_t* h, int32_t e0, int32_t ne, const auv_policy_io_t* io, void* stream) {
+  REQUIRE_READY(h);
+  int rc = check_policy_io(h, e0, ne, io, "auv_policy_act");
+  if (rc) return rc;
+  HIP_TRY(auv_policy_prepare(io->obs_dim));
+  auv_launch_policy(*io, e0, ne, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_gae(auv_handle_t* h, const float* R, const float* V, const float* Dn, const float* last_v, float gamma, float lam, float* adv_out,
+            float* ret_out, int32_t T, int32_t N, void* stream) {
+  if (!h) return fail(AUV_EINVAL, "null handle");
+  if (!R || !V || !Dn || !last_v || !adv_out || !ret_out || T < 1 || N < 1) return fail(AUV_EINVAL, "auv_gae: bad arguments");
+  HIP_TRY(hipSetDevice(h->device));
+  auv_launch_gae(R, V, Dn, last_v, gamma, lam, adv_out, ret_out, T, N, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_policy_rollout(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, const auv_policy_io_t* ios,
+                       float* obs_dev, float* reward_dev, uint8_t* done_dev, int32_t n_steps, int32_t flush) {
+  REQUIRE_READY(h);
+  int rc = check_slices(h, n_slices, bounds, streams, "auv_policy_rollout");
+  if (rc) return rc;
+  if (!ios || n_steps < 0) return fail(AUV_EINVAL, "auv_policy_rollout: bad arguments");
+  for (int i = 0; i < n_slices; i++) {
+    rc = check_policy_io(h, bounds[i], bounds[i + 1] - bounds[i], ios + i, "auv_policy_rollout");
+    if (rc) return rc;
+    rc = check_actions(ios[i].actions_out, AUV_F32, "auv_policy_rollout");
+    if (rc) return rc;
+  }
+  PAIR_CHECK(h);
+  HIP_TRY(auv_policy_prepare(ios[0].obs_dim));
+  for (int32_t k = 0; k < n_steps; k++)
+    for (int i = 0; i < n_slices && rc == AUV_OK; i++) {
+      const int ne = bounds[i + 1] - bounds[i];
+      auv_launch_policy(ios[i], bounds[i], ne, (hipStream_t)streams[i]);
+      rc = enqueue_step(h, effective_mode(h, ne), bounds[i], ne, ios[i].actions_out, AUV_F32, obs_dev, reward_dev, done_dev,
+                        (hipStream_t)streams[i], false);
+    }
+  if (rc) return rc;
+  if (flush)
+    for (int i = 0; i < n_slices; i++) auv_launch_policy(ios[i], bounds[i], bounds[i + 1] - bounds[i], (hipStream_t)streams[i]);
   HIP_TRY(hipGetLastError());
   return AUV_OK;
 }

@@ -82,7 +82,11 @@ struct AuvDev {
   int32_t ep_log_cap;  // a power of two
   double* step_info;   // [N][4] info of the last step (terminal values survive an auto-reset)
   unsigned long long* pair_word; // [N] one-launch step: what the LiDAR wave leaves for the finish wave (k_step_fused.hip)
-  int32_t* pair_error; // [1] one-launch step: set when a wave gave up polling for a hand-over (1 sweep's word, 2 state packet, 3 packet / search record)
+  int32_t* pair_error; // [4] mapped HOST memory: [0] set when a wave gave up polling for a hand-over (1 sweep's word, 2 state packet, 3 packet /
+                       //     search record; 4 / 5: a rendezvous kernel of auv_step_async / _wait), [1] / [2] e0 / ne of the launch that reported
+  int32_t* abort_flag; // [1] device: raised with pair_error; from then on the dynamics role of every launch hands out ABORT packets, i.e. launches
+                       //     queued behind a time-out do nothing (and leave every environment they cover consistent) until the host has recovered
+  uint8_t* broken;     // [N] environments whose step a wave that gave up has left unfinished: what the recovery resets
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   unsigned long long* nav_hand; // [N][8] one-launch step: the nearest path segment the navigation role's search hands to the finish role
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position

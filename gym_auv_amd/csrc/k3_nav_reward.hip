@@ -377,15 +377,29 @@ __device__ __forceinline__ NavSpec nav_bounds(const AuvDev& d, const int e, cons
       const int jj = jhl < P - 1 ? jhl : 0;
       sA = xy[jj], sB = xy[jj + 1], scum = d.poly_cum[ed.p0 + jj];   // kept if this chunk survives
     }
+#ifdef AUV_NAV_CIRCLE_SQRT
 #pragma unroll
     for (int i = 0; i < NAV_CPL; i++) {
       const double dx = qx - b[i].x, dy = qy - b[i].y;
       cdist[i] = sqrt(dx * dx + dy * dy);
       if (i * AUV_WAVE + lane < nch) U = fmin(U, cdist[i] + b[i].z);   // from the circles: min of |q - c| + rad
     }
-    // (round 3: these four distances in fp32 with widened comparisons -- they only prune -- were measured under the SQ
-    // counters: 325 -> 347 VALU instructions per wave for this phase; the conversions and margins cost what the fp64
-    // square roots do, so the fp64 form stays)
+#else
+    // Round 4: no square roots here.  The upper bound U is the exact distance to the hint chunk's segments alone (any
+    // distance to any segment of the path bounds the minimum from above; the circles' own bound |q - c| + rad was only ever
+    // the tighter one when the hint was off by whole chunks), and a chunk survives iff |q - c| <= U + rad, decided on the
+    // squares: (U + rad)^2 is formed with the radius that was inflated by 1e-9 (relative and absolute) at load time, six
+    // orders of magnitude more than the roundings of the two squares, so every chunk that can hold the minimum survives --
+    // the survivors' exact distances and the (distance, first index) minimum are what they were.  Four fp64 square roots per
+    // lane less (~100 of this phase's 325 instructions, profiles/r03/valu_budget_polygons50_four_roles.json), and the
+    // search record leaves earlier.  (Round 3 tried these distances in fp32 with widened comparisons: 325 -> 347
+    // instructions, the conversions and margins cost what the square roots did.)
+#pragma unroll
+    for (int i = 0; i < NAV_CPL; i++) {
+      const double dx = qx - b[i].x, dy = qy - b[i].y;
+      cdist[i] = dx * dx + dy * dy;                                    // |q - c|^2
+    }
+#endif
     {
       double dd = 1.7976931348623157e308;
       if (jhl < P - 1) dd = auv_pt_seg_dist(qx, qy, sA.x, sA.y, sB.x, sB.y);
@@ -395,7 +409,12 @@ __device__ __forceinline__ NavSpec nav_bounds(const AuvDev& d, const int e, cons
 #pragma unroll
     for (int i = 0; i < NAV_CPL; i++) {
       const int c = i * AUV_WAVE + lane;
+#ifdef AUV_NAV_CIRCLE_SQRT
       const bool act = (c < nch) && (cdist[i] - b[i].z <= U);
+#else
+      const double reach = U + b[i].z;
+      const bool act = (c < nch) && (cdist[i] <= reach * reach);
+#endif
       const unsigned long long mask = __ballot(act);
       if (act) list[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = c;
       n_act += __popcll(mask);

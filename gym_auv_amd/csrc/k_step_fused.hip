@@ -67,6 +67,19 @@ namespace {
 #define PAIR_EMPTY AUV_PAIR_EMPTY
 #define PAIR_COLLISION AUV_PAIR_COLLISION
 #define PAIR_POLL_LIMIT (1 << 22)
+#define ROLES_ABORT_COUNTER 0xffffffffu   // step-counter word of an ABORT packet (a real Vessel._step_counter never gets there)
+
+// A poll has run out.  The wave records which environments it leaves unfinished (`broken`: the caller does, per
+// environment), raises the device-wide abort flag -- launches queued behind this one then do nothing instead of consuming
+// half-finished hand-overs -- and tells the host (mapped memory: code, and the slice of the launch that reports).
+__device__ __forceinline__ void roles_give_up(const AuvDev& d, const int e0, const int ne, const int code, const int lane) {
+  if (lane == 0) {
+    __hip_atomic_store(d.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d.pair_error + 1, e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(d.pair_error + 2, ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(d.pair_error, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 
 __device__ __forceinline__ void pair_publish_lidar(const AuvDev& d, const int e, const int lane, const int collision,
                                                    const double term) {
@@ -187,8 +200,9 @@ __device__ __forceinline__ unsigned long long roles_lane_word(const unsigned lon
          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
 }
 
-// the state the dynamics role left for environment e in this launch; false: gave up polling
-__device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, const int lane, EnvPre& pre) {
+// the state the dynamics role left for environment e in this launch.  0: here it is; 1: gave up polling (reported, the
+// environment marked broken); 2: an ABORT packet -- a launch behind a time-out: the wave ends without touching anything
+__device__ __forceinline__ int roles_wait_state(const AuvDev& d, const int e, const int lane, EnvPre& pre) {
   const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
   // (polling harder does not pay: with two requests in flight per wave the packet is noticed sooner, but the
   // traffic of 3500 polling waves slows the dynamics role down by more -- 102.3 M against 104.7 M env-steps/s;
@@ -204,15 +218,16 @@ __device__ __forceinline__ bool roles_wait_state(const AuvDev& d, const int e, c
       if (roles_mark(x) == got) break;                       // mark and payload belong together
     }
     if (polls == (AUV_HOOK_FAULT(d) ? (1 << 12) : PAIR_POLL_LIMIT)) {
-      if (lane == 0) __hip_atomic_store(d.pair_error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return false;
+      if (lane == 0) auv_st<true>(d.broken + e, (uint8_t)1);
+      roles_give_up(d, d.e0, d.ne, 2, lane);
+      return 1;
     }
     __builtin_amdgcn_s_sleep(8);
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) pre.s[i] = pair_lane_value(v, i);
   pre.cnt.y = (int)__builtin_amdgcn_readlane((int)(unsigned)v, 6);   // the vessel's step counter of this launch
-  return true;
+  return (unsigned)pre.cnt.y == ROLES_ABORT_COUNTER ? 2 : 0;
 }
 
 // ---- the finish role: navigation tail + reward / done / auto-reset, eight environments per wave ----
@@ -314,18 +329,28 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
 #endif
   // ---- the state packet and the search record of every group ----
   unsigned long long vp = 0ull, vh = 0ull;
-  bool okp = !live, okh = !live;
+  bool okp = !live, okh = !live, aborted = false;
+  uint8_t* const broken = dc->broken;
   for (int polls = 0;; polls++) {
     if (!okp) vp = __hip_atomic_load(pk + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // one 64-byte request per group
     if (!okh) vh = __hip_atomic_load(hd + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     okp = !live || roles_record_ok(vp, c);
-    okh = !live || roles_record_ok(vh, c);
+    // an ABORT packet (a launch behind a time-out): no search record, no sweep's word will follow
+    aborted = live && okp && (unsigned)roles_group_word(vp, 6) == ROLES_ABORT_COUNTER;
+    okh = !live || aborted || roles_record_ok(vh, c);
     if (!__any(!(okp && okh))) break;
     if (polls == limit) {
-      if (lane == 0) __hip_atomic_store(d.pair_error, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (live && c == 0) auv_st<true>(broken + e, (uint8_t)1);
+      roles_give_up(d, e0, ne, 3, lane);
       return;
     }
     __builtin_amdgcn_s_sleep(8);
+  }
+  if (__any(aborted)) {
+    // the eight environments of a finish wave are the eight of ONE dynamics wave: all of them or none.  The ABORT packets
+    // stay up -- this wave does not know whether the environments' sweep and search waves have seen them yet; later
+    // launches are aborted too (they overwrite them with their own) and the host's recovery clears every mark
+    return;
   }
   t.px = roles_group_value(vp, 0), t.py = roles_group_value(vp, 1), t.psi = roles_group_value(vp, 2);
   t.u = roles_group_value(vp, 3), t.v = roles_group_value(vp, 4), t.r = roles_group_value(vp, 5);
@@ -350,7 +375,8 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
     if (word == PAIR_EMPTY) word = __hip_atomic_load(pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!__any(word == PAIR_EMPTY)) break;
     if (polls == limit) {
-      if (lane == 0) __hip_atomic_store(d.pair_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (live && c == 0) auv_st<true>(broken + e, (uint8_t)1);
+      roles_give_up(d, e0, ne, 1, lane);
       return;
     }
     __builtin_amdgcn_s_sleep(8);
@@ -417,9 +443,15 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     const bool live = er < ne;
     const int eg = d.e0 + (live ? er : ne - 1);                     // idle groups compute along, store nothing
     const int y = d.counters[eg].y + 1;                             // Vessel._step_counter (vessel.py:247); requested up front
-    const double t = k1_group(d, actions, eg, lane);
+    // a launch queued behind a hand-over time-out (the flag is wave-uniform, a scalar load): the dynamics role hands out
+    // ABORT packets instead of states, on which every other wave of the launch ends without touching its environment --
+    // the whole decision hangs on THIS wave's one look at the flag, so an environment's four waves always agree
+    const int aborted = auv_uniform(*d.abort_flag);
+    double t = 0.0;
+    if (!aborted) t = k1_group(d, actions, eg, lane);
     unsigned long long* pk = d.k1_pkt + 8 * (size_t)eg;
-    const unsigned long long word = c < 6 ? (unsigned long long)__double_as_longlong(t) : (c == 6 ? (unsigned long long)(unsigned)y : 0ull);
+    const unsigned long long word = aborted ? (c == 6 ? (unsigned long long)ROLES_ABORT_COUNTER : 0ull)
+                                            : (c < 6 ? (unsigned long long)__double_as_longlong(t) : (c == 6 ? (unsigned long long)(unsigned)y : 0ull));
     const unsigned long long mark = roles_mark(roles_group_xor(word));
     // The packet is ALL this role stores: payload and mark in ONE store instruction, 64 contiguous bytes per group, and
     // the wave does not wait for it.  The mark is a checksum of the payload, so a reader that sees the mark before all
@@ -466,6 +498,9 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 3] = wall_clock64();
 #endif
+    // (a launch queued behind a hand-over time-out: nothing is touched.  The dynamics wave's look at the flag is the one
+    // that counts -- see there -- this one only keeps the movers from being advanced by a launch that will be aborted)
+    if (auv_uniform(*d.abort_flag)) return;
     ed = d.env_desc[e];
     pre.cnt = d.counters[e];                               // t_step, episodes; the step counter comes with the state
     pre.ed = &ed;
@@ -478,7 +513,15 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 1] = wall_clock64();
 #endif
-    if (!roles_wait_state(d, e, lane, pre)) return;
+    {
+      const int ws = roles_wait_state(d, e, lane, pre);
+      if (ws) {
+        // an ABORT packet although this wave saw the flag down a moment ago: the flag went up in between, and the movers of
+        // this environment have been advanced for a step that will not happen -- the recovery resets it
+        if (ws == 2 && ed.M > 0 && lane == 0) auv_st<true>(d.broken + e, (uint8_t)1);
+        return;
+      }
+    }
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 2] = wall_clock64();
 #endif
@@ -511,7 +554,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 12] = wall_clock64();
 #endif
-    if (!roles_wait_state(d, e, lane, pre)) return;
+    if (roles_wait_state(d, e, lane, pre)) return;
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 5] = wall_clock64();
 #endif

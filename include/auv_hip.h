@@ -136,6 +136,8 @@ enum {
   AUV_FIELD_COLLISION = 12,  /* [N] uint8  Vessel._collision                                */
   AUV_FIELD_STAMPS = 13,     /* [N][16] uint64 per-phase cycle counts; zeros unless the library
                                  was built with STAMPS=1 (diagnostic)                       */
+  AUV_FIELD_BROKEN = 15,     /* [N] uint8  environments whose step a wave that gave up polling has left unfinished
+                                 (all zero except between a hand-over time-out and the call that recovers)     */
   AUV_FIELD_STEP_INFO = 14   /* [N][4] the `info` dict of the last step() as the reference
                                  returns it (environment.py:336-340): collision, reached_goal,
                                  goal_distance, progress -- of the step that was taken, i.e. the
@@ -302,8 +304,10 @@ int auv_set_action_ring(auv_handle_t* h, int32_t n_slots);
  * therefore runs a probe launch of the same structure (more one-wave workgroups than the chip has slots, three
  * generations polling each other); if any of its polls runs out, and whenever the LiDAR is off, the handle steps in
  * AUV_STEP_SIDE_BY_SIDE whatever mode is set.  Should a poll of a real step ever run out (bounded: seconds), the
- * NEXT call on the handle returns AUV_ESTATE once, having cleared the hand-over words, put EVERY environment back
- * into its reset state and switched the handle to AUV_STEP_SIDE_BY_SIDE for good; later calls succeed.  A step
+ * wave marks the environments it leaves unfinished and raises a device-wide flag on which the launches queued behind
+ * it do nothing (their dynamics role hands out ABORT packets); the NEXT call on the handle returns AUV_ESTATE once,
+ * having reset exactly the marked environments (auv_health tells which launch reported and how many), cleared the
+ * hand-over words and switched the handle to AUV_STEP_SIDE_BY_SIDE for good; later calls succeed.  A step
  * replayed from a captured graph (hipGraphLaunch, or a torch CUDAGraph around auv_step) is not checked per replay:
  * poll auv_health() once per rollout there.
  * (Removed in round 3, measured slower: the whole step as one kernel, [K1 + K3-nav] -> [K2 + K3-reward], K3-nav
@@ -312,10 +316,16 @@ enum { AUV_STEP_SIDE_BY_SIDE = 0, AUV_STEP_ONE_LAUNCH = 5, AUV_STEP_AUTO = 6 };
 int auv_set_step_mode(auv_handle_t* h, int32_t mode);
 /* The shape a launch of n_envs_per_launch environments (<= 0: the whole batch) is really stepped in: AUV_STEP_*. */
 int auv_effective_step_mode(auv_handle_t* h, int32_t n_envs_per_launch);
-/* out4: [0] 1 = in-launch hand-overs in use, [1] polls of the load-time probe that ran out (-1: no bank yet),
+/* out8: [0] 1 = in-launch hand-overs in use, [1] polls of the last dispatch-order probe that ran out (-1: no bank yet),
  *       [2] hand-over time-outs over the life of the handle, [3] 1 = a time-out is pending (the next step call
- *       will recover and return AUV_ESTATE).  Reads host memory only: no synchronisation.                       */
-int auv_health(auv_handle_t* h, int32_t* out4);
+ *       will recover and return AUV_ESTATE), [4] / [5] e0 / ne of the launch that reported the last time-out (-1: none),
+ *       [6] environments the last recovery reset, [7] 0.  Reads host memory only: no synchronisation.              */
+int auv_health(auv_handle_t* h, int32_t* out8);
+/* The dispatch-order probe on the streams production uses: one probe launch per stream, all in flight together, a foreign
+ * kernel behind each, two rounds (BatchedAuvEnv.set_sub_batches runs it on the chain streams it has chosen).  Updates
+ * what auv_health reports in [0] / [1]; a probe that fails is not an error -- the handle then steps in the
+ * three-launch shape.  Synchronises the device.                                                                   */
+int auv_probe_streams(auv_handle_t* h, int32_t n_streams, void* const* streams);
 
 /* One step with every dispatch stamped with its own start / stop HIP event on `stream` (the kernel's
  * own duration, as a kernel trace reports it).  out_ms[0..3] by effective mode:
@@ -378,6 +388,60 @@ enum {
 };
 size_t auv_bank_bytes(const auv_handle_t* h, int32_t table);
 int auv_read_bank(auv_handle_t* h, int32_t table, void* dst_dev, size_t bytes, void* stream);
+
+/* ---- the policy in the loop (scripts/run.py:332-357: PPO2 with MlpPolicy, net_arch [256, 128, 64] for
+ * policy and value function, tanh, diagonal Gaussian over the two actions) --------------------------------------------
+ * auv_policy_act evaluates actor and critic for the environments [e0, e0 + ne) with ONE launch on `stream`, straight from
+ * the observation rows the step has written: obs -> [256, 128, 64] tanh -> (mu[2] | value), f32 on the matrix cores
+ * (v_mfma_f32_16x16x4_f32: exact f32), then in the epilogue a = mu + exp(log_std) eps (counter-based generator keyed by
+ * seed, step counter, environment), log pi(a), the action mapped into the action space and written into the
+ * environment's action buffer, and the transition stored at position t of the rollout:
+ *   O[t] = obs, A[t] = a, LP[t] = log pi(a), V[t] = value, and -- of the step the environment completed BEFORE this
+ *   call -- R[t - 1] = reward_scale * clip(reward), Dn[t - 1] = done.  A rollout row holds `ld` environments; environment e
+ *   sits in column e - env_base of it (one [T][N] buffer shared by all sub-batches: ld = N, env_base = 0).
+ * t lives on the device (ctr[0]; the host zeroes it before a rollout), is advanced by the launch itself, and a call
+ * with t == T only stores R[T - 1] / Dn[T - 1] (the flush behind a rollout's last step); so the call can sit in a
+ * captured graph.  params: auv_policy_param_floats(obs_dim) floats, 16-byte aligned -- the policy net then the value
+ * net, each W1 [256][K0p] b1 [256] W2 [128][256] b2 [128] W3 [64][128] b3 [64] W4 [16][64] b4 [16], then log_std[2]
+ * and two floats of padding.  A weight matrix is torch's Linear.weight [out][in], columns padded with zeros to a multiple
+ * of 32 (K0p = obs_dim rounded up), the last layer's rows to 16, and stored in MFMA fragment order: element [n][k] at
+ *   ((((n / 16) * (K / 32) + k / 32) * 2 + (k % 8) / 4) * 64 + ((k % 32) / 8) * 16 + n % 16) * 4 + k % 4
+ * (gym_auv_amd/policy.py: FusedActorCritic.refresh does it with one permuted copy per layer).  All pointers are device
+ * pointers.                                                                                                        */
+typedef struct auv_policy_io {
+  const float* obs;          /* [N][obs_dim]  the environment's observation buffer                          */
+  const float* params;       /* packed weights (above)                                                       */
+  int64_t* ctr;              /* [4] device: t, generator step counter (monotonic), scratch, -                */
+  const float* reward_in;    /* [N]  the environment's reward buffer                                         */
+  const uint8_t* done_in;    /* [N]  the environment's done buffer                                           */
+  float* actions_out;        /* [N][2] the action buffer auv_step* reads (AUV_F32)                           */
+  float* O;                  /* [T][ld][obs_dim] (nullable)                                                  */
+  float* A;                  /* [T][ld][2]                                                                   */
+  float* LP;                 /* [T][ld]                                                                      */
+  float* V;                  /* [T][ld]                                                                      */
+  float* R;                  /* [T][ld]                                                                      */
+  float* Dn;                 /* [T][ld]                                                                      */
+  float* mu_out;             /* [ne][2] (nullable: tests)                                                    */
+  float* eps_out;            /* [ne][2] (nullable: tests)                                                    */
+  uint64_t seed;
+  int32_t obs_dim, T;
+  int32_t ld, env_base;      /* environments per rollout row; the environment in column 0                   */
+  float act_mid[2], act_half[2], clip_lo[2], clip_hi[2];   /* action = mid + half * clip(a, lo, hi)          */
+  float reward_scale, reward_clip;                         /* reward_clip <= 0: no clipping                  */
+} auv_policy_io_t;
+size_t auv_policy_param_floats(int32_t obs_dim);
+int auv_policy_act(auv_handle_t* h, int32_t e0, int32_t ne, const auv_policy_io_t* io, void* stream);
+/* n_steps transitions of every slice with ONE call: per step and slice the policy launch and the environment's step of
+ * that slice (actions = ios[i].actions_out), back to back on streams[i]; `flush` != 0: a final policy call per slice
+ * stores the last step's reward / done.  The chains are not ordered against each other or the caller's stream. */
+int auv_policy_rollout(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams,
+                       const auv_policy_io_t* ios, float* obs_dev, float* reward_dev, uint8_t* done_dev, int32_t n_steps,
+                       int32_t flush);
+
+/* Generalised advantage estimation over a rollout of T steps x N environments (row-major [T][N] device buffers; V and
+ * last_v in the same units as R): adv and ret = adv + V, one launch on `stream`.                                       */
+int auv_gae(auv_handle_t* h, const float* R, const float* V, const float* Dn, const float* last_v, float gamma, float lam,
+            float* adv_out, float* ret_out, int32_t T, int32_t N, void* stream);
 
 int32_t auv_abi_version(void);
 const char* auv_last_error(void);

@@ -70,36 +70,62 @@ def main():
         print(json.dumps(dict(case="skew", mode=mode, bitwise=bool(ok), n_done=n_done, n=n, effective=par.effective_step_mode())), flush=True)
         ref.close(), par.close()
 
-    # ---- a poll that runs out: the launch ENDS, the next call reports it once, every environment is back in its
-    # reset state, the handle goes on in the three-launch shape -- bit for bit what a fresh handle does from reset
+    # ---- a poll that runs out: the launch ENDS, launches queued behind it do nothing (ABORT packets), the next call
+    # reports once and resets exactly the environments whose step was left unfinished; every other environment keeps the
+    # state of the one step it completed; the handle goes on in the three-launch shape -- bit for bit what a fresh handle
+    # does that steps once, resets the same environments and carries on.  Two sub-batches of 128: the hook hits the first
+    # environment of EVERY launch, so both chains report.
     for mode, fault in (("one_launch", 1), ("one_launch", 2), ("one_launch", 3)):   # sweep's word / state packet / search record withheld
-        n = 64
+        n = 256
         cfg = effective_reference_config(use_lidar=True)
         env = env_(cfg, n, mode, fault=fault)
+        slices = env.set_sub_batches(2, strict=True)   # (streams measured to run side by side: a chain queued BEHIND the other's faulty
+                                                       # launch on one hardware queue would be aborted before its first step)
         a = torch.zeros((n, 2), dtype=torch.float32, device="cuda:0")
+        a[:, 0] = 0.7
         h0 = env.health()
-        env.step(a)                                  # the faulty launch itself is enqueued normally ...
-        torch.cuda.synchronize()                     # ... and ENDS (no hang)
+        for _ in range(3):
+            env.step_pipelined(a)                    # the faulty launches and two more behind each of them ...
+        torch.cuda.synchronize()                     # ... all END (no hang)
         h1 = env.health()
+        marked = torch.nonzero(env.read("BROKEN")).flatten().tolist()   # (before the recovery clears the marks)
         msg = ""
         try:
             env.step(a)
         except RuntimeError as exc:
             msg = str(exc)
-        h2 = env.health()
+        h2, lt = env.health(), env.last_timeout()
+        # the eight environments of the finish wave that covers a launch's first environment: e0 + 8 g
+        broken = sorted(lo + 8 * g for lo, _ in slices for g in range(8))
+        mask = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+        mask[torch.as_tensor(broken, device="cuda:0")] = 1
+        t_step = env.read("COUNTERS")[:, 0]
+        steps_as_expected = bool((t_step[mask == 0] == 1).all()) and bool((t_step[mask == 1] == 0).all())
         ref = env_(cfg, n, "side_by_side")
-        same_reset = all(torch.equal(ref.read(f), env.read(f)) for f in FIELDS if f not in ("EPISODE", "COUNTERS", "STEP_INFO", "REWARD64"))
+        ref.step(a)
+        ref.reset(mask=mask)
+        same_state = all(torch.equal(ref.read(f), env.read(f)) for f in FIELDS if f not in ("EPISODE", "STEP_INFO", "REWARD64"))
+        obs_rows_reset = torch.equal(ref.obs[mask == 1], env.obs[mask == 1])     # the recovery wrote the reset observation rows
         ok = True
         for _ in range(5):
             o0, r0, d0, _ = ref.step(a)
             o1, r1, d1, _ = env.step(a)              # (fault hook still on: the three-launch shape has no hand-over to fail)
             torch.cuda.synchronize()
             ok = ok and torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1)
-        ok = ok and all(torch.equal(ref.read(f), env.read(f)) for f in ("STATE", "LIDAR_D", "OBS64", "NAV64", "MOVER_STATE", "NEARBY", "CULL_LIMITS"))
-        print(json.dumps(dict(case="fault", mode=mode, fault=fault, before=h0, after_launch=h1, after_recovery=h2, message=msg,
-                              reset_state_equal=bool(same_reset), continues_bitwise=bool(ok),
+        ok = ok and all(torch.equal(ref.read(f), env.read(f)) for f in ("STATE", "LIDAR_D", "OBS64", "NAV64", "MOVER_STATE", "NEARBY", "CULL_LIMITS", "COUNTERS"))
+        print(json.dumps(dict(case="fault", mode=mode, fault=fault, before=h0, after_launch=h1, after_recovery=h2, last_timeout=lt, message=msg,
+                              n_broken_expected=len(broken), marked=marked, t_step=t_step.tolist(), steps_as_expected=steps_as_expected, state_equal=bool(same_state),
+                              obs_rows_reset=bool(obs_rows_reset), continues_bitwise=bool(ok),
                               effective=env.effective_step_mode())), flush=True)
         ref.close(), env.close()
+
+    # ---- the dispatch-order probe in the shape production runs: four launches in flight on four streams, a foreign kernel
+    # behind each (set_sub_batches runs it); and a rendezvous kernel of step_async that gives up (nobody publishes)
+    cfg = effective_reference_config(use_lidar=True)
+    env = env_(cfg, 1024, "one_launch")
+    env.set_sub_batches(4)
+    print(json.dumps(dict(case="probe", sub_batches=env.sub_batches, health=env.health(), effective=env.effective_step_mode(256))), flush=True)
+    env.close()
 
 
 if __name__ == "__main__":

@@ -49,14 +49,17 @@ def test_struct_sizes_match_header(tmp_path):
     """sizeof() from the real header (compiled with gcc) == the ctypes mirrors."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu\\n", '
-                   'sizeof(auv_config_t), sizeof(auv_world_bank_t));return 0;}\n'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu\\n", '
+                   'sizeof(auv_config_t), sizeof(auv_world_bank_t), sizeof(auv_policy_io_t), offsetof(auv_policy_io_t, seed), '
+                   'offsetof(auv_policy_io_t, reward_scale));return 0;}\n'
                    % os.path.join(ROOT, "include", "auv_hip.h"))
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", str(src), "-o", str(exe)])
-    a, b = map(int, subprocess.check_output([str(exe)]).split())
+    a, b, c, o_seed, o_scale = map(int, subprocess.check_output([str(exe)]).split())
     assert C.sizeof(_capi.AuvConfig) == a == 9 * 8 + 10 * 4
     assert C.sizeof(_capi.AuvWorldBank) == b
+    assert C.sizeof(_capi.AuvPolicyIO) == c
+    assert _capi.AuvPolicyIO.seed.offset == o_seed and _capi.AuvPolicyIO.reward_scale.offset == o_scale
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -252,7 +252,7 @@ def test_bench_launch_shape_4x1024_polygons50(interleave):
     np.testing.assert_allclose(_np(four.read("STATE"))[:, sub], ora.read("STATE"), rtol=0, atol=1e-9)
     np.testing.assert_allclose(_np(four.read("LIDAR_D"))[sub], ora.read("LIDAR_D"), rtol=0, atol=1e-9)
     assert n_done >= 2 * N                                  # every environment turned over, most of them twice
-    assert four.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0)
+    assert four.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0)   # (incl. the four-stream probe of set_sub_batches)
     one.close(), four.close()
 
 

@@ -331,8 +331,9 @@ def test_hook_build_cases(hook_cases):
     """(a) hand-overs across XCDs: with three idle workgroups between the roles an environment's waves sit on
     different XCDs, so the packet, the word and the restore rows cross L2s -- still bit for bit the three-launch shape.
     (b) the waits inside the one-launch step are bounded: with one sweep withholding its word, the dynamics role one
-    state packet or one search its record, the waves that poll for it give up, the launch ENDS, the next call raises once ("timed out") having put every environment back into
-    its reset state, and the handle carries on in the three-launch shape, bit for bit what a fresh handle does."""
+    state packet or one search its record, the waves that poll for it give up, the launch ENDS, the launches queued behind it do nothing, the next call raises
+    once ("timed out") having reset exactly the environments whose step was left unfinished, and the handle carries on in the three-launch shape, bit for bit
+    what a fresh handle does that resets the same environments.  (c) the dispatch-order probe on four concurrent streams passes."""
     skew = [c for c in hook_cases if c["case"] == "skew"]
     fault = [c for c in hook_cases if c["case"] == "fault"]
     assert {c["mode"] for c in skew} == {"one_launch"} and {c["mode"] for c in fault} == {"one_launch"}
@@ -344,7 +345,16 @@ def test_hook_build_cases(hook_cases):
         assert c["after_launch"]["pending"] == 1, c
         assert "timed out" in c["message"] and "reset" in c["message"], c
         assert c["after_recovery"] == dict(handover_ok=0, probe_failures=0, timeouts=1, pending=0), c
-        assert c["reset_state_equal"] and c["continues_bitwise"] and c["effective"] == "side_by_side", c
+        # only the environments the waves that gave up left unfinished were reset: sixteen of 256 --
+        # the eight of the first finish wave of each of the two launches -- and the recovery names a launch that reported
+        assert c["last_timeout"]["reset_envs"] == c["n_broken_expected"] == 16 and c["last_timeout"]["ne"] == 128, c
+        assert c["last_timeout"]["e0"] in (0, 128), c
+        # ... everybody else completed exactly the one step of the launches that ran: the launches queued behind did nothing
+        assert c["steps_as_expected"] and c["state_equal"] and c["obs_rows_reset"], c
+        assert c["continues_bitwise"] and c["effective"] == "side_by_side", c
+    probe = [c for c in hook_cases if c["case"] == "probe"]
+    assert len(probe) == 1 and probe[0]["sub_batches"] == 4 and probe[0]["effective"] == "one_launch", probe
+    assert probe[0]["health"] == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0), probe
 
 
 def test_shipped_library_has_no_test_hooks(monkeypatch):

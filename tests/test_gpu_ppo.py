@@ -18,8 +18,9 @@ def test_ppo_colav_runs_as_chains_with_episode_metrics():
     """The Colav task with the rollout as four sub-batch chains (eager and as one captured graph per chain and step):
     finite, the same bookkeeping either way, and the per-update episode metrics come from the library's episode log."""
     import ppo
-    for graphs in (False, True):
-        hist = ppo.train(envs=1024, updates=5, rollout=16, log=lambda *_: None, sub_batches=4, graph_rollout=graphs)
+    # the fused policy launch (default), the torch modules eagerly, the torch modules as one captured graph per chain and step
+    for fused, graphs in ((True, False), (False, False), (False, True)):
+        hist = ppo.train(envs=1024, updates=5, rollout=16, log=lambda *_: None, sub_batches=4, graph_rollout=graphs, fused_policy=fused)
         assert len(hist) == 5
         assert all(math.isfinite(h["mean_step_reward"]) and math.isfinite(h["loss"]) for h in hist)
         assert all(h["rollout_sps"] > 0 and h["episodes"] >= 0 for h in hist)
@@ -27,7 +28,7 @@ def test_ppo_colav_runs_as_chains_with_episode_metrics():
 
 
 def test_ppo_learns_path_following():
-    """PathFollowNoObstacles-v0, eager rollouts and updates.  What the curve looks like (profiles/r03/ppo_pathfollow_*.log):
+    """PathFollowNoObstacles-v0, rollouts with the fused policy launch (gym_auv_amd/policy.py: the default), eager updates.  What the curve looks like (profiles/r03/ppo_pathfollow_*.log):
     the thruster is learnt within ten updates (step reward -1.1 -> -0.25), then the vessels -- started near the path with
     random headings -- run away from it at speed and the reward DIPS (-0.45 around updates 20-35) until the rudder is learnt
     (|heading error| 0.86 -> 0.35 rad) and it recovers.  Asserted: speed up, heading error down, reward above the
@@ -50,7 +51,7 @@ def test_ppo_rollout_as_captured_graphs_learns_and_moves_the_weights():
     path following as with eager rollouts, and its weights change with EVERY update (round 2's captured update step froze
     them silently after the first update and nothing noticed: that path is gone and this is asserted now)."""
     import ppo
-    hist = ppo.train(envs=2048, updates=40, rollout=32, task="pathfollow", log=lambda *_: None, graph_rollout=True)
+    hist = ppo.train(envs=2048, updates=40, rollout=32, task="pathfollow", log=lambda *_: None, graph_rollout=True, fused_policy=False)
     assert mean(hist[-5:], "surge") > mean(hist[:2], "surge") + 0.04, (mean(hist[:2], "surge"), mean(hist[-5:], "surge"))
     assert mean(hist[-5:], "mean_step_reward") > hist[0]["mean_step_reward"] + 0.3, (hist[0]["mean_step_reward"], mean(hist[-5:], "mean_step_reward"))
     w = [h["weight_l1"] for h in hist]
