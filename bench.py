@@ -340,7 +340,8 @@ def main():
         t_probe = env.stream_probe_s
     elif api == "async":
         env.set_sub_batches(1, inline_first=bool(args.inline_first))
-    env.rendezvous = args.rendezvous
+    if args.probe_streams or sub <= 1:
+        env.rendezvous = args.rendezvous        # (unprobed streams -- profiler runs -- keep the event-based ordering set_sub_batches chose)
     act = torch.ones((n_local, 2), dtype=torch.float32, device=dev)
 
     def pilot_all():
@@ -488,7 +489,7 @@ def main():
     # the timed region): the headline loop is open-loop chain throughput, a VecEnv consumer that waits for every step
     # sees the rendezvous figure
     comparison = None
-    if rank == 0 and world == 1 and args.actions == "uniform" and not K and args.steps >= 20:
+    if rank == 0 and world == 1 and args.actions == "uniform" and not K and args.steps >= 20 and args.probe_streams:
         n_cmp = 300
 
         def rate(fn):

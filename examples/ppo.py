@@ -265,11 +265,13 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             if fused is not None:
                 O, A, LP, V, R, Dn = fused.buffers()
                 V = V * ret_std + ret_mean
-                if graph_update == 3:
+                if graph_update >= 3:
                     # (the configuration that froze in profiles/r04/ppo_graph_update_colav_stacked_frozen.log: stack-based
-                    # norms inside the captured update AND concatenations of the chains' buffers outside it, every update)
-                    for x in (O, A, LP, R, Dn, fused.V):
-                        torch.cat([x[:, lo:lo + cnt] for lo, cnt in slices], 1)
+                    # norms inside the captured update, fresh concatenations of the chains' buffers as the update's inputs and
+                    # the advantage recursion as T x 6 small tensor operations outside it, every update; 4: the same around the
+                    # stack-free norms)
+                    O, A, LP, R, Dn = (torch.cat([x[:, lo:lo + cnt] for lo, cnt in slices], 1) for x in (O, A, LP, R, Dn))
+                    V = torch.cat([fused.V[:, lo:lo + cnt] for lo, cnt in slices], 1) * ret_std + ret_mean
             else:
                 O = torch.cat([b["O"] for b in buf], 1)
                 A = torch.cat([b["A"] for b in buf], 1)
@@ -278,7 +280,7 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
                 R = torch.cat([b["R"] for b in buf], 1)
                 Dn = torch.cat([b["Dn"] for b in buf], 1)
             last_v = net.v(env.obs).squeeze(-1) * ret_std + ret_mean
-            if fused is not None:
+            if fused is not None and graph_update < 3:
                 adv, RET = fused.gae(V, last_v, gamma, lam)            # one launch (auv_gae) instead of T x 6 small ones
             else:
                 adv = torch.zeros_like(R)
@@ -288,7 +290,7 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
                     delta = R[t] + gamma * nv * (1 - Dn[t]) - V[t]
                     gae = delta + gamma * lam * (1 - Dn[t]) * gae
                     adv[t] = gae
-            if fused is None:
+            if fused is None or graph_update >= 3:
                 RET = adv + V
             # running statistics of the returns (one pass of exponential averaging per update)
             m, s = RET.mean(), RET.std()
@@ -322,8 +324,8 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             # -5000 collision return cannot scale the policy's gradient away under a shared norm)
             bad_in = sum((~torch.isfinite(x)).sum() for x in (o, a, lp, advn, retn))
             bad_g = sum((~torch.isfinite(q.grad)).sum() for q in params if q.grad is not None)
-            n_pi = clip_grad_norm(pi_params, 0.5, stacked=graph_update >= 2)
-            n_v = clip_grad_norm(v_params, 0.5, stacked=graph_update >= 2)
+            n_pi = clip_grad_norm(pi_params, 0.5, stacked=graph_update in (2, 3))
+            n_v = clip_grad_norm(v_params, 0.5, stacked=graph_update in (2, 3))
             # (the record is filled element by element: no stack / cat inside a region that may be captured, see clip_grad_norm)
             if graph_update == 3:
                 diag_row.copy_(torch.stack([n_pi, n_v, loss.detach(), advn.abs().max(), ratio.detach().max(), bad_in.float(), bad_g.float(),
@@ -384,6 +386,14 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
                             weight_l1=float(sum(p_.detach().abs().sum() for p_ in pi_params)),
                             cross_track=cte, episodes=int(ep.shape[0]), goal_rate=goal, collision_rate=col, ep_return=ep_ret,
                             ep_len=ep_len, ep_progress=ep_prog, rollout_sps=world * n_total / t_roll_only, rollout_gae_sps=world * n_total / t_roll, sps=world * n_total / dt_all))
+        if graph_update and steps_bad:
+            # The captured update's own record shows values that cannot come from its inputs (a gradient norm of inf over
+            # finite gradient elements, or a count of non-finite inputs far beyond the number of inputs): the replayed
+            # graph's reductions returned stale memory (DESIGN.md section 8 -- reproduced in this loop, not root-caused
+            # below the framework).  Such a step scales the gradients by 0 or garbage; from here on the update runs eagerly.
+            log("update %4d: the captured update step returned corrupt reductions in %d of %d replays -- falling back to the eager update"
+                % (upd, steps_bad, d1 - d0))
+            graph_update, upd_graph = 0, None
         if rank == 0 and (upd % log_every == 0 or upd == updates - 1):
             if steps_bad:
                 bad = rows[(~torch.isfinite(rows[:, :3])).any(1) | (rows[:, 5:7] > 0).any(1)][:4]

@@ -210,7 +210,12 @@ class BatchedAuvEnv:
         # (probe_streams = False: any k streams -- under a counter-collecting profiler dispatches are serialised, the
         # probe would find no two streams side by side and the batch would not be split at all)
         if k > 1 and probe_streams:
-            streams = self._concurrent_streams(k, first=cur if inline_first else None)
+            # (the probe times two 300 us kernels against the wall clock: a busy host -- eight ranks starting at once -- can
+            # make a pair look serialised, so a short selection is tried again before it is believed)
+            for _attempt in range(3):
+                streams = self._concurrent_streams(k, first=cur if inline_first else None)
+                if len(streams) >= k:
+                    break
         else:
             streams = ([cur] if inline_first else []) + [torch.cuda.Stream(device=self.device) for _ in range(k - int(inline_first))]
         self.stream_probe_s = time.perf_counter() - t0
@@ -226,6 +231,10 @@ class BatchedAuvEnv:
         self._streams_c = (C.c_void_p * self.sub_batches)(*[st.cuda_stream for st in self._sub_streams])
         self._async_pending = False
         self._chain_graph = None
+        # the device-word rendezvous lets a one-wave kernel on one stream poll for a kernel on another: the two must be
+        # able to RUN side by side.  Streams that were not measured to (probe_streams = False: e.g. under a counter-
+        # collecting profiler, which executes one kernel at a time) get the event-based ordering, which cannot block
+        self.rendezvous = "device" if (probe_streams or self.sub_batches == 1) else "events"
         if self.sub_batches > 1 and self.effective_step_mode(per) == "one_launch":
             self.probe_streams()        # the hand-overs' dispatch-order assumption, probed in the shape production runs
         return self._slices

@@ -102,12 +102,40 @@ __device__ __forceinline__ float pol_tanh(const float x) {
 //   from L2 with only a wave or two per SIMD to hide the latency (one 16-k step ahead: 60 us for 4096 rows; profiles/r04).
 //   KS = 2: the k range alternates between two accumulators per n-tile (a single v_mfma_f32_16x16x4_f32 chain is
 //   latency-bound: 40 cycles dependent against 32 of issue).
-#define POL_DEPTH 2
+#ifndef POL_DEPTH
+#define POL_DEPTH 2                // (4 was measured: 141 VGPRs, or 24 spilled under the 128 that two workgroups per CU allow: 27 against 23 us)
+#endif
+// the weight fragments of a wave's n-tiles for the next DEPTH k-steps, in flight or landed
+template <int NTILES>
+struct PolW {
+  static constexpr int NT = (NTILES + POL_WAVES - 1) / POL_WAVES;   // n-tiles of this wave: wave, wave + WAVES, ...
+  float4 q[POL_DEPTH][NT][2];
+  const float* row[NT];
+};
+
+// Request the first DEPTH k-steps of a layer's weights.  They depend on nothing the kernel computes, so the request for
+// layer l + 1 goes out BEFORE layer l's epilogue and the barrier behind it (and layer 1's before the observation tile is
+// fetched): a layer then starts on fragments that have landed instead of on a cold trip to L2.
+template <int NTILES>
+__device__ __forceinline__ void pol_prefetch(PolW<NTILES>& w, const float* __restrict__ W, const int Kp, const int wave, const int lane) {
+  if (wave >= NTILES) return;
+  const int nJ = Kp / 32;
+#pragma unroll
+  for (int t = 0; t < PolW<NTILES>::NT; t++) w.row[t] = W + (size_t)((wave + POL_WAVES * t) % NTILES) * nJ * 512 + 4 * lane;   // (% : a tile index past
+                                                                         // the end re-reads a valid tile, its result is dropped)
+#pragma unroll
+  for (int d = 0; d < POL_DEPTH; d++) {
+    const int Jd = d < nJ ? d : nJ - 1;
+#pragma unroll
+    for (int t = 0; t < PolW<NTILES>::NT; t++) w.q[d][t][0] = *(const float4*)(w.row[t] + 512 * Jd), w.q[d][t][1] = *(const float4*)(w.row[t] + 512 * Jd + 256);
+  }
+}
+
 template <int NTILES, int KS, bool LAST>
-__device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int ldx, const float* __restrict__ W,
+__device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int ldx, PolW<NTILES>& w,
                                           const float* __restrict__ b, const int Kp, const int wave, const int lane,
                                           float* __restrict__ Y, const int ldy, f32x4 (*out)[POL_MT]) {
-  constexpr int NT = (NTILES + POL_WAVES - 1) / POL_WAVES;   // n-tiles of this wave: wave, wave + WAVES, ...
+  constexpr int NT = PolW<NTILES>::NT;
   if (wave >= NTILES) return;                                // (more waves than tiles in the narrow layers: nothing to do)
   const int m = lane & 15, g = lane >> 4;
   f32x4 acc[POL_MT][NT][KS];
@@ -119,18 +147,6 @@ __device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int
       for (int s = 0; s < KS; s++) acc[u][t][s] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   const float* xrow = X + m * ldx + 8 * g;                   // m-tile u: + 16 u rows
   const int nJ = Kp / 32;                                    // (a multiple of KS for every layer of this architecture)
-  // W is stored in fragment order (FusedActorCritic.refresh): block (n-tile, J) = 2 x 1 KB, lane l's floats j = 4 h .. 4 h + 3
-  // at [h][l][0..3] -- every load instruction of a wave reads one contiguous kilobyte
-  const float* wrow[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++) wrow[t] = W + (size_t)((wave + POL_WAVES * t) % NTILES) * nJ * 512 + 4 * lane;   // (% : a tile index past the end re-reads a valid tile, its result is dropped)
-  float4 bq[POL_DEPTH][NT][2];
-#pragma unroll
-  for (int d = 0; d < POL_DEPTH; d++) {
-    const int Jd = d < nJ ? d : nJ - 1;
-#pragma unroll
-    for (int t = 0; t < NT; t++) bq[d][t][0] = *(const float4*)(wrow[t] + 512 * Jd), bq[d][t][1] = *(const float4*)(wrow[t] + 512 * Jd + 256);
-  }
   for (int J = 0; J < nJ; J += POL_DEPTH) {
 #pragma unroll
     for (int d = 0; d < POL_DEPTH; d++) {
@@ -142,10 +158,12 @@ __device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int
           a[u][0] = *(const float4*)(xrow + 16 * u * ldx + 32 * Jc), a[u][1] = *(const float4*)(xrow + 16 * u * ldx + 32 * Jc + 4);
         float4 cur[NT][2];
 #pragma unroll
-        for (int t = 0; t < NT; t++) cur[t][0] = bq[d][t][0], cur[t][1] = bq[d][t][1];
-        const int Jn = (Jc + POL_DEPTH < nJ) ? Jc + POL_DEPTH : nJ - 1;   // refill this slot for step Jc + DEPTH
+        for (int t = 0; t < NT; t++) cur[t][0] = w.q[d][t][0], cur[t][1] = w.q[d][t][1];
+        if (Jc + POL_DEPTH < nJ) {                           // refill this slot for step Jc + DEPTH
 #pragma unroll
-        for (int t = 0; t < NT; t++) bq[d][t][0] = *(const float4*)(wrow[t] + 512 * Jn), bq[d][t][1] = *(const float4*)(wrow[t] + 512 * Jn + 256);
+          for (int t = 0; t < NT; t++)
+            w.q[d][t][0] = *(const float4*)(w.row[t] + 512 * (Jc + POL_DEPTH)), w.q[d][t][1] = *(const float4*)(w.row[t] + 512 * (Jc + POL_DEPTH) + 256);
+        }
         const int s = (KS == 2) ? (d & 1) : 0;               // (DEPTH is even: step parity == slot parity)
 #pragma unroll
         for (int t = 0; t < NT; t++)
@@ -186,7 +204,7 @@ __device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int
 }
 
 // grid (ceil(ne / 16), 2): blockIdx.y = 0 the policy net, 1 the value net.
-__global__ void __launch_bounds__(POL_THREADS) k6_policy_act(PolicyArgs pa) {
+__global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_policy_act(PolicyArgs pa) {   // (two workgroups per CU)
   extern __shared__ __align__(16) unsigned char smem[];
   const auv_policy_io_t& io = pa.io;
   const int tid = threadIdx.x, wave = tid / AUV_WAVE, lane = tid % AUV_WAVE;
@@ -215,6 +233,20 @@ __global__ void __launch_bounds__(POL_THREADS) k6_policy_act(PolicyArgs pa) {
   }
   const bool act = t < T;                                        // t == T: the flush call after a rollout's last step
   if (act) {
+    const float* P = io.params + (size_t)net * pol_net_floats(K0);
+    const float* W1 = P;
+    const float* b1 = W1 + (size_t)POL_H1 * K0p;
+    const float* W2 = b1 + POL_H1;
+    const float* b2 = W2 + (size_t)POL_H2 * POL_H1;
+    const float* W3 = b2 + POL_H2;
+    const float* b3 = W3 + (size_t)POL_H3 * POL_H2;
+    const float* W4 = b3 + POL_H3;
+    const float* b4 = W4 + (size_t)POL_OUT * POL_H3;
+    PolW<POL_H1 / 16> w1;
+    PolW<POL_H2 / 16> w2;
+    PolW<POL_H3 / 16> w3;
+    PolW<1> w4;
+    pol_prefetch(w1, W1, K0p, wave, lane);                       // (in flight while the observation tile is fetched)
     // ---- observation tile -> LDS (zero padded), and into the rollout (policy workgroup) ----
     // the tile's rows are consecutive rows of the observation buffer: one contiguous range, read two floats per lane
     // (rows of an even number of columns start 8-byte aligned and no pair straddles two rows)
@@ -239,24 +271,18 @@ __global__ void __launch_bounds__(POL_THREADS) k6_policy_act(PolicyArgs pa) {
       }
     }
     __syncthreads();
-    const float* P = io.params + (size_t)net * pol_net_floats(K0);
-    const float* W1 = P;
-    const float* b1 = W1 + (size_t)POL_H1 * K0p;
-    const float* W2 = b1 + POL_H1;
-    const float* b2 = W2 + (size_t)POL_H2 * POL_H1;
-    const float* W3 = b2 + POL_H2;
-    const float* b3 = W3 + (size_t)POL_H3 * POL_H2;
-    const float* W4 = b3 + POL_H3;
-    const float* b4 = W4 + (size_t)POL_OUT * POL_H3;
-    pol_layer<POL_H1 / 16, 1, false>(X, ldx, W1, b1, K0p, wave, lane, Y1, ld1, nullptr);
+    pol_prefetch(w2, W2, POL_H1, wave, lane);                    // (the next layer's weights: in flight during this layer)
+    pol_layer<POL_H1 / 16, 1, false>(X, ldx, w1, b1, K0p, wave, lane, Y1, ld1, nullptr);
     __syncthreads();
-    pol_layer<POL_H2 / 16, 1, false>(Y1, ld1, W2, b2, POL_H1, wave, lane, Y2, ld2, nullptr);
+    pol_prefetch(w3, W3, POL_H2, wave, lane);
+    pol_layer<POL_H2 / 16, 1, false>(Y1, ld1, w2, b2, POL_H1, wave, lane, Y2, ld2, nullptr);
     __syncthreads();
-    pol_layer<POL_H3 / 16, 2, false>(Y2, ld2, W3, b3, POL_H2, wave, lane, Y3, ld3, nullptr);
+    pol_prefetch(w4, W4, POL_H3, wave, lane);
+    pol_layer<POL_H3 / 16, 2, false>(Y2, ld2, w3, b3, POL_H2, wave, lane, Y3, ld3, nullptr);
     __syncthreads();
     if (wave == 0) {
       f32x4 o[1][POL_MT];
-      pol_layer<1, 2, true>(Y3, ld3, W4, b4, POL_H3, 0, lane, nullptr, 0, o);
+      pol_layer<1, 2, true>(Y3, ld3, w4, b4, POL_H3, 0, lane, nullptr, 0, o);
       const int n = lane & 15, g = lane >> 4;
       if (net == 0) {
         // ---- diagonal Gaussian: sample, log-probability, action ----

@@ -30,6 +30,15 @@ def _pad16(x: int) -> int:
     return (x + 31) & ~31          # (rows are padded to the kernel's k-step of 32 columns)
 
 
+def pack_linear(weight: torch.Tensor, out_pad: int, in_pad: int) -> torch.Tensor:
+    """A Linear.weight [out, in] zero-padded to [out_pad, in_pad] (multiples of 16 / 32) and laid out in MFMA fragment order
+    (include/auv_hip.h, auv_policy_io): [n-tile][k-step J][half h][group g][row n][4 floats] -- lane 16 g + n of a wave holds
+    k = 32 J + 8 g + 4 h + (0..3) of row n of the tile, and each load instruction of the kernel reads 1 KB contiguously."""
+    w = torch.zeros((out_pad, in_pad), dtype=torch.float32, device=weight.device)
+    w[:weight.shape[0], :weight.shape[1]].copy_(weight)
+    return w.view(out_pad // 16, 16, in_pad // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5).contiguous().view(-1)
+
+
 class FusedActorCritic:
     def __init__(self, net: nn.Module, env: BatchedAuvEnv, rollout: int, reward_scale: float = 1.0, reward_clip: float = 0.0,
                  act_mid=None, act_half=None, clip_lo=None, clip_hi=None, seed: int = 0, store_obs: bool = True, debug: bool = False):
@@ -99,12 +108,7 @@ class FusedActorCritic:
             for j, l in enumerate(lin):
                 out_p = l.out_features if j < 3 else 16
                 in_p = self.k0p if j == 0 else l.in_features
-                # MFMA fragment order: [n-tile][k-step J][half h][group g][row n][4 floats] -- lane 16 g + n of a wave holds
-                # k = 32 J + 8 g + 4 h + (0..3) of row n of the tile, and each load instruction reads 1 KB contiguously
-                w = torch.zeros((out_p, in_p), dtype=torch.float32, device=self.device)
-                w[:l.out_features, :l.in_features].copy_(l.weight)
-                w = w.view(out_p // 16, 16, in_p // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5)
-                p[off:off + out_p * in_p].view(out_p // 16, in_p // 32, 2, 4, 16, 4).copy_(w)
+                p[off:off + out_p * in_p].copy_(pack_linear(l.weight, out_p, in_p))
                 off += out_p * in_p
                 p[off:off + l.out_features].copy_(l.bias)
                 off += out_p

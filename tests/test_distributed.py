@@ -39,8 +39,10 @@ def _worker(rank, world, port, n_total, q):
     stats = {"episode_return": idx * 2.0, "episode_length": idx + 100.0, "collision": (idx % 3 == 0).float()}
     full = D.gather_episode_stats(stats)
     t = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    per_rank = D.gather_floats([10.0 * rank + 1.0, float(hi - lo)], torch.device("cpu"))   # (bench.py: per-rank world_gen_s, ...)
+    assert D.backend_name() == "gloo"
     D.barrier()
-    q.put((rank, lo, hi, {k: v.tolist() for k, v in full.items()}, t))
+    q.put((rank, lo, hi, {k: v.tolist() for k, v in full.items()}, t, per_rank))
     torch.distributed.destroy_process_group()
 
 
@@ -58,7 +60,8 @@ def test_gloo_world2_gather_episode_stats():
         p.join(30)
         assert p.exitcode == 0
     exp = torch.arange(n_total, dtype=torch.float32)
-    for rank, lo, hi, full, t in res:
+    for rank, lo, hi, full, t, per_rank in res:
+        assert per_rank == [[1.0, 6.0], [11.0, 5.0]]           # every rank sees every rank's figures, in rank order
         assert full["episode_return"] == (exp * 2).tolist()
         assert full["episode_length"] == (exp + 100).tolist()
         assert full["collision"] == (exp % 3 == 0).float().tolist()

@@ -2,7 +2,7 @@
 
 All 4096 LiDAR waves of the headline batch are resident at once only if `k23_lidar_nav` stays
 within 128 VGPRs (4 waves per SIMD) -- and spilled VGPRs cost real HBM traffic and latency (17
-spilled registers were worth 4.6 % of the step).  This compiles the kernel for
+spilled registers were worth 4.6 % of the step, docs/HISTORY.md section 4).  This compiles the kernel for
 gfx950 and reads the resource usage the compiler reports."""
 import os
 import re

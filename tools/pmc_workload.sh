@@ -11,9 +11,13 @@ sha256sum gym_auv_amd/csrc/libauv_hip.so > $OUT/lib_sha256.txt
 B="$ROOT/bench.py --bank-cache /tmp/bank --workload $WL --sub-batches $SUB --probe-streams 0 --cpu-baseline 0"
 python $B --steps 20 "$@" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
+echo "  pmc pass 1/3 (FETCH_SIZE)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $B --steps 100 --warmup 100 "$@" > $OUT/pmc_fetch_bench.json 2>/dev/null
+echo "  pmc pass 2/3 (WRITE_SIZE)"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $B --steps 100 --warmup 100 "$@" > $OUT/pmc_write_bench.json 2>/dev/null
+echo "  pmc pass 3/3 (SQ counters)"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $B --steps 300 --warmup 1900 "$@" > $OUT/pmc_sq_bench.json 2>/dev/null
+echo "  pmc passes done"
 cd $ROOT
 python tools/pmc_step_summary.py $OUT $SUB > $OUT/pmc_step_summary.json   # (checks $SUB against config.sub_batches of the passes)
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
