@@ -297,12 +297,15 @@ def main():
     if bank is None:
         bank = build_bank_parallel(gen, seeds, procs=procs, **kwargs)
         if cache:
+            tmp = "%s.%d.tmp.npz" % (cache, os.getpid())
             try:
-                tmp = "%s.%d.tmp.npz" % (cache, os.getpid())
                 np.savez(tmp, **bank)
                 os.replace(tmp, cache)                     # (atomic: another rank or run never reads half a file)
-            except OSError:
-                pass
+            except OSError:                                # (a full or read-only temp directory: the cache is a convenience)
+                try:
+                    os.remove(tmp)
+                except OSError:
+                    pass
     t_gen = time.time() - t0
 
     from gym_auv_amd import distributed as D
@@ -335,8 +338,17 @@ def main():
     t_probe = 0.0
     if sub > 1:
         # fewer streams side by side than chains asked for would silently time a different shape: fail instead
-        env.set_sub_batches(sub, probe_streams=bool(args.probe_streams), inline_first=bool(args.inline_first and api == "async"),
-                            strict=bool(args.probe_streams))
+        for attempt in range(3):
+            try:
+                env.set_sub_batches(sub, probe_streams=bool(args.probe_streams), inline_first=bool(args.inline_first and api == "async"),
+                                    strict=bool(args.probe_streams))
+                break
+            except RuntimeError:
+                # (the stream probe times kernels against the wall clock; with several ranks starting on one host it can read a
+                # busy host as "serialised": ask again before giving up -- and do give up rather than time another shape)
+                if attempt == 2:
+                    raise
+                time.sleep(0.5 * (attempt + 1))
         t_probe = env.stream_probe_s
     elif api == "async":
         env.set_sub_batches(1, inline_first=bool(args.inline_first))
