@@ -109,7 +109,7 @@ def average_gradients(params, world):
 def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=0, log_every=1,
           task="colav", step_mode=None, graph_rollout=False, sub_batches=4, minibatches=32,
           reward_scale=0.01, reward_clip=0.0, min_cumulative_reward=None, act_space="raw", ret_norm=False, orthogonal=False, ent_coef=0.01, log_std=-0.5, lr=2e-4,
-          fused_policy=True, graph_update=False):
+          fused_policy=True, graph_update=False, policy_bf16=False):
     from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
@@ -206,7 +206,8 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
         # of every chain is one C call.  The torch modules stay the owners of the weights (refresh() after each update).
         from gym_auv_amd.policy import FusedActorCritic
         fused = FusedActorCritic(net, env, rollout=T, reward_scale=reward_scale, reward_clip=reward_clip, act_mid=a_mid.tolist(),
-                                 act_half=a_half.tolist(), clip_lo=c_lo.tolist(), clip_hi=c_hi.tolist(), seed=1000 * seed + rank)
+                                 act_half=a_half.tolist(), clip_lo=c_lo.tolist(), clip_hi=c_hi.tolist(), seed=1000 * seed + rank,
+                                 bf16=policy_bf16)
         graph_rollout = False
     graphs = None
     if graph_rollout:
@@ -439,6 +440,9 @@ if __name__ == "__main__":
     ap.add_argument("--graph-rollout", type=int, default=0, help="1: one captured device graph per chain and rollout step (torch-module policy only)")
     ap.add_argument("--graph-update", type=int, default=0,
                     help="1: a minibatch's forward, backward, clipping and Adam step as one captured device graph (single rank)")
+    ap.add_argument("--policy-bf16", type=int, default=0,
+                    help="1: the fused policy launch multiplies with bf16 weights on the bf16 matrix cores (faster rollouts, ~1e-2 on the "
+                         "action means: the PPO ratio then compares log-probabilities of slightly different policies); default 0 = exact f32")
     ap.add_argument("--fused-policy", type=int, default=1,
                     help="1 (default): the policy in the loop is ONE HIP launch per chain and step (gym_auv_amd/policy.py); 0: the torch modules")
     ap.add_argument("--step-mode", default=None, help="launch shape of a step (BatchedAuvEnv.STEP_MODES); default: the library's")
@@ -455,7 +459,7 @@ if __name__ == "__main__":
     from gym_auv_amd import distributed as D
     _rank, _world, local = D.init_from_env()     # one process per GPU under torch.distributed.run; cuda:0 alone
     train(a.envs, a.updates, a.rollout, device="cuda:%d" % local, seed=a.seed, worlds=a.worlds, regen=a.regen, log_every=a.log_every,
-          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout), fused_policy=bool(a.fused_policy), graph_update=a.graph_update,
+          task=a.task, step_mode=a.step_mode, graph_rollout=bool(a.graph_rollout), fused_policy=bool(a.fused_policy), graph_update=a.graph_update, policy_bf16=bool(a.policy_bf16),
           sub_batches=a.sub_batches, minibatches=a.minibatches, act_space=a.act_space, ret_norm=bool(a.ret_norm),
           orthogonal=bool(a.orthogonal), ent_coef=a.ent_coef, log_std=a.log_std, lr=a.lr, reward_clip=a.reward_clip,
           min_cumulative_reward=a.min_cumulative_reward)

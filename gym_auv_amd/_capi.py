@@ -113,7 +113,7 @@ class AuvPolicyIO(C.Structure):
         ("R", C.c_void_p), ("Dn", C.c_void_p), ("mu_out", C.c_void_p), ("eps_out", C.c_void_p),
         ("seed", C.c_uint64), ("obs_dim", C.c_int32), ("T", C.c_int32), ("ld", C.c_int32), ("env_base", C.c_int32),
         ("act_mid", C.c_float * 2), ("act_half", C.c_float * 2), ("clip_lo", C.c_float * 2), ("clip_hi", C.c_float * 2),
-        ("reward_scale", C.c_float), ("reward_clip", C.c_float),
+        ("reward_scale", C.c_float), ("reward_clip", C.c_float), ("params_bf16", C.c_void_p),
     ]
 
 
@@ -156,7 +156,8 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_policy_param_floats": (sz, [i32]),
         "auv_policy_act": (C.c_int, [vp, i32, i32, C.POINTER(AuvPolicyIO), vp]),
         "auv_gae": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, vp]),
-        "auv_policy_rollout": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(AuvPolicyIO), vp, vp, vp, i32, i32]),
+        "auv_policy_rollout": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(AuvPolicyIO), vp, vp, vp, i32, i32,
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "auv_step_pipelined_timed": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp, C.POINTER(C.c_float)]),
         "auv_streams_overlap": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float)]),
         "auv_episode_log": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),

@@ -27,6 +27,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef POL_MT
 #define POL_MT 1                   // MFMA M-tiles (of 16 rows) per workgroup.  (2 -- every weight fragment a wave loads then serves two
@@ -63,6 +64,8 @@ __host__ __device__ inline size_t pol_lds_bytes(int obs_dim) {
 struct PolicyArgs {
   auv_policy_io_t io;
   int32_t e0, ne;
+  long long t_host, gstep_host;      // >= 0: the host names the rollout position and the generator's step (auv_policy_rollout: a plain
+                                     // loop of launches); -1: both live on the device (io.ctr) and the launch moves them on itself
 };
 
 // splitmix64 finaliser: a counter-based generator -- (seed, step, row, component) -> 64 well-mixed bits
@@ -105,37 +108,53 @@ __device__ __forceinline__ float pol_tanh(const float x) {
 #ifndef POL_DEPTH
 #define POL_DEPTH 2                // (4 was measured: 141 VGPRs, or 24 spilled under the 128 that two workgroups per CU allow: 27 against 23 us)
 #endif
-// the weight fragments of a wave's n-tiles for the next DEPTH k-steps, in flight or landed
-template <int NTILES>
+// the weight fragments of a wave's n-tiles for the next DEPTH k-steps, in flight or landed.  BF: the weights are stored as
+// bf16 (auv_policy_io::params_bf16, optional): a k-step's fragment is then 16 bytes per lane and ONE
+// v_mfma_f32_16x16x32_bf16 instead of eight f32 MFMAs (activations are rounded to bf16 on the way into the MFMA,
+// accumulation, bias and tanh stay f32) -- NOT the reference's arithmetic: ~1e-2 on the means, behind a flag.
+template <int NTILES, bool BF>
 struct PolW {
   static constexpr int NT = (NTILES + POL_WAVES - 1) / POL_WAVES;   // n-tiles of this wave: wave, wave + WAVES, ...
-  float4 q[POL_DEPTH][NT][2];
+  static constexpr int BLK = BF ? 256 : 512;                         // floats (4-byte units) per (n-tile, k-step) block
+  float4 q[POL_DEPTH][NT][BF ? 1 : 2];
   const float* row[NT];
 };
 
 // Request the first DEPTH k-steps of a layer's weights.  They depend on nothing the kernel computes, so the request for
 // layer l + 1 goes out BEFORE layer l's epilogue and the barrier behind it (and layer 1's before the observation tile is
 // fetched): a layer then starts on fragments that have landed instead of on a cold trip to L2.
-template <int NTILES>
-__device__ __forceinline__ void pol_prefetch(PolW<NTILES>& w, const float* __restrict__ W, const int Kp, const int wave, const int lane) {
+template <int NTILES, bool BF>
+__device__ __forceinline__ void pol_prefetch(PolW<NTILES, BF>& w, const float* __restrict__ W, const int Kp, const int wave, const int lane) {
   if (wave >= NTILES) return;
   const int nJ = Kp / 32;
+  constexpr int BLK = PolW<NTILES, BF>::BLK;
 #pragma unroll
-  for (int t = 0; t < PolW<NTILES>::NT; t++) w.row[t] = W + (size_t)((wave + POL_WAVES * t) % NTILES) * nJ * 512 + 4 * lane;   // (% : a tile index past
-                                                                         // the end re-reads a valid tile, its result is dropped)
+  for (int t = 0; t < PolW<NTILES, BF>::NT; t++) w.row[t] = W + (size_t)((wave + POL_WAVES * t) % NTILES) * nJ * BLK + 4 * lane;   // (% : a tile index
+                                                                         // past the end re-reads a valid tile, its result is dropped)
 #pragma unroll
   for (int d = 0; d < POL_DEPTH; d++) {
     const int Jd = d < nJ ? d : nJ - 1;
 #pragma unroll
-    for (int t = 0; t < PolW<NTILES>::NT; t++) w.q[d][t][0] = *(const float4*)(w.row[t] + 512 * Jd), w.q[d][t][1] = *(const float4*)(w.row[t] + 512 * Jd + 256);
+    for (int t = 0; t < PolW<NTILES, BF>::NT; t++) {
+      w.q[d][t][0] = *(const float4*)(w.row[t] + BLK * Jd);
+      if (!BF) w.q[d][t][BF ? 0 : 1] = *(const float4*)(w.row[t] + BLK * Jd + 256);
+    }
   }
 }
 
-template <int NTILES, int KS, bool LAST>
-__device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int ldx, PolW<NTILES>& w,
+__device__ __forceinline__ bf16x8 pol_to_bf16(const float4 lo, const float4 hi) {
+  bf16x8 v;
+  v[0] = (__bf16)lo.x, v[1] = (__bf16)lo.y, v[2] = (__bf16)lo.z, v[3] = (__bf16)lo.w;
+  v[4] = (__bf16)hi.x, v[5] = (__bf16)hi.y, v[6] = (__bf16)hi.z, v[7] = (__bf16)hi.w;
+  return v;
+}
+
+template <int NTILES, int KS, bool LAST, bool BF>
+__device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int ldx, PolW<NTILES, BF>& w,
                                           const float* __restrict__ b, const int Kp, const int wave, const int lane,
                                           float* __restrict__ Y, const int ldy, f32x4 (*out)[POL_MT]) {
-  constexpr int NT = PolW<NTILES>::NT;
+  constexpr int NT = PolW<NTILES, BF>::NT;
+  constexpr int BLK = PolW<NTILES, BF>::BLK;
   if (wave >= NTILES) return;                                // (more waves than tiles in the narrow layers: nothing to do)
   const int m = lane & 15, g = lane >> 4;
   f32x4 acc[POL_MT][NT][KS];
@@ -158,11 +177,13 @@ __device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int
           a[u][0] = *(const float4*)(xrow + 16 * u * ldx + 32 * Jc), a[u][1] = *(const float4*)(xrow + 16 * u * ldx + 32 * Jc + 4);
         float4 cur[NT][2];
 #pragma unroll
-        for (int t = 0; t < NT; t++) cur[t][0] = w.q[d][t][0], cur[t][1] = w.q[d][t][1];
+        for (int t = 0; t < NT; t++) cur[t][0] = w.q[d][t][0], cur[t][1] = w.q[d][t][BF ? 0 : 1];
         if (Jc + POL_DEPTH < nJ) {                           // refill this slot for step Jc + DEPTH
 #pragma unroll
-          for (int t = 0; t < NT; t++)
-            w.q[d][t][0] = *(const float4*)(w.row[t] + 512 * (Jc + POL_DEPTH)), w.q[d][t][1] = *(const float4*)(w.row[t] + 512 * (Jc + POL_DEPTH) + 256);
+          for (int t = 0; t < NT; t++) {
+            w.q[d][t][0] = *(const float4*)(w.row[t] + BLK * (Jc + POL_DEPTH));
+            if (!BF) w.q[d][t][BF ? 0 : 1] = *(const float4*)(w.row[t] + BLK * (Jc + POL_DEPTH) + 256);
+          }
         }
         const int s = (KS == 2) ? (d & 1) : 0;               // (DEPTH is even: step parity == slot parity)
 #pragma unroll
@@ -170,14 +191,20 @@ __device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int
 #pragma unroll
           for (int u = 0; u < POL_MT; u++) {
             f32x4 c = acc[u][t][s];
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0].x, cur[t][0].x, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0].y, cur[t][0].y, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0].z, cur[t][0].z, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0].w, cur[t][0].w, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1].x, cur[t][1].x, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1].y, cur[t][1].y, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1].z, cur[t][1].z, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1].w, cur[t][1].w, c, 0, 0, 0);
+            if (BF) {
+              const bf16x8 av = pol_to_bf16(a[u][0], a[u][1]);
+              const bf16x8 bv = *(const bf16x8*)&cur[t][0];
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+            } else {
+              c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0].x, cur[t][0].x, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0].y, cur[t][0].y, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0].z, cur[t][0].z, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0].w, cur[t][0].w, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1].x, cur[t][1].x, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1].y, cur[t][1].y, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1].z, cur[t][1].z, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1].w, cur[t][1].w, c, 0, 0, 0);
+            }
             acc[u][t][s] = c;
           }
       }
@@ -204,6 +231,7 @@ __device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int
 }
 
 // grid (ceil(ne / 16), 2): blockIdx.y = 0 the policy net, 1 the value net.
+template <bool BF>
 __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_policy_act(PolicyArgs pa) {   // (two workgroups per CU)
   extern __shared__ __align__(16) unsigned char smem[];
   const auv_policy_io_t& io = pa.io;
@@ -217,8 +245,9 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
   float* Y2 = X;                                                 // (X is dead once layer 1 is through: a barrier lies in between)
   float* Y3 = Y1;                                                // (Y1 is dead once layer 2 is through)
   // position in the rollout and the generator's step counter: read by every workgroup before anybody moves them on
-  const long long t = io.ctr[0];
-  const unsigned long long gstep = (unsigned long long)io.ctr[1];
+  const bool host_counts = pa.t_host >= 0;
+  const long long t = host_counts ? pa.t_host : io.ctr[0];
+  const unsigned long long gstep = (unsigned long long)(host_counts ? pa.gstep_host : io.ctr[1]);
   const int T = io.T;
   const int cnt = pa.ne;
   const size_t ld = (size_t)io.ld;                               // environments per rollout row
@@ -242,10 +271,18 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
     const float* b3 = W3 + (size_t)POL_H3 * POL_H2;
     const float* W4 = b3 + POL_H3;
     const float* b4 = W4 + (size_t)POL_OUT * POL_H3;
-    PolW<POL_H1 / 16> w1;
-    PolW<POL_H2 / 16> w2;
-    PolW<POL_H3 / 16> w3;
-    PolW<1> w4;
+    if (BF) {
+      // bf16 weights: the four matrices of a net back to back, half the floats each (biases and log_std stay in `params`)
+      const float* Q = (const float*)io.params_bf16 + (size_t)net * (pol_net_floats(K0) - POL_H1 - POL_H2 - POL_H3 - POL_OUT) / 2;
+      W1 = Q;
+      W2 = W1 + (size_t)POL_H1 * K0p / 2;
+      W3 = W2 + (size_t)POL_H2 * POL_H1 / 2;
+      W4 = W3 + (size_t)POL_H3 * POL_H2 / 2;
+    }
+    PolW<POL_H1 / 16, BF> w1;
+    PolW<POL_H2 / 16, BF> w2;
+    PolW<POL_H3 / 16, BF> w3;
+    PolW<1, BF> w4;
     pol_prefetch(w1, W1, K0p, wave, lane);                       // (in flight while the observation tile is fetched)
     // ---- observation tile -> LDS (zero padded), and into the rollout (policy workgroup) ----
     // the tile's rows are consecutive rows of the observation buffer: one contiguous range, read two floats per lane
@@ -272,17 +309,17 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
     }
     __syncthreads();
     pol_prefetch(w2, W2, POL_H1, wave, lane);                    // (the next layer's weights: in flight during this layer)
-    pol_layer<POL_H1 / 16, 1, false>(X, ldx, w1, b1, K0p, wave, lane, Y1, ld1, nullptr);
+    pol_layer<POL_H1 / 16, 1, false, BF>(X, ldx, w1, b1, K0p, wave, lane, Y1, ld1, nullptr);
     __syncthreads();
     pol_prefetch(w3, W3, POL_H2, wave, lane);
-    pol_layer<POL_H2 / 16, 1, false>(Y1, ld1, w2, b2, POL_H1, wave, lane, Y2, ld2, nullptr);
+    pol_layer<POL_H2 / 16, 1, false, BF>(Y1, ld1, w2, b2, POL_H1, wave, lane, Y2, ld2, nullptr);
     __syncthreads();
     pol_prefetch(w4, W4, POL_H3, wave, lane);
-    pol_layer<POL_H3 / 16, 2, false>(Y2, ld2, w3, b3, POL_H2, wave, lane, Y3, ld3, nullptr);
+    pol_layer<POL_H3 / 16, 2, false, BF>(Y2, ld2, w3, b3, POL_H2, wave, lane, Y3, ld3, nullptr);
     __syncthreads();
     if (wave == 0) {
       f32x4 o[1][POL_MT];
-      pol_layer<1, 2, true>(Y3, ld3, w4, b4, POL_H3, 0, lane, nullptr, 0, o);
+      pol_layer<1, 2, true, BF>(Y3, ld3, w4, b4, POL_H3, 0, lane, nullptr, 0, o);
       const int n = lane & 15, g = lane >> 4;
       if (net == 0) {
         // ---- diagonal Gaussian: sample, log-probability, action ----
@@ -323,7 +360,19 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
       }
     }
   }
-  // ---- count off: the last workgroup of the launch moves the rollout position and the generator's counter on ----
+  // ---- the rollout position and the generator's counter move on ----
+  if (host_counts) {
+    // the host named them (nobody in this launch reads io.ctr): one workgroup keeps the device copies in step, for a later
+    // auv_policy_act on the same buffers
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+      if (t <= T) io.ctr[0] = t + 1;
+      io.ctr[1] = (long long)(gstep + 1);
+    }
+    return;
+  }
+  // on the device (a launch that may sit in a captured graph): every workgroup has read them by the time it counts itself off,
+  // the last one moves them.  (512 returning atomics on one word: ~4 of the 8 us an EMPTY launch of this grid takes -- why
+  // auv_policy_rollout, a plain host loop, names the counters itself.)
   __syncthreads();
   if (tid == 0) {
     const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
@@ -370,12 +419,16 @@ size_t auv_policy_lds_bytes(int obs_dim) { return pol_lds_bytes(obs_dim); }
 hipError_t auv_policy_prepare(int obs_dim) {
   const size_t b = pol_lds_bytes(obs_dim);
   if (b <= 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute((const void*)k6_policy_act, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  hipError_t e = hipFuncSetAttribute((const void*)k6_policy_act<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)k6_policy_act<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
 }
 
-void auv_launch_policy(const auv_policy_io_t& io, int e0, int ne, hipStream_t st) {
+void auv_launch_policy(const auv_policy_io_t& io, int e0, int ne, hipStream_t st, long long t_host, long long gstep_host) {
   PolicyArgs pa;
   pa.io = io, pa.e0 = e0, pa.ne = ne;
+  pa.t_host = t_host, pa.gstep_host = gstep_host;
   const dim3 grid((ne + POL_ROWS - 1) / POL_ROWS, 2), block(POL_THREADS);
-  hipLaunchKernelGGL(k6_policy_act, grid, block, pol_lds_bytes(io.obs_dim), st, pa);
+  if (io.params_bf16) hipLaunchKernelGGL(k6_policy_act<true>, grid, block, pol_lds_bytes(io.obs_dim), st, pa);
+  else hipLaunchKernelGGL(k6_policy_act<false>, grid, block, pol_lds_bytes(io.obs_dim), st, pa);
 }

@@ -39,9 +39,18 @@ def pack_linear(weight: torch.Tensor, out_pad: int, in_pad: int) -> torch.Tensor
     return w.view(out_pad // 16, 16, in_pad // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5).contiguous().view(-1)
 
 
+def pack_linear_bf16(weight: torch.Tensor, out_pad: int, in_pad: int) -> torch.Tensor:
+    """The same matrix as bf16 fragments for v_mfma_f32_16x16x32_bf16 (auv_policy_io::params_bf16): [n-tile][k-step J][group g]
+    [row n][8 bf16] -- lane 16 g + n holds k = 32 J + 8 g + (0..7) of row n, 16 bytes."""
+    w = torch.zeros((out_pad, in_pad), dtype=torch.float32, device=weight.device)
+    w[:weight.shape[0], :weight.shape[1]].copy_(weight)
+    return w.view(out_pad // 16, 16, in_pad // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1).to(torch.bfloat16)
+
+
 class FusedActorCritic:
     def __init__(self, net: nn.Module, env: BatchedAuvEnv, rollout: int, reward_scale: float = 1.0, reward_clip: float = 0.0,
-                 act_mid=None, act_half=None, clip_lo=None, clip_hi=None, seed: int = 0, store_obs: bool = True, debug: bool = False):
+                 act_mid=None, act_half=None, clip_lo=None, clip_hi=None, seed: int = 0, store_obs: bool = True, debug: bool = False,
+                 bf16: bool = False):
         self.net, self.env, self.T = net, env, int(rollout)
         self.device = env.device
         self._lin = []
@@ -57,6 +66,11 @@ class FusedActorCritic:
         n_float = int(_LIB.auv_policy_param_floats(env.obs_dim))
         self.params = torch.zeros(n_float, dtype=torch.float32, device=self.device)
         assert self.params.data_ptr() % 16 == 0
+        # bf16 = True: the weights also as bf16 fragments, and the launch multiplies on v_mfma_f32_16x16x32_bf16 (one MFMA where
+        # the exact path issues eight; ~1e-2 on the means -- NOT the reference's arithmetic; default off)
+        self.bf16 = bool(bf16)
+        n_w = (n_float - 4) // 2 - (sum(HIDDEN) + 16)                                  # weight elements of one net
+        self.params_bf16 = torch.zeros(2 * n_w, dtype=torch.bfloat16, device=self.device) if self.bf16 else None
         if env._slices is None:
             env.set_sub_batches(1)
         self.slices = list(env._slices)
@@ -91,9 +105,14 @@ class FusedActorCritic:
             io.eps_out = self.eps[lo:].data_ptr() if debug else None
             io.seed = (int(seed) * 0x9E3779B97F4A7C15 + i) & 0xFFFFFFFFFFFFFFFF
             io.obs_dim, io.T, io.ld, io.env_base = D, self.T, N, 0
+            io.params_bf16 = self.params_bf16.data_ptr() if self.bf16 else None
             for k in range(2):
                 io.act_mid[k], io.act_half[k], io.clip_lo[k], io.clip_hi[k] = mid[k], half[k], clo[k], chi[k]
             io.reward_scale, io.reward_clip = float(reward_scale), float(reward_clip)
+        # host mirror of every chain's rollout position and generator step (the device copies in `ctr` stay in step with them):
+        # rollout() names them to the launches, which then need no count-off
+        self._t = [0] * len(self.slices)
+        self._g = [0] * len(self.slices)
         self.refresh()
 
     # ------------------------------------------------------------------------------ weights
@@ -102,13 +121,16 @@ class FusedActorCritic:
         """Repack the modules' weights into the kernel's layout (rows padded to a multiple of 16 columns, the last layer to 16
         rows): device-side copies on the current stream, no host synchronisation.  Call after every optimiser step that
         precedes a rollout."""
-        off = 0
+        off = off16 = 0
         p = self.params
         for lin in self._lin:
             for j, l in enumerate(lin):
                 out_p = l.out_features if j < 3 else 16
                 in_p = self.k0p if j == 0 else l.in_features
                 p[off:off + out_p * in_p].copy_(pack_linear(l.weight, out_p, in_p))
+                if self.bf16:
+                    self.params_bf16[off16:off16 + out_p * in_p].copy_(pack_linear_bf16(l.weight, out_p, in_p))
+                    off16 += out_p * in_p
                 off += out_p * in_p
                 p[off:off + l.out_features].copy_(l.bias)
                 off += out_p
@@ -121,6 +143,7 @@ class FusedActorCritic:
         for i, b in enumerate(self.buf):
             with torch.cuda.stream(self.env._sub_streams[i]):
                 b["ctr"][0] = 0
+            self._t[i] = 0
 
     def act(self, i: int, stream: Optional[torch.cuda.Stream] = None):
         """The policy launch of sub-batch i alone (auv_policy_act) on `stream` (default: the sub-batch's): writes the
@@ -128,6 +151,8 @@ class FusedActorCritic:
         lo, cnt = self.slices[i]
         st = self.env._sub_streams[i] if stream is None else stream
         _check(_LIB.auv_policy_act(self.env._h, lo, cnt, C.byref(self._ios[i]), C.c_void_p(st.cuda_stream)), "auv_policy_act")
+        self._t[i] = min(self._t[i] + 1, self.T + 1)
+        self._g[i] += 1
 
     def rollout(self, n_steps: int, flush: bool = True):
         """`n_steps` transitions of every sub-batch: per step and chain the policy launch and the environment's step of that
@@ -135,9 +160,15 @@ class FusedActorCritic:
         `flush`: a final policy call stores reward / done of the last step.  The chains are not ordered against the caller's
         stream: order them yourself (wait_stream) around the call."""
         env = self.env
+        k = len(self.slices)
+        t0, g0 = (C.c_int64 * k)(*self._t), (C.c_int64 * k)(*self._g)
         _check(_LIB.auv_policy_rollout(env._h, env.sub_batches, env._bounds_c, env._streams_c, self._ios,
                                        C.c_void_p(env.obs.data_ptr()), C.c_void_p(env.reward.data_ptr()),
-                                       C.c_void_p(env.done.data_ptr()), int(n_steps), int(bool(flush))), "auv_policy_rollout")
+                                       C.c_void_p(env.done.data_ptr()), int(n_steps), int(bool(flush)), t0, g0), "auv_policy_rollout")
+        n_launch = int(n_steps) + int(bool(flush))
+        for i in range(k):
+            self._t[i] = min(self._t[i] + n_launch, self.T + 1)
+            self._g[i] += n_launch
 
     def buffers(self):
         """(O, A, LP, V, R, Dn) of the whole batch, [T, N, ...] (written in place by the chains: no copy)."""

@@ -431,15 +431,25 @@ typedef struct auv_policy_io {
   int32_t ld, env_base;      /* environments per rollout row; the environment in column 0                   */
   float act_mid[2], act_half[2], clip_lo[2], clip_hi[2];   /* action = mid + half * clip(a, lo, hi)          */
   float reward_scale, reward_clip;                         /* reward_clip <= 0: no clipping                  */
+  const void* params_bf16;   /* NULL: exact f32 (the default).  Else the eight weight matrices as bf16 -- policy net W1 W2
+                                W3 W4, then the value net's, padded like the f32 ones, element [n][k] of a matrix at
+                                (((n / 16) * (K / 32) + k / 32) * 64 + ((k % 32) / 8) * 16 + n % 16) * 8 + k % 8 -- and the
+                                launch runs v_mfma_f32_16x16x32_bf16 (activations rounded to bf16 into the MFMA, f32
+                                accumulation / bias / tanh): ~1e-2 on the means, NOT the reference's arithmetic; biases and
+                                log_std still come from `params`.  16-byte aligned.                            */
 } auv_policy_io_t;
 size_t auv_policy_param_floats(int32_t obs_dim);
 int auv_policy_act(auv_handle_t* h, int32_t e0, int32_t ne, const auv_policy_io_t* io, void* stream);
 /* n_steps transitions of every slice with ONE call: per step and slice the policy launch and the environment's step of
  * that slice (actions = ios[i].actions_out), back to back on streams[i]; `flush` != 0: a final policy call per slice
- * stores the last step's reward / done.  The chains are not ordered against each other or the caller's stream. */
+ * stores the last step's reward / done.  t0 / gstep0 (host arrays, one entry per slice; both or neither): the rollout
+ * position and the generator's step counter of the FIRST launch of each slice -- the host then names them for every launch
+ * (position t0 + k, generator step gstep0 + k) and the launches skip their count-off on io.ctr (~4 us per launch; the
+ * device copies are still kept in step); NULL: the launches use and advance io.ctr like auv_policy_act.  The chains are
+ * not ordered against each other or the caller's stream.                                                           */
 int auv_policy_rollout(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams,
                        const auv_policy_io_t* ios, float* obs_dev, float* reward_dev, uint8_t* done_dev, int32_t n_steps,
-                       int32_t flush);
+                       int32_t flush, const int64_t* t0, const int64_t* gstep0);
 
 /* Generalised advantage estimation over a rollout of T steps x N environments (row-major [T][N] device buffers; V and
  * last_v in the same units as R): adv and ret = adv + V, one launch on `stream`.                                       */

@@ -147,3 +147,33 @@ def test_gae_kernel_matches_the_reference_recursion():
     assert float((adv - ref).abs().max()) <= 1e-5 * float(ref.abs().max())    # (f32, another association of the products)
     assert float((ret - (ref + V)).abs().max()) <= 1e-5 * float((ref + V).abs().max())
     env.close()
+
+
+def test_policy_bf16_option_matches_a_bf16_emulation():
+    """FusedActorCritic(bf16=True) -- optional, NOT the reference's arithmetic: weights stored as bf16, activations rounded to
+    bf16 on the way into v_mfma_f32_16x16x32_bf16, f32 accumulation / bias / tanh.  Against the same computation spelt out in
+    torch (2e-3: the summation order differs), and within 5e-2 of the exact f32 modules."""
+    import ppo
+    from gym_auv_amd.policy import FusedActorCritic
+    env, net, _ = _setup(512, 2, 4)
+    fused = FusedActorCritic(net, env, rollout=4, debug=True, bf16=True)
+    fused.begin_rollout()
+    obs = env.obs.clone()
+    for i in range(env.sub_batches):
+        fused.act(i)
+    torch.cuda.synchronize()
+
+    def emulate(seq, x):
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+        for j, l in enumerate(lin):
+            x = x.bfloat16().float() @ l.weight.bfloat16().float().t() + l.bias
+            if j < len(lin) - 1:
+                x = torch.tanh(x)
+        return x
+    with torch.no_grad():
+        mu_emu, v_emu = emulate(net.pi, obs), emulate(net.v, obs).squeeze(-1)
+        mu_f32, v_f32 = net.pi(obs), net.v(obs).squeeze(-1)
+    assert float((fused.mu - mu_emu).abs().max()) <= 2e-3
+    assert float((fused.V[0] - v_emu).abs().max()) <= 2e-3
+    assert float((fused.mu - mu_f32).abs().max()) <= 5e-2 and float((fused.V[0] - v_f32).abs().max()) <= 5e-2
+    env.close()

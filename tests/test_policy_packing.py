@@ -3,7 +3,7 @@ documents for auv_policy_io.params, and the sizes agree with the library's auv_p
 import torch
 
 from gym_auv_amd import _capi
-from gym_auv_amd.policy import HIDDEN, _pad16, pack_linear
+from gym_auv_amd.policy import HIDDEN, _pad16, pack_linear, pack_linear_bf16
 
 
 def test_fragment_order_matches_the_header_formula():
@@ -17,6 +17,20 @@ def test_fragment_order_matches_the_header_formula():
             for k in range(0, in_p, 3):
                 idx = ((((n // 16) * (K // 32) + k // 32) * 2 + (k % 8) // 4) * 64 + ((k % 32) // 8) * 16 + n % 16) * 4 + k % 4
                 want = float(w[n, k]) if (n < out_f and k < in_f) else 0.0
+                assert float(packed[idx]) == want, (n, k)
+
+
+def test_bf16_fragment_order_matches_the_header_formula():
+    torch.manual_seed(1)
+    for out_f, in_f, out_p, in_p in ((256, 186, 256, 192), (2, 64, 16, 64), (128, 256, 128, 256)):
+        w = torch.randn(out_f, in_f)
+        packed = pack_linear_bf16(w, out_p, in_p)
+        assert packed.dtype == torch.bfloat16 and packed.numel() == out_p * in_p
+        K = in_p
+        for n in range(0, out_p, 7):
+            for k in range(0, in_p, 5):
+                idx = (((n // 16) * (K // 32) + k // 32) * 64 + ((k % 32) // 8) * 16 + n % 16) * 8 + k % 8
+                want = float(w[n, k].bfloat16()) if (n < out_f and k < in_f) else 0.0
                 assert float(packed[idx]) == want, (n, k)
 
 

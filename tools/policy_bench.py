@@ -17,13 +17,14 @@ from gym_auv_amd.policy import FusedActorCritic  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = effective_reference_config(use_lidar=True)
+BF16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
 for k in (1, 2, 4):
     env = BatchedAuvEnv(cfg, GeneratedWorlds(2 * n, 17, 11, seed=1), n, device="cuda:0")
     env.reset()
     env.set_sub_batches(k)
     net = ppo.ActorCritic(env.obs_dim).to("cuda:0")
     T = 256
-    fused = FusedActorCritic(net, env, rollout=T, reward_scale=0.01)
+    fused = FusedActorCritic(net, env, rollout=T, reward_scale=0.01, bf16=BF16)
     # the policy launch alone, back to back on each chain's stream
     fused.begin_rollout()
     for _ in range(3):
