@@ -309,6 +309,18 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     HIP_TRY(hipMemset(d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
     if (((uintptr_t)d.k1_pkt & 63) != 0 || ((uintptr_t)d.nav_hand & 63) != 0) return fail(AUV_EHIP, "hand-over records are not 64-byte aligned");
   }
+  if (!h->rdv) {
+    // the words of the step_async / step_wait rendezvous (signal memory: what hipStreamWaitValue64 / WriteValue64 accept; an
+    // ordinary device allocation to the kernels) -- here, so that no step call ever allocates or synchronises
+    if (hipExtMallocWithFlags((void**)&h->rdv, AUV_RDV_BYTES, hipMallocSignalMemory) != hipSuccess) {
+      (void)hipGetLastError();
+      h->rdv = nullptr;
+      HIP_TRY(hipMalloc((void**)&h->rdv, AUV_RDV_BYTES));
+    }
+  }
+  HIP_TRY(hipMemset(h->rdv, 0, AUV_RDV_BYTES));
+  h->rdv_seq = h->rdv_target = 0;
+  h->async_pending = 0;
   d.w_ready = 0;
   auv_launch_derive(d, nullptr);
   std::vector<int32_t> wi(n);
@@ -483,7 +495,7 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->ev_actions = nullptr;
   h->rdv = nullptr;
   h->rdv_seq = h->rdv_target = 0;
-  h->rdv_limit_s = 30.0;
+  h->rdv_limit_s = 300.0;   // (a chain's gate waits for as long as the caller's stream is busy between two steps: minutes are legitimate)
   *out = h;
   return AUV_OK;
 }
@@ -887,16 +899,7 @@ int auv_step_async(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, voi
   for (int i = 0; i < n_slices; i++)
     if ((hipStream_t)streams[i] != cs) h->async_streams.push_back((hipStream_t)streams[i]);
   const size_t nr = h->async_streams.size();         // chains on streams of their own: the others are in stream order already
-  if (nr && rendezvous != AUV_RDV_EVENTS && !h->rdv) {
-    // (signal memory: what hipStreamWaitValue64 / WriteValue64 accept; an ordinary device allocation to the kernels)
-    if (hipExtMallocWithFlags((void**)&h->rdv, AUV_RDV_BYTES, hipMallocSignalMemory) != hipSuccess) {
-      (void)hipGetLastError();
-      h->rdv = nullptr;
-      HIP_TRY(hipMalloc((void**)&h->rdv, AUV_RDV_BYTES));
-    }
-    HIP_TRY(hipMemset(h->rdv, 0, AUV_RDV_BYTES));
-    HIP_TRY(hipDeviceSynchronize());
-  }
+  if (nr && rendezvous != AUV_RDV_EVENTS && !h->rdv) return fail(AUV_ESTATE, "auv_step_async: rendezvous words missing (no bank loaded?)");
   if (nr && rendezvous == AUV_RDV_EVENTS) {
     if (!h->ev_actions) HIP_TRY(hipEventCreateWithFlags(&h->ev_actions, hipEventDisableTiming));
     while (h->ev_chain.size() < nr) {

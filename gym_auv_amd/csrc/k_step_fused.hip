@@ -680,12 +680,16 @@ __global__ void k_rdv_arrive(unsigned long long* word) {
 __global__ void k_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, unsigned long long limit_ticks) {
   if (threadIdx.x != 0) return;
   const unsigned long long t0 = wall_clock64();                    // 100 MHz
+  int polls = 0;
   while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     if (wall_clock64() - t0 > limit_ticks) {
       __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
-    __builtin_amdgcn_s_sleep(2);
+    // eager for the first few microseconds (a step's rendezvous), then a poll per ~2 us: a chain's gate may sit here for as long
+    // as the caller's stream is busy with something else -- a PPO update between two rollouts -- and should not cost anything
+    if (++polls < 256) __builtin_amdgcn_s_sleep(2);
+    else __builtin_amdgcn_s_sleep(127);
   }
 }
 

@@ -191,7 +191,7 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
  *                   a one-wave kernel in front of each chain's launch polls for it (bounded), a one-wave kernel behind it counts
  *                   the chain off, ONE polling kernel on the caller's stream waits for all of them (csrc/k_step_fused.hip:
  *                   k_rdv_*).  Every waiter waits for something submitted before it; a wait that runs out
- *                   (auv_set_rendezvous_limit, default 30 s) is reported like a hand-over time-out (auv_health).
+ *                   (auv_set_rendezvous_limit, default 300 s) is reported like a hand-over time-out (auv_health).
  *                   Needs streams whose kernels really execute side by side (auv_streams_overlap): where dispatches are
  *                   serialised -- a counter-collecting profiler -- a polling kernel would sit in front of the kernel it
  *                   waits for until its limit; use AUV_RDV_EVENTS there (BatchedAuvEnv does for unprobed streams).

@@ -502,6 +502,43 @@ def test_step_async_rendezvous_closed_loop_bitwise(rendezvous, inline_first):
     assert asy.health()["timeouts"] == 0 and asy.health()["pending"] == 0
 
 
+def test_rendezvous_wait_that_runs_out_is_reported_once_and_nothing_hangs():
+    """AUV_RDV_DEVICE: a chain's polling kernel waits for the caller's stream to publish the actions.  With the limit set to
+    20 ms and the caller's stream kept busy for ~0.3 s in front of step_async, the polls run out: the launches still END, the
+    next call reports it once ("rendezvous"), no environment is reset, the in-launch hand-overs stay in use, and stepping goes
+    on -- bit for bit what a handle does that was never disturbed (the actions were resident all along)."""
+    n = 512
+    bank = _mixed_bank(16)
+    cfg = effective_reference_config(use_lidar=True)
+    ref, env = _env(cfg, bank, n), _env(cfg, bank, n)
+    ref.reset(), env.reset()
+    env.set_sub_batches(2)
+    assert env.rendezvous == "device"
+    env.set_rendezvous_limit(0.02)
+    a = torch.zeros((n, 2), device="cuda:0")
+    a[:, 0] = 0.8
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(6e8))                           # ~0.25 s of a one-thread kernel on the caller's stream: the publish
+    env.step_async(a)                                     # kernel sits behind it, the chains' polling kernels run out meanwhile
+    env.step_wait()
+    torch.cuda.synchronize()
+    ref.step(a)
+    assert env.health()["pending"] == 1
+    with pytest.raises(RuntimeError, match="rendezvous"):
+        env.step(a)
+    h = env.health()
+    assert h == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0), h
+    env.set_rendezvous_limit(10.0)
+    for _ in range(5):
+        o0, r0, d0, _ = ref.step(a)
+        env.step_async(a)
+        o1, r1, d1, _ = env.step_wait()
+        torch.cuda.synchronize()
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1)
+    for f in ("STATE", "COUNTERS", "OBS64"):
+        assert torch.equal(ref.read(f), env.read(f)), f
+
+
 @pytest.mark.parametrize("kind", ["cpu", "f16", "strided", "int"])
 def test_step_async_converts_actions_before_ordering(kind):
     """actions that need a conversion (host tensor, half precision, non-contiguous view, integers) are converted
