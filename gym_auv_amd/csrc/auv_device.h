@@ -268,14 +268,41 @@ __device__ __forceinline__ void auv_wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// wave64 reductions through DPP/permute shuffles
-__device__ __forceinline__ double auv_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, AUV_WAVE);
+// wave64 reductions.  Inside a row of 16 lanes the partner comes by DPP (a VALU move, no trip through the LDS
+// crossbar: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- each pairs lanes that hold different
+// partial results, and a + b == b + a bit for bit, so all 16 lanes end with the same value); the four row results are
+// read into scalar registers and combined in one fixed order, so every lane returns the same bits.
+template <int CTRL> __device__ __forceinline__ double auv_dpp_f64(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double auv_readlane_f64(const double v, const int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// inclusive prefix sum over the wave's 64 lanes, all by DPP: four shifted adds inside each row of 16, then the last lane
+// of row 0 / 2 onto rows 1 / 3 (row_bcast:15) and lane 31 onto rows 2 and 3 (row_bcast:31).  Integer adds: any order.
+__device__ __forceinline__ int auv_wave_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1 (lanes shifted in from outside the row: 0)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
   return v;
 }
+__device__ __forceinline__ int auv_wave_last(const int v) { return __builtin_amdgcn_readlane(v, AUV_WAVE - 1); }
+__device__ __forceinline__ double auv_wave_sum(double v) {
+  v += auv_dpp_f64<0xB1>(v);
+  v += auv_dpp_f64<0x4E>(v);
+  v += auv_dpp_f64<0x141>(v);
+  v += auv_dpp_f64<0x140>(v);
+  return (auv_readlane_f64(v, 0) + auv_readlane_f64(v, 16)) + (auv_readlane_f64(v, 32) + auv_readlane_f64(v, 48));
+}
 __device__ __forceinline__ double auv_wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, AUV_WAVE));
-  return v;
+  v = fmin(v, auv_dpp_f64<0xB1>(v));
+  v = fmin(v, auv_dpp_f64<0x4E>(v));
+  v = fmin(v, auv_dpp_f64<0x141>(v));
+  v = fmin(v, auv_dpp_f64<0x140>(v));
+  return fmin(fmin(auv_readlane_f64(v, 0), auv_readlane_f64(v, 16)), fmin(auv_readlane_f64(v, 32), auv_readlane_f64(v, 48)));
 }

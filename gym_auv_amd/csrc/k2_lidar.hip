@@ -336,7 +336,7 @@ __device__ __forceinline__ K2Pre k2_prefetch(const AuvDev& d, const int e, const
 template <bool WT = false>
 __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
                         const EnvPre* pre = nullptr, const int movers_done = 0,
-                        const K2Pre* kp = nullptr, const bool beams_staged = false) {
+                        const K2Pre* kp = nullptr, const bool beams_staged = false, int2* lim_defer = nullptr) {
   const int S = d.cfg.n_sensors;
   const size_t n = (size_t)d.n;
   const int4 cnt = pre ? pre->cnt : d.counters[e];
@@ -411,13 +411,8 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
       const unsigned long long und = __ballot(state == 2);
       if (und) {
         const int nu = __popcll(und), pos = __popcll(und & ((1ull << lane) - 1ull));
-        int incl = (state == 2) ? meta.z : 0;
-#pragma unroll
-        for (int o = 1; o < AUV_WAVE; o <<= 1) {
-          const int t = __shfl_up(incl, o, AUV_WAVE);
-          if (lane >= o) incl += t;
-        }
-        const int total = __shfl(incl, AUV_WAVE - 1, AUV_WAVE);
+        const int incl = auv_wave_scan_incl((state == 2) ? meta.z : 0);
+        const int total = auv_wave_last(incl);
         if (state == 2) {
           ObsLds o;
           o.kind = meta.x, o.seg_off = (meta.x == AUV_OBS_MOVER) ? meta.w : meta.y, o.nseg = meta.z;
@@ -582,14 +577,18 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
           active = true;
         }
       }
-      auv_st<WT>(&d.limits[(size_t)e * d.k_max + k], lim);
+      // (lim_defer: the first 64 obstacles' rows are stored by k2_back -- a wait for a load, here the boundary segments of
+      // the staging pass, also waits for every store issued before it, and a write-through store takes ~0.7 us)
+      if (lim_defer && kb == 0) *lim_defer = lim;
+      else auv_st<WT>(&d.limits[(size_t)e * d.k_max + k], lim);
       L.obs[k] = o;
     }
     const unsigned long long mask = __ballot(active);
     if (active) L.act[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = k;
     n_act += __popcll(mask);
   }
-  for (int k = K + lane; k < d.k_max; k += AUV_WAVE) auv_st<WT>(&d.limits[(size_t)e * d.k_max + k], make_int2(INT32_MIN, INT32_MIN));
+  for (int k = ((lim_defer && K < AUV_WAVE) ? AUV_WAVE : K) + lane; k < d.k_max; k += AUV_WAVE)
+    auv_st<WT>(&d.limits[(size_t)e * d.k_max + k], make_int2(INT32_MIN, INT32_MIN));
   if (lane == 0) L.hdr->n_act = n_act;
   auv_wave_lds_sync();
   // prefix of boundary-segment counts over the active list (wave scan, 64 entries per pass);
@@ -598,17 +597,12 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
     int carry = 0;
     for (int ab = 0; ab < n_act; ab += AUV_WAVE) {
       const int a = ab + lane;
-      int v = (a < n_act) ? L.obs[L.act[a]].nseg : 0;
-#pragma unroll
-      for (int o = 1; o < AUV_WAVE; o <<= 1) {
-        int t = __shfl_up(v, o, AUV_WAVE);
-        if (lane >= o) v += t;
-      }
+      const int v = auv_wave_scan_incl((a < n_act) ? L.obs[L.act[a]].nseg : 0);
       if (a < n_act) {
         L.sbase[a + 1] = carry + v;
         L.par[a] = 0;
       }
-      carry += __shfl(v, AUV_WAVE - 1, AUV_WAVE);
+      carry += auv_wave_last(v);
     }
     if (lane == 0) L.sbase[0] = 0;
   }
@@ -660,8 +654,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
     double4 s_nx = make_double4(0.0, 0.0, 0.0, 0.0);
     auto fetch = [&](int tb_f) {
       const int t = tb_f + lane;
-      a_nx = a0;
-      if (t < T_raw) {
+      if (t < T_raw) {                                     // (a lane's t only grows from pass to pass: the walk carries on)
         while (t + base0 >= L.sbase[a_nx + 1]) a_nx++;
         o_nx = L.obs[L.act[a_nx]];
         const int si = t + base0 - L.sbase[a_nx];
@@ -778,14 +771,9 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
         const ObsLds o = L.obs[L.act[a]];
         if (!((o.kind & K2_PIP_FLAG) && L.par[a] != 0)) v = (L.span[t].y + K2_ITEM_RAYS - 1) / K2_ITEM_RAYS;
       }
-      int incl = v;
-#pragma unroll
-      for (int o = 1; o < AUV_WAVE; o <<= 1) {
-        int x = __shfl_up(incl, o, AUV_WAVE);
-        if (lane >= o) incl += x;
-      }
+      const int incl = auv_wave_scan_incl(v);
       if (t < T) L.ioff[t + 1] = (unsigned short)(n_items + incl);
-      n_items += __shfl(incl, AUV_WAVE - 1, AUV_WAVE);
+      n_items += auv_wave_last(incl);
     }
     if (lane == 0) L.ioff[0] = 0;
     auv_wave_lds_sync();
@@ -795,10 +783,22 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 #endif
     if (!AUV_RUN_L(d, 5)) n_items = 0;
     for (int it = lane; it < n_items; it += AUV_WAVE) {
-      int lo = 0, hi = T;                                  // largest t with ioff[t] <= it
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if ((int)L.ioff[mid] <= it) lo = mid; else hi = mid;
+      // largest t < T with ioff[t] <= it (the prefix is non-decreasing), in three rounds of INDEPENDENT LDS reads --
+      // strides 16, 4, 1 -- instead of the seven dependent ones of a bisection: three trips to LDS per pass, not seven
+      int lo = 0;
+      {
+        int c = 0;
+#pragma unroll
+        for (int k = 16; k < K2_SEG_CAP; k += 16) c += (k < T && (int)L.ioff[k] <= it) ? 1 : 0;
+        lo = 16 * c;
+        c = 0;
+#pragma unroll
+        for (int k = 4; k < 16; k += 4) c += (lo + k < T && (int)L.ioff[lo + k] <= it) ? 1 : 0;
+        lo += 4 * c;
+        c = 0;
+#pragma unroll
+        for (int k = 1; k < 4; k++) c += (lo + k < T && (int)L.ioff[lo + k] <= it) ? 1 : 0;
+        lo += c;
       }
       const int t = lo;
       const int a = L.owner[t];
@@ -850,10 +850,15 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 // indices of the beams WITH a return into LDS (ballot + popcount); the square root / log / exp are then
 // evaluated over that dense list only (typically one pass of 64 instead of S / 64).
 // n_act == 0 (no obstacle had a ray to test): the whole row is free, nothing was swept.
-#define K2_HIT_CAP (K2_SEG_CAP * 8)    // ints that fit the (by now idle) segment stage
+// Global loads and write-through stores of a wave count down ONE counter in issue order: a wait for a load also waits for
+// every store issued before it (~0.7 us for a write-through one).  So everything this phase reads from memory -- the beam
+// weights, the per-config constants -- is requested before its first store, the returns take their weights along through
+// LDS, and the cull-limit rows of phase B (`lim0`: this lane's row of the first 64 obstacles) are stored here, not there.
+#define K2_HIT_S 256                   // beams whose (index, weight) list fits the (by now idle) segment stage: 12 B each
+static_assert(K2_HIT_S * 12 <= K2_SEG_CAP * 32, "the returns' list lives in the segment stage");
 template <bool WT = false>
 __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, const int n_act,
-                       float* __restrict__ obs_out = nullptr, double* rew_lidar_out = nullptr) {
+                       float* __restrict__ obs_out = nullptr, double* rew_lidar_out = nullptr, const int2* lim0 = nullptr) {
   const int S = d.cfg.n_sensors;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
   const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
@@ -862,11 +867,12 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
   double* ob = d.obs64 + (size_t)e * (6 + S) + 6;
   float* oo = obs_out ? obs_out + (size_t)e * D + 6 : nullptr;
   if (n_act == 0) {
+    const double term = colav ? d.derived[3] : 0.0;
+    if (lim0 && lane < d.k_max) auv_st<WT>(&d.limits[(size_t)e * d.k_max + lane], *lim0);
     for (int i = lane; i < S; i += AUV_WAVE) {
       auv_st<WT>(dd + i, R), auv_st<WT>(ob + i, 0.0);
       if (oo) auv_st<WT>(oo + i, 0.0f);
     }
-    const double term = colav ? d.derived[3] : 0.0;
     if (lane == 0) {
       auv_st<WT>(d.collision + e, (uint8_t)0);
       if (colav) auv_st<WT>(d.rew_lidar + e, term);
@@ -876,24 +882,53 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
   }
   const double logR = d.derived[0];                        // log(1 + R)
   const double raw_free = d.derived[1];                    // R exp(-0.1 R)
+  const double wsum = colav ? d.derived[2] : 1.0;          // sum of the beam weights
   const double px = L.hdr->px, py = L.hdr->py;
-  int* hits = (int*)L.stage;
   int col = 0;
   double num = 0.0;
-  if (S <= K2_HIT_CAP) {
-    // ---- free beams + compaction of the returns ----
+  if (S <= K2_HIT_S) {
+    int* hits = (int*)L.stage;
+    double* hitw = (double*)(hits + K2_HIT_S);
+    constexpr int NQ = K2_HIT_S / AUV_WAVE;
+    double bw[NQ];                                         // gamma_theta from the per-config table
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int i = q * AUV_WAVE + lane;
+      bw[q] = (colav && i < S) ? d.beam_w[i] : 0.0;
+    }
+    // ---- which beams have a return; their indices compacted into LDS (no store yet) ----
+    unsigned long long hm[NQ];
     int n_hit = 0;
-    for (int i0 = 0; i0 < S; i0 += AUV_WAVE) {
-      const int i = i0 + lane;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      hm[q] = 0;
+      if (q * AUV_WAVE >= S) continue;                     // (uniform)
+      const int i = q * AUV_WAVE + lane;
       const bool hit = (i < S) && (u2d(L.dbits[i]) <= 1.0);
-      if (i < S && !hit) {
-        auv_st<WT>(dd + i, R), auv_st<WT>(ob + i, 0.0);    // sensor.py:156; closeness 1 - clip(x / x) = 0
-        if (oo) auv_st<WT>(oo + i, 0.0f);
-        if (colav) num += d.beam_w[i] * raw_free;          // gamma_theta from the per-config table
+      hm[q] = __ballot(hit);
+      if (hit) hits[n_hit + __popcll(hm[q] & ((1ull << lane) - 1ull))] = i;
+      n_hit += __popcll(hm[q]);
+    }
+    // the weights are here before the first store goes out: no later wait in this phase has a load behind stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) -- as the builtin, so that the compiler knows too
+    asm volatile("" ::: "memory");
+    if (lim0 && lane < d.k_max) auv_st<WT>(&d.limits[(size_t)e * d.k_max + lane], *lim0);
+    // ---- free beams: constants; the returns' weights go to LDS beside their indices ----
+    {
+      int base = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        if (q * AUV_WAVE >= S) continue;
+        const int i = q * AUV_WAVE + lane;
+        const bool hit = (hm[q] >> lane) & 1ull;
+        if (i < S && !hit) {
+          auv_st<WT>(dd + i, R), auv_st<WT>(ob + i, 0.0);  // sensor.py:156; closeness 1 - clip(x / x) = 0
+          if (oo) auv_st<WT>(oo + i, 0.0f);
+          if (colav) num += bw[q] * raw_free;
+        }
+        if (hit) hitw[base + __popcll(hm[q] & ((1ull << lane) - 1ull))] = bw[q];
+        base += __popcll(hm[q]);
       }
-      const unsigned long long m = __ballot(hit);
-      if (hit) hits[n_hit + __popcll(m & ((1ull << lane) - 1ull))] = i;
-      n_hit += __popcll(m);
     }
     auv_wave_lds_sync();
     if (!AUV_RUN_L(d, 6)) n_hit = 0;
@@ -902,6 +937,7 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
       const int h = h0 + lane;
       if (h < n_hit) {
         const int i = hits[h];
+        const double wgt = hitw[h];
         const double t = u2d(L.dbits[i]);
         // intersection point, then Point.distance: exactly the reference's arithmetic
         const double2 r = L.rayv[i];
@@ -913,12 +949,13 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
         cl = auv_clip(cl, -1.0, 1.0);
         auv_st<WT>(ob + i, cl);
         if (oo) auv_st<WT>(oo + i, (float)cl);
-        if (colav) num += d.beam_w[i] * ((di != R) ? R * exp(-0.1 * di) : raw_free);   // gamma_x
+        if (colav) num += wgt * ((di != R) ? R * exp(-0.1 * di) : raw_free);   // gamma_x
         col |= (di < W);
       }
     }
   } else {
-    // (more beams than the hit list holds: every pass does everything)
+    // (more beams than the list holds: every pass does everything)
+    if (lim0 && lane < d.k_max) auv_st<WT>(&d.limits[(size_t)e * d.k_max + lane], *lim0);
     for (int i = lane; i < S; i += AUV_WAVE) {
       const double t = u2d(L.dbits[i]);
       double di = R;
@@ -940,7 +977,7 @@ __device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice
   }
   col = __any(col);
   if (colav) num = auv_wave_sum(num);
-  const double term = (colav && S > 0) ? -num / d.derived[2] : 0.0;   // the same in every lane
+  const double term = (colav && S > 0) ? -num / wsum : 0.0;   // the same in every lane
   if (lane == 0) {
     auv_st<WT>(d.collision + e, (uint8_t)(col != 0));
     if (colav) auv_st<WT>(d.rew_lidar + e, term);

@@ -526,7 +526,8 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     if (lane == 0) d.stamps[(size_t)e * 16 + 2] = wall_clock64();
 #endif
     int n_act = 0;
-    if (AUV_RUN_L(d, 1)) n_act = k2_front<true>(d, e, lane, L, 1, &pre, 1, &kp, true);
+    int2 lim0 = make_int2(INT32_MIN, INT32_MIN);           // this lane's cull-limit row: stored by k2_back (see there)
+    if (AUV_RUN_L(d, 1)) n_act = k2_front<true>(d, e, lane, L, 1, &pre, 1, &kp, true, &lim0);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 8] = wall_clock64();      // front (B0, B, C) done
 #endif
@@ -535,7 +536,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     if (lane == 0) d.stamps[(size_t)e * 16 + 11] = wall_clock64();     // staging + pair sweep (S, D) done
 #endif
     double term = 0.0;
-    const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term);
+    const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term, &lim0);
 #ifdef AUV_STAMPS
     if (lane == 0) d.stamps[(size_t)e * 16 + 4] = wall_clock64();
 #endif
