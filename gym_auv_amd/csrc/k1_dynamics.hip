@@ -174,6 +174,18 @@ __device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const voi
 // components.  Returns component c of the new state (lanes c >= 6: unspecified).  Lanes whose group
 // is idle (`e` clamped by the caller) compute along.
 #define K1_GROUP 8
+// component K (2..5) of the caller's group of eight lanes in every lane of the group, by two DPP moves per register half
+// instead of a trip through the LDS crossbar: the quad's own lane K % 4 (quad_perm), then the quad that does not hold
+// component K takes the other quad's copy (row_shr:4 into banks 1, 3 / row_shl:4 into banks 0, 2).  All 64 lanes are active.
+template <int K> __device__ __forceinline__ int k1_group_bcast32(const int x) {
+  static_assert(K >= 0 && K < 8, "lane of the group");
+  constexpr int q = K % 4, qp = q | (q << 2) | (q << 4) | (q << 6);
+  const int a = __builtin_amdgcn_update_dpp(0, x, qp, 0xF, 0xF, true);
+  return K < 4 ? __builtin_amdgcn_update_dpp(a, a, 0x114, 0xF, 0xA, false) : __builtin_amdgcn_update_dpp(a, a, 0x104, 0xF, 0x5, false);
+}
+template <int K> __device__ __forceinline__ double k1_group_bcast(const double t) {
+  return __hiloint2double(k1_group_bcast32<K>(__double2hiint(t)), k1_group_bcast32<K>(__double2loint(t)));
+}
 __device__ __forceinline__ double k1_group(const AuvDev& d, const void* __restrict__ actions, const int e, const int lane) {
   const int c = lane % K1_GROUP, gbase = lane - c;
   const size_t n = (size_t)d.n;
@@ -185,13 +197,14 @@ __device__ __forceinline__ double k1_group(const AuvDev& d, const void* __restri
   const double tr = auv_clip(a1, -1.0, 1.0) * d.cfg.moment_max;
   const double h = d.cfg.dt;
   const double y = d.state[(size_t)(own ? c : 0) * n + e];
-  const Heading0 h0 = heading0(__shfl(y, gbase + 2, AUV_WAVE));
+  (void)gbase;
+  const Heading0 h0 = heading0(k1_group_bcast<2>(y));
   // _state_dot of the stage vector whose component c this lane holds in `t`; returns component c
   auto sdot = [&](double t) {
     Vec6 v;
     v.v[0] = 0.0, v.v[1] = 0.0;                              // x, y do not enter _state_dot
-    v.v[2] = __shfl(t, gbase + 2, AUV_WAVE), v.v[3] = __shfl(t, gbase + 3, AUV_WAVE);
-    v.v[4] = __shfl(t, gbase + 4, AUV_WAVE), v.v[5] = __shfl(t, gbase + 5, AUV_WAVE);
+    v.v[2] = k1_group_bcast<2>(t), v.v[3] = k1_group_bcast<3>(t);
+    v.v[4] = k1_group_bcast<4>(t), v.v[5] = k1_group_bcast<5>(t);
     const Vec6 o = state_dot(v, tu, tr, h0);
     double r = o.v[0];
 #pragma unroll

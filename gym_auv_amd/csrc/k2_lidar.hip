@@ -809,18 +809,28 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
       const bool all = o.count >= S;
       const int start_w = wrap_ray(o.start, S);
       const int j0 = (it - (int)L.ioff[t]) * K2_ITEM_RAYS;
-      // the item's rays are fetched together (independent LDS loads), then tested
+      // the item's rays are fetched together (independent LDS loads), then tested.  Ray index and position inside the
+      // obstacle's window are wrapped ONCE per item; from ray to ray both go up by one and wrap at most once (the index
+      // arithmetic of eight rays used to be 2.4x their fp64 arithmetic)
       double2 rv[K2_ITEM_RAYS];
       int rr[K2_ITEM_RAYS];
+      const int r0 = wrap_ray(sp.x + j0, S);
+      int x0 = r0 - start_w;                                  // position of the item's first ray inside the window
+      if (x0 < 0) x0 += S;
+      int n_left = (int)sp.y - j0;                            // rays of the span from this item's first on
+      int r0m = r0 - S, x0m = x0 - S;                         // (index - S: "wrapped" is then the sign)
+      // (opaque to the optimiser, which otherwise re-derives every ray's index from the five values above: six dependent
+      // subtractions per ray instead of one add)
+      asm volatile("" : "+v"(r0m), "+v"(x0m), "+v"(n_left));
 #pragma unroll
       for (int jj = 0; jj < K2_ITEM_RAYS; jj++) {
-        int r = wrap_ray(sp.x + j0 + jj, S);
-        int x = r - start_w;                                  // position of ray r inside the window
-        if (x < 0) x += S;
-        const bool ok = (j0 + jj < sp.y) && (all || x < o.count);
+        int r = r0m + jj, x = x0m + jj;                       // in [-S, 8): negative = not wrapped yet
+        r = r < 0 ? r + S : r;
+        x = x < 0 ? x + S : x;
+        const bool ok = (jj < n_left) && (all || x < o.count);
         r = ok ? r : -1;
         rr[jj] = r;
-        rv[jj] = L.rayv[r < 0 ? 0 : r];
+        rv[jj] = L.rayv[ok ? r : 0];
       }
       if (tn != 0.0) {
         const double sg = tn < 0.0 ? -1.0 : 1.0, ta = fabs(tn);

@@ -532,11 +532,12 @@ __device__ __forceinline__ NavNear nav_nearest(const AuvDev& d, const int e, con
     wmask = __ballot(best.d == dmin && best.j == jm);
   }
   // the winning lane hands over its segment (no second trip to memory)
-  const int src = wmask ? __ffsll((long long)wmask) - 1 : 0;
+  // (the lane's number is wave-uniform: scalar reads of its registers, no trip through the LDS crossbar)
+  const int src = auv_uniform(wmask ? __ffsll((long long)wmask) - 1 : 0);
   NavNear nr;
-  nr.A.x = __shfl(bA.x, src, AUV_WAVE), nr.A.y = __shfl(bA.y, src, AUV_WAVE);
-  nr.B.x = __shfl(bB.x, src, AUV_WAVE), nr.B.y = __shfl(bB.y, src, AUV_WAVE);
-  nr.cum = __shfl(my_cum, src, AUV_WAVE);
+  nr.A.x = auv_readlane_f64(bA.x, src), nr.A.y = auv_readlane_f64(bA.y, src);
+  nr.B.x = auv_readlane_f64(bB.x, src), nr.B.y = auv_readlane_f64(bB.y, src);
+  nr.cum = auv_readlane_f64(my_cum, src);
   return nr;
 }
 
