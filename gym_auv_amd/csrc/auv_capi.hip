@@ -277,7 +277,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     rc |= dev_upload(ep, &d.beam_cs, bcs.data(), S ? S : 1);
   }
   rc |= dev_alloc(ep, &d.beam_w, S ? S : 1);
-  rc |= dev_alloc(ep, &d.derived, 4);
+  rc |= dev_alloc(ep, &d.derived, 8);
   rc |= dev_alloc(ep, &d.w_obs64, (size_t)W * (6 + S));
   rc |= dev_alloc(ep, &d.w_lidar, (size_t)W * S);
   rc |= dev_alloc(ep, &d.w_info, (size_t)W * 8);

@@ -112,7 +112,7 @@ struct AuvDev {
   double* rew_lidar;    // [N] LiDAR term of the Colav reward, left by K2
   const double2* beam_cs; // [S] cos, sin of the body-frame beam angles -pi + (i + 1) 2 pi / S (vessel.py:66-68)
   double* beam_w;         // [S] gamma_theta weight of each beam, 1 / (1 + |10 angle|) (rewarder.py:205-222)
-  double* derived;        // [4] per-config constants formed once on the device: log(1 + R), R exp(-0.1 R),
+  double* derived;        // [8] per-config constants formed once on the device: log(1 + R), R exp(-0.1 R),
                           //     sum of beam_w (in the wave-reduction order), -
   int32_t* ring_pos;    // [1]  current slot of the action ring (advanced once per step by K3)
   int32_t ring_slots;   // 1 = plain action buffer

@@ -173,10 +173,11 @@ __device__ __forceinline__ void test_pair(const double4 w, const double tn, cons
 // >= 0, i.e. den of the sign of tn, so the flip is decided once per item (sg = -1 for tn < 0: exact) and
 // a ray whose den has the other sign fails `dn > 0`.  tn == 0 (p0 on the segment's line: t = 0 for any
 // non-parallel ray) has no preferred sign and takes the general form above.
-__device__ __forceinline__ void test_pair_signed(const double4 w, const double tn, const double ta, const double sg,
-                                                 const double2 r, unsigned long long* slot) {
-  const double dn = sg * (r.x * w.w - r.y * w.z);
-  const double u1 = sg * (w.x * r.y - w.y * r.x);
+// `ws` = sg * w, formed once per item: sg (r.x w.w - r.y w.z) == r.x (sg w.w) - r.y (sg w.z) bit for bit (negation commutes
+// with every rounding), so the two multiplications by sg per ray are gone.
+__device__ __forceinline__ void test_pair_signed(const double4 ws, const double ta, const double2 r, unsigned long long* slot) {
+  const double dn = r.x * ws.w - r.y * ws.z;
+  const double u1 = ws.x * r.y - ws.y * r.x;
   const bool hit = (dn > 0.0) & (ta <= dn) & (u1 >= 0.0) & (u1 <= dn);
   if (hit) atomicMin(slot, d2u(ta / dn));                  // = tn / den: both signs flipped, exact
 }
@@ -354,7 +355,9 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
   const long long k0 = ed.k0;
   const int K = ed.K;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;
-  const double dangle = 2 * AUV_PI / S, inv_dangle = (double)S / (2 * AUV_PI);
+  // 2 pi / S and S / (2 pi): per-config constants (k_derive forms them with these very divisions), two scalar loads
+  // instead of two fp64 divisions (~32 instructions) per wave
+  const double dangle = d.derived[4], inv_dangle = d.derived[5];
   if (lane == 0) {
     L.hdr->px = px, L.hdr->py = py;
     L.hdr->n_act = 0;
@@ -532,16 +535,18 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
           bool exact = true;
           {
             const float rxf = (float)relx, ryf = (float)rely;
-            const float df = sqrtf(rxf * rxf + ryf * ryf);
-            const float qf = (float)rho / df;
+            // (hardware square root / reciprocal / reciprocal square root, ~1 ulp each, instead of the correctly rounded
+            // library forms: ~50 instructions fewer; their error is inside the budget below)
+            const float df = __builtin_amdgcn_sqrtf(rxf * rxf + ryf * ryf);
+            const float qf = (float)rho * __builtin_amdgcn_rcpf(df);
             const bool outside = qf < 0.999f, inside = qf > 1.001f;       // (NaN / inf: neither)
             if ((outside || inside) && df > 1e-3f) {
               const float th = atan2f(ryf, rxf);
               double f64 = AUV_PI, err = 3.0e-6;
               if (outside) {
-                const float amp = 1.0f / sqrtf(1.0f - qf * qf);
+                const float amp = __builtin_amdgcn_rsqf(1.0f - qf * qf);
                 f64 = (double)asinf(qf);
-                err += 1.0e-6 + 6.0e-7 * (double)amp;
+                err += 1.0e-6 + 1.2e-6 * (double)amp;
               }
               const double b64 = (double)th - psi;
               // (a product with 1 / dangle instead of two fp64 divisions: the screen only accepts quotients that stay
@@ -833,10 +838,11 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
         rv[jj] = L.rayv[ok ? r : 0];
       }
       if (tn != 0.0) {
-        const double sg = tn < 0.0 ? -1.0 : 1.0, ta = fabs(tn);
+        const double ta = fabs(tn);
+        const double4 ws = tn < 0.0 ? make_double4(-w.x, -w.y, -w.z, -w.w) : w;
 #pragma unroll
         for (int jj = 0; jj < K2_ITEM_RAYS; jj++)
-          if (rr[jj] >= 0) test_pair_signed(w, tn, ta, sg, rv[jj], &L.dbits[rr[jj]]);
+          if (rr[jj] >= 0) test_pair_signed(ws, ta, rv[jj], &L.dbits[rr[jj]]);
       } else {
 #pragma unroll
         for (int jj = 0; jj < K2_ITEM_RAYS; jj++)

@@ -213,6 +213,8 @@ __global__ void k_derive(AuvDev d) {
   num_free = auv_wave_sum(num_free);
   // [3]: the LiDAR term of the Colav reward when no beam has a return
   if (lane == 0) d.derived[0] = log(1 + R), d.derived[1] = raw_free, d.derived[2] = den, d.derived[3] = (S > 0) ? -num_free / den : 0.0;
+  // [4], [5]: the beam spacing and its reciprocal, as the cull windows use them (k2_front)
+  if (lane == 0) d.derived[4] = 2 * AUV_PI / S, d.derived[5] = (double)S / (2 * AUV_PI);
 }
 #endif
 

@@ -14,7 +14,7 @@ from gym_auv_amd.config import effective_reference_config
 
 cfg = effective_reference_config(use_lidar=True)
 n = 4096
-z = np.load(os.environ.get("BANK", "/tmp/bank.polygons50.0.4096.4096.2.npz"))
+z = np.load(os.environ.get("BANK") or sorted(__import__("glob").glob("/tmp/bank.polygons50.0.4096.4096.2*.npz"))[0])   # (bench.py --bank-cache /tmp/bank: name carries a source hash)
 bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
 env = BatchedAuvEnv(cfg, bank, n, auto_reset=True)
 env.set_step_mode("one_launch")

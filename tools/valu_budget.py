@@ -48,7 +48,7 @@ def main():
     cfg = effective_reference_config(use_lidar=True)
     cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
     n = 4096
-    z = np.load(os.environ.get("BANK", "/tmp/bank.%s.0.4096.4096.2.npz" % workload))
+    z = np.load(os.environ.get("BANK") or sorted(__import__("glob").glob("/tmp/bank.%s.0.4096.4096.2*.npz" % workload))[0])
     bank = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
     dev = torch.device("cuda:0")
     env = BatchedAuvEnv(cfg, bank, n, device=dev, auto_reset=True)
