@@ -365,7 +365,8 @@ __device__ __forceinline__ NavSpec nav_bounds(const AuvDev& d, const int e, cons
     // segments are requested together with the chunk circles: the exact distance to them bounds the
     // distance to the path within centimetres, without a second trip to memory
     {
-      int jh = (int)(prog.x / sp.L * (double)(P - 1));
+      // (only a hint -- whichever chunk it names, the survivors and the minimum are the same: a hardware reciprocal will do)
+      int jh = (int)(prog.x * __builtin_amdgcn_rcp(sp.L) * (double)(P - 1));
       jh = jh < 0 ? 0 : (jh > P - 2 ? P - 2 : jh);
       cstar = jh / AUV_CHUNK;
     }
