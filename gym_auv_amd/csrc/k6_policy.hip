@@ -118,14 +118,20 @@ struct PolW {
   static constexpr int BLK = BF ? 256 : 512;                         // floats (4-byte units) per (n-tile, k-step) block
   float4 q[POL_DEPTH][NT][BF ? 1 : 2];
   const float* row[NT];
+  float bias[NT];                    // the epilogue's bias of this lane's column of each n-tile, requested with the weights
 };
 
 // Request the first DEPTH k-steps of a layer's weights.  They depend on nothing the kernel computes, so the request for
 // layer l + 1 goes out BEFORE layer l's epilogue and the barrier behind it (and layer 1's before the observation tile is
 // fetched): a layer then starts on fragments that have landed instead of on a cold trip to L2.
 template <int NTILES, bool BF>
-__device__ __forceinline__ void pol_prefetch(PolW<NTILES, BF>& w, const float* __restrict__ W, const int Kp, const int wave, const int lane) {
+__device__ __forceinline__ void pol_prefetch(PolW<NTILES, BF>& w, const float* __restrict__ W, const float* __restrict__ b,
+                                             const int Kp, const int wave, const int lane) {
   if (wave >= NTILES) return;
+  // (the biases too: asked for in a layer's epilogue they cost it a trip to L2 with nothing else to do; asked for here,
+  // ahead of the barrier in front of the layer, they cannot be moved back down to their use)
+#pragma unroll
+  for (int t = 0; t < PolW<NTILES, BF>::NT; t++) w.bias[t] = b[((wave + POL_WAVES * t) % NTILES) * 16 + (lane & 15)];
   const int nJ = Kp / 32;
   constexpr int BLK = PolW<NTILES, BF>::BLK;
 #pragma unroll
@@ -214,7 +220,7 @@ __device__ __forceinline__ void pol_layer(const float* __restrict__ X, const int
   for (int t = 0; t < NT; t++) {
     if (wave + POL_WAVES * t >= NTILES) break;
     const int n = (wave + POL_WAVES * t) * 16 + m;           // D: column on the lane (lane & 15), rows 4 g + i in the registers
-    const float bias = b[n];
+    const float bias = w.bias[t];
 #pragma unroll
     for (int u = 0; u < POL_MT; u++) {
       f32x4 c = acc[u][t][0];
@@ -253,13 +259,12 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
   const size_t ld = (size_t)io.ld;                               // environments per rollout row
   const int col0 = pa.e0 - io.env_base + r0;                     // the tile's first column in a rollout row
   // ---- the transition the environment's last step completed: reward and done of step t - 1 ----
-  if (net == 0 && t >= 1 && t <= T && tid < POL_ROWS && r0 + tid < cnt) {
-    const int e = pa.e0 + r0 + tid;
-    float r = io.reward_in[e];
-    if (io.reward_clip > 0.0f) r = fminf(fmaxf(r, -io.reward_clip), io.reward_clip);
-    io.R[(size_t)(t - 1) * ld + col0 + tid] = r * io.reward_scale;
-    io.Dn[(size_t)(t - 1) * ld + col0 + tid] = io.done_in[e] ? 1.0f : 0.0f;
-  }
+  // (requested here, stored at the end: load - store - load - store at the head of the kernel were two trips to memory in
+  // front of everything wave 0 does, and wave 0 is the one that samples)
+  const bool trans = net == 0 && t >= 1 && t <= T && tid < POL_ROWS && r0 + tid < cnt;
+  float trans_r = 0.0f;
+  uint8_t trans_d = 0;
+  if (trans) trans_r = io.reward_in[pa.e0 + r0 + tid], trans_d = io.done_in[pa.e0 + r0 + tid];
   const bool act = t < T;                                        // t == T: the flush call after a rollout's last step
   if (act) {
     const float* P = io.params + (size_t)net * pol_net_floats(K0);
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
     PolW<POL_H2 / 16, BF> w2;
     PolW<POL_H3 / 16, BF> w3;
     PolW<1, BF> w4;
-    pol_prefetch(w1, W1, K0p, wave, lane);                       // (in flight while the observation tile is fetched)
+    pol_prefetch(w1, W1, b1, K0p, wave, lane);                       // (in flight while the observation tile is fetched)
     // ---- observation tile -> LDS (zero padded), and into the rollout (policy workgroup) ----
     // the tile's rows are consecutive rows of the observation buffer: one contiguous range, read two floats per lane
     // (rows of an even number of columns start 8-byte aligned and no pair straddles two rows)
@@ -308,13 +313,17 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
       }
     }
     __syncthreads();
-    pol_prefetch(w2, W2, POL_H1, wave, lane);                    // (the next layer's weights: in flight during this layer)
+    pol_prefetch(w2, W2, b2, POL_H1, wave, lane);                    // (the next layer's weights: in flight during this layer)
     pol_layer<POL_H1 / 16, 1, false, BF>(X, ldx, w1, b1, K0p, wave, lane, Y1, ld1, nullptr);
     __syncthreads();
-    pol_prefetch(w3, W3, POL_H2, wave, lane);
+    pol_prefetch(w3, W3, b3, POL_H2, wave, lane);
     pol_layer<POL_H2 / 16, 1, false, BF>(Y1, ld1, w2, b2, POL_H1, wave, lane, Y2, ld2, nullptr);
     __syncthreads();
-    pol_prefetch(w4, W4, POL_H3, wave, lane);
+    pol_prefetch(w4, W4, b4, POL_H3, wave, lane);
+    // (the sampling's log-std with them: ahead of the barrier, so that the request is not moved down to its use)
+    const int nc = (lane & 15) < 2 ? (lane & 15) : 0;
+    float ls = 0.0f;
+    if (wave == 0 && net == 0) ls = (io.params + 2 * pol_net_floats(K0))[nc];
     pol_layer<POL_H3 / 16, 2, false, BF>(Y2, ld2, w3, b3, POL_H2, wave, lane, Y3, ld3, nullptr);
     __syncthreads();
     if (wave == 0) {
@@ -323,9 +332,13 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
       const int n = lane & 15, g = lane >> 4;
       if (net == 0) {
         // ---- diagonal Gaussian: sample, log-probability, action ----
-        const float* log_std = io.params + 2 * pol_net_floats(K0);
-        const int nc = n < 2 ? n : 0;
-        const float ls = log_std[nc], sigma = expf(ls);
+        const float sigma = expf(ls);
+        // the action map of this lane's component: launch arguments picked by a select (indexed by the lane they are vector
+        // loads from the argument segment, behind the stores of every row: four trips to memory in this epilogue)
+        float cl0 = io.clip_lo[0], cl1 = io.clip_lo[1], ch0 = io.clip_hi[0], ch1 = io.clip_hi[1];
+        float am0 = io.act_mid[0], am1 = io.act_mid[1], ah0 = io.act_half[0], ah1 = io.act_half[1];
+        asm volatile("" : "+s"(cl0), "+s"(cl1), "+s"(ch0), "+s"(ch1), "+s"(am0), "+s"(am1), "+s"(ah0), "+s"(ah1));   // (or the selects become indexed loads again)
+        const float clip_lo = nc ? cl1 : cl0, clip_hi = nc ? ch1 : ch0, act_mid = nc ? am1 : am0, act_half = nc ? ah1 : ah0;
 #pragma unroll
         for (int u = 0; u < POL_MT; u++)
 #pragma unroll
@@ -343,8 +356,8 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
               const size_t q = (size_t)t * ld + col0 + rr;
               io.A[2 * q + n] = a;
               if (n == 0) io.LP[q] = lp;
-              const float ac = fminf(fmaxf(a, io.clip_lo[n]), io.clip_hi[n]);
-              io.actions_out[2 * (size_t)e + n] = io.act_mid[n] + io.act_half[n] * ac;
+              const float ac = fminf(fmaxf(a, clip_lo), clip_hi);
+              io.actions_out[2 * (size_t)e + n] = act_mid + act_half * ac;
               if (io.mu_out) io.mu_out[2 * (size_t)row + n] = mu;
               if (io.eps_out) io.eps_out[2 * (size_t)row + n] = eps;
             }
@@ -359,6 +372,12 @@ __global__ void __launch_bounds__(POL_THREADS, (POL_WAVES >= 8 ? 4 : 2)) k6_poli
           }
       }
     }
+  }
+  if (trans) {
+    float r = trans_r;
+    if (io.reward_clip > 0.0f) r = fminf(fmaxf(r, -io.reward_clip), io.reward_clip);
+    io.R[(size_t)(t - 1) * ld + col0 + tid] = r * io.reward_scale;
+    io.Dn[(size_t)(t - 1) * ld + col0 + tid] = trans_d ? 1.0f : 0.0f;
   }
   // ---- the rollout position and the generator's counter move on ----
   if (host_counts) {
