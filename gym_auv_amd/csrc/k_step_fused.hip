@@ -124,7 +124,8 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
 #ifdef AUV_STAMPS
     const unsigned long long t_real0 = wall_clock64();
 #endif
-    const int n_act = k2_front(d, e, lane, L, 1);
+    int2 lim0 = make_int2(INT32_MIN, INT32_MIN);           // this lane's cull-limit row: stored by k2_back (see there)
+    const int n_act = k2_front(d, e, lane, L, 1, nullptr, 0, nullptr, false, d.cfg.use_lidar ? &lim0 : nullptr);
     if (d.cfg.use_lidar) {
       AUV_STAMP()
 #ifdef AUV_STAMPS
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
 #endif
       AUV_STAMP()
       double term = 0.0;
-      k2_back(d, e, lane, L, n_act, obs_out, &term);
+      k2_back(d, e, lane, L, n_act, obs_out, &term, &lim0);
       AUV_STAMP()
       AUV_STAMP_FLUSH(e, 0)   // 0: front (A, C, B, S)  1: pairs (D)  2: back (E)
 #ifdef AUV_STAMPS
