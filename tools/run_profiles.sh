@@ -68,4 +68,5 @@ python tools/trace_overlap.py $OUT/trace/*/*_kernel_trace.csv k_step_roles 4000 
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace
 head -6 $OUT/kernel_trace_summary.txt; head -12 $OUT/kernel_trace_overlap.txt
-bash tools/pmc_workload.sh $TAG polygons50 4
+# (SKIP_PMC=1: the counter passes go in a GPU call of their own -- tools/pmc_workload.sh <tag> polygons50 4 -- when one call cannot hold both)
+[ "${SKIP_PMC:-0}" = 1 ] || bash tools/pmc_workload.sh $TAG polygons50 4
