@@ -90,7 +90,8 @@ class BatchedAuvEnv:
         self.sub_batches = 1
         # how step_async / step_wait order chains on other streams against the caller's: "device" (one-wave kernels and two
         # words in device memory) beats "cp" (command-processor waits) beats "events" at every chain count measured
-        # (4096 x 180: 80 / 68 / 40 M env-steps/s with four chains, 100 / 92 / 56 M with two; profiles/r04/sweep_api*.jsonl)
+        # (4096 x 180, slices all on other streams: 70 / 66 / 43 M env-steps/s with four chains, 109 / 100 / 58 M with two;
+        # profiles/r04/sweep_api_final.jsonl)
         self.rendezvous = "device"
         self.stream_probe_s = 0.0
         self._chain_graph = None

@@ -63,7 +63,7 @@ class AuvVecEnv:
         self.numpy = bool(numpy)
         self._rewarder = _RewarderView(rewarder)
         # (the VecEnv protocol waits for ALL environments every step: one launch on the caller's stream is then the fastest
-        # shape -- 110 M env-steps/s at 4096 x 180 against 102 / 83 M with two / four chains and a rendezvous per step;
+        # shape -- 118-121 M env-steps/s at 4096 x 180 against 108-110 / 89-105 M with two / four chains and a rendezvous per step;
         # chains pay where slices are consumed independently: BatchedAuvEnv.step_slice, examples/ppo.py)
         if sub_batches > 1:
             self.env.set_sub_batches(sub_batches, inline_first=True)
