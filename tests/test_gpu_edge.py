@@ -57,7 +57,8 @@ def _cfg(ns=9, nps=20, **kw):
     return cfg
 
 
-@pytest.mark.parametrize("n,ns,nps", [(1, 9, 20), (5, 9, 1), (7, 10, 10), (3, 3, 1), (130, 13, 7)])
+# (300 / 520 beams: more than the back phase's (index, weight) list of returns and than four ray passes hold -- the generic routes)
+@pytest.mark.parametrize("n,ns,nps", [(1, 9, 20), (5, 9, 1), (7, 10, 10), (3, 3, 1), (130, 13, 7), (4, 15, 20), (3, 13, 40)])
 def test_ragged_env_and_sensor_counts(n, ns, nps):
     specs = [sc.moving_obstacles_world(700 + i) for i in range(3)]
     _run(_cfg(ns, nps, max_timesteps=11), specs, n, steps=25, auto_reset=True)
