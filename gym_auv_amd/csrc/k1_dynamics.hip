@@ -168,7 +168,7 @@ __device__ __forceinline__ EnvPre k1_env(const AuvDev& d, const int e, const voi
 
 // Eight lanes advance one environment: lane c < 6 owns state component c and forms its
 // Runge-Kutta combinations (15 of the 90 fp64 divisions by tableau constants), every lane evaluates
-// _state_dot of the stage vector it gathers from its group with shuffles and keeps component c.  The
+// _state_dot of the stage vector it gathers from its group by DPP moves (k1_group_bcast) and keeps component c.  The
 // same operations in the same order per component as k1_env, so the results are bit-identical; the
 // wave retires ~2x fewer instructions per environment step than with one lane doing all six
 // components.  Returns component c of the new state (lanes c >= 6: unspecified).  Lanes whose group

@@ -33,6 +33,9 @@
 //            test, a hit does an LDS atomic-min on the ray's t (non-negative fp64 as uint64).
 //   phase E  lanes <-> rays: distance from the min t, closeness (fp64 + the float32 observation
 //            columns), ballot -> collision, and the LiDAR term of the Colav reward.
+// Two rules the phases keep (round 4): (1) a wave's global loads and stores count down one counter in issue order, so a
+// phase requests everything it reads before its first store (k2_back stores phase B's limit rows for that reason); (2) lane
+// exchanges that are not data-dependent go by DPP (auv_wave_scan_incl, auv_wave_sum), not through the LDS crossbar.
 // Work per environment is ~(rays subtended by the nearby front-facing boundaries), ~100 pair
 // tests instead of S x G = 99 k, and does not depend on how wide the reference's windows are.
 // Roofline: HBM.  Algorithmic bytes per env-step (fp64 layout): 32*G (segments, G per env)
