@@ -356,8 +356,6 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
   t.px = roles_group_value(vp, 0), t.py = roles_group_value(vp, 1), t.psi = roles_group_value(vp, 2);
   t.u = roles_group_value(vp, 3), t.v = roles_group_value(vp, 4), t.r = roles_group_value(vp, 5);
   cnt.y = (int)(unsigned)roles_group_word(vp, 6);                 // the vessel's step counter of this launch
-  // STATE rows of the new state (the dynamics role leaves only the packet): lane c of a group holds component c
-  if (live && c < 6) state[(size_t)c * (size_t)n_envs + e] = __longlong_as_double((long long)vp);
   t.nr.A = make_double2(roles_group_value(vh, 0), roles_group_value(vh, 1));
   t.nr.B = make_double2(roles_group_value(vh, 2), roles_group_value(vh, 3));
   t.nr.cum = roles_group_value(vh, 4);
@@ -366,13 +364,19 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
 #endif
   NavOut no;
   no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = no.cte100 = 0.0;
+  // a first look at the sweeps' words BEFORE the tail's stores (a look behind them waits for them: with one chain the words
+  // are there by the time a finish wave runs, and the poll below is then not entered at all)
+  unsigned long long word = live ? __hip_atomic_load(pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
   if (AUV_RUN_N(dk, 3)) no = nav_tail<K1_GROUP>(st, e, c, live, t, obs_out);
+  // STATE rows of the new state (the dynamics role leaves only the packet): lane c of a group holds component c.  (Behind the
+  // tail, not in front of it: the tail's loads would wait for this store -- one counter, in issue order.)
+  if (live && c < 6) state[(size_t)c * (size_t)n_envs + e] = __longlong_as_double((long long)vp);
 #ifdef AUV_STAMPS
   if (live && c == 0) d.stamps[(size_t)e * 16 + 13] = wall_clock64();   // the tail is done
 #endif
   // ---- the sweeps' words ----
-  unsigned long long word = live ? PAIR_EMPTY : 0ull;
   for (int polls = 0;; polls++) {
+    if (!__any(word == PAIR_EMPTY)) break;
     if (word == PAIR_EMPTY) word = __hip_atomic_load(pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!__any(word == PAIR_EMPTY)) break;
     if (polls == limit) {
