@@ -67,6 +67,9 @@ namespace {
 #define PAIR_EMPTY AUV_PAIR_EMPTY
 #define PAIR_COLLISION AUV_PAIR_COLLISION
 #define PAIR_POLL_LIMIT (1 << 22)
+#ifndef ROLES_POLL_SLEEP
+#define ROLES_POLL_SLEEP 8          // 64-cycle quanta between two looks at a hand-over word (2, 4 and 16 measured in round 4: no difference, profiles/r04/ab_poll_sleep.jsonl)
+#endif
 #define ROLES_ABORT_COUNTER 0xffffffffu   // step-counter word of an ABORT packet (a real Vessel._step_counter never gets there)
 
 // A poll has run out.  The wave records which environments it leaves unfinished (`broken`: the caller does, per
@@ -223,7 +226,7 @@ __device__ __forceinline__ int roles_wait_state(const AuvDev& d, const int e, co
       roles_give_up(d, d.e0, d.ne, 2, lane);
       return 1;
     }
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
   }
 #pragma unroll
   for (int i = 0; i < 6; i++) pre.s[i] = pair_lane_value(v, i);
@@ -345,7 +348,7 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
       roles_give_up(d, e0, ne, 3, lane);
       return;
     }
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
   }
   if (__any(aborted)) {
     // the eight environments of a finish wave are the eight of ONE dynamics wave: all of them or none.  The ABORT packets
@@ -384,7 +387,7 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
       roles_give_up(d, e0, ne, 1, lane);
       return;
     }
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
   }
 #ifdef AUV_STAMPS
   if (live && c == 0) d.stamps[(size_t)e * 16 + 7] = wall_clock64();    // the sweep's word is here: start of the reward phase
