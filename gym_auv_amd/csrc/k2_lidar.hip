@@ -27,7 +27,7 @@
 //            xor/or per obstacle, all edges) and the conservative range of ray indices each staged
 //            segment can possibly be hit by (its angular span seen from p0, fp32 atan2, widened
 //            by two rays on both sides).
-//   phase D  work items = (staged segment, run of <= 8 rays of its span), lanes <-> items: the rays
+//   phase D  work items = (staged segment, run of <= K2_ITEM_RAYS (6) rays of its span), lanes <-> items: the rays
 //            that also lie in the obstacle's window (the reference's culling decides visibility;
 //            the span only skips pairs that cannot intersect) get the exact fp64 ray/segment
 //            test, a hit does an LDS atomic-min on the ray's t (non-negative fp64 as uint64).
@@ -99,7 +99,9 @@ struct MoverSegs {
 #ifndef K2_RAW_CAP
 #define K2_RAW_CAP 192   // boundary segments looked at per batch; only the front-facing ones are staged
 #endif
-#define K2_ITEM_RAYS 8    // rays per work item of the pair sweep
+#ifndef K2_ITEM_RAYS
+#define K2_ITEM_RAYS 6    // rays per work item of the pair sweep (4, 5, 6, 8, 12 measured: profiles/r04/ab_item_rays.jsonl)
+#endif
 
 // per-wave LDS slice (decreasing alignment):
 //   EnvHdr | [Mmax] double4 mover pose (cos, sin, x, y) | [CAP] double4 staged (wx,wy,sx,sy) |
