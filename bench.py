@@ -373,8 +373,11 @@ def main():
             # captured CHAINS: K steps of every sub-batch per replay, each chain with its own position in the ring
             ring = env.capture_graph_chains(torch.float32, slots=n_pool, steps=K, one_graph=bool(args.one_graph))
             if args.steps % K or args.warmup % K:
-                raise SystemExit("--graph K with sub-batches: --steps and --warmup must be multiples of K (every chain keeps "
-                                 "its own ring position; eager steps in between would not advance it)")
+                # every chain keeps its own ring position and eager steps in between would not advance it: whole replays only.
+                # Rounded UP (the default warm-up of 200 made `--graph 16` exit); the JSON line reports what ran.
+                args.steps, args.warmup = -(-args.steps // K) * K, -(-args.warmup // K) * K
+                sys.stderr.write("bench.py: --graph %d with sub-batch chains: steps / warmup rounded up to %d / %d (whole replays)\n"
+                                 % (K, args.steps, args.warmup))
         else:
             ring = env.capture_graph(torch.float32, slots=n_pool, steps=K)
         ring.copy_(pool)
@@ -437,16 +440,24 @@ def main():
     # microseconds over xGMI) to every rank's time -- a tenth of the driver's 0.7 ms window of 20 steps, and nothing
     # the step path does: the path has no collective.
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     D.barrier()
     torch.cuda.synchronize(dev)
     elapsed = D.max_over_ranks(elapsed, dev)
-    # the only exchange of the path: episode returns for reporting, RCCL all_gather over xGMI
-    stats = D.gather_episode_stats(env.episode_stats())
+    # the only exchange of the path: episode returns for reporting, RCCL all_gather over xGMI -- timed on its own (second call:
+    # the first one pays the communicator's lazy set-up), outside the timed region
+    ep_stats = env.episode_stats()
+    stats = D.gather_episode_stats(ep_stats)
+    torch.cuda.synchronize(dev)
+    t_ag = time.perf_counter()
+    stats = D.gather_episode_stats(ep_stats)
+    torch.cuda.synchronize(dev)
+    t_ag = time.perf_counter() - t_ag
     total_envs = n_local * world
     value = total_envs * args.steps / elapsed
     if api == "pipelined" and sub == 1:
         api = "step"
-    per_rank = D.gather_floats([t_gen, t_probe, float(bank_from_cache), float(sub)], dev)
+    per_rank = D.gather_floats([t_gen, t_probe, float(bank_from_cache), float(sub), 1e3 * elapsed_local / args.steps, 1e3 * t_ag], dev)
 
     world_of_env = env.read("WORLD_IDX").cpu().numpy()
     nearby = env.read("NEARBY").cpu().numpy()
@@ -592,7 +603,10 @@ def main():
                    worlds_per_env=wpe, world_gen_s=round(t_gen, 1),
                    # first contact with an 8-GPU node: what every rank spent before the timed region, and on what
                    per_rank=dict(world_gen_s=[round(r[0], 1) for r in per_rank], stream_probe_s=[round(r[1], 2) for r in per_rank],
-                                 bank_from_cache=[int(r[2]) for r in per_rank], sub_batches=[int(r[3]) for r in per_rank]),
+                                 bank_from_cache=[int(r[2]) for r in per_rank], sub_batches=[int(r[3]) for r in per_rank],
+                                 # every rank's OWN time per step (the line's ms_per_step is their maximum) and what the one
+                                 # reporting collective took on it: a first SCALE record that explains itself
+                                 ms_per_step=[round(r[4], 5) for r in per_rank], episode_all_gather_ms=[round(r[5], 3) for r in per_rank]),
                    collective_backend=D.backend_name(),
                    episodes_finished=int(stats["episodes"].sum().item()))
     if os.environ.get("AUV_HIP_LIB"):

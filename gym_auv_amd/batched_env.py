@@ -349,6 +349,13 @@ class BatchedAuvEnv:
         self._health_raw = [int(x) for x in out]
         return dict(handover_ok=int(out[0]), probe_failures=int(out[1]), timeouts=int(out[2]), pending=int(out[3]))
 
+    def rendezvous_state(self) -> Dict[str, int]:
+        """`device_ok`: the device-word rendezvous of step_async / step_wait is in use (0: its trial on the chains' streams or a
+        real wait has run out once -- the library orders the chains by HIP events from then on, whatever `self.rendezvous`
+        says); `timeouts`: how often."""
+        self.health()
+        return dict(device_ok=int(self._health_raw[7] == 0), timeouts=self._health_raw[7])
+
     def last_timeout(self) -> Dict[str, int]:
         """The last hand-over time-out this handle recovered from: the slice [e0, e0 + ne) of the launch that reported it
         and the number of environments the recovery reset (e0 = -1: none so far)."""

@@ -40,7 +40,8 @@ void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs,
 void auv_launch_spin(unsigned long long ticks, hipStream_t st);
 void auv_launch_rdv_publish(unsigned long long* word, unsigned long long seq, hipStream_t st);
 void auv_launch_rdv_arrive(unsigned long long* word, hipStream_t st);
-void auv_launch_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, double limit_s, hipStream_t st);
+void auv_launch_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, double limit_s, int32_t* abort_flag,
+                         int32_t* report, hipStream_t st);
 hipError_t auv_launch_probe(unsigned int* words, int np, int nc, unsigned int tag, unsigned int* failures, uint32_t lds, hipStream_t st);
 size_t auv_policy_param_floats_impl(int obs_dim);
 size_t auv_policy_lds_bytes(int obs_dim);
@@ -84,7 +85,6 @@ struct auv_handle {
   int probe_failures;            // of the last probe (0 = the dispatch order is what the hand-overs rely on)
   int handover_timeouts;         // polls that ran out over the life of the handle (each one disables the hand-overs)
   int last_timeout_e0, last_timeout_ne, last_reset_envs;   // the launch that reported the last time-out; environments its recovery reset
-  float* last_obs;               // the caller's observation buffer of the last step call (a recovery writes the reset rows there)
   hipEvent_t ev[6];
   std::vector<hipEvent_t> slice_ev;   // auv_step_pipelined_timed: start / stop event per sub-batch launch
   // auv_step_async / auv_step_wait: the chains of the pending step that do NOT run on the caller's stream, and how
@@ -97,6 +97,9 @@ struct auv_handle {
                                       //   [0] actions-ready sequence, [16] chains-arrived count, [32 + 16 j] chain j's sequence
   unsigned long long rdv_seq, rdv_target;
   double rdv_limit_s;                 // how long a rendezvous kernel waits before it gives up (pair_error 4 / 5)
+  bool rdv_device_ok;                 // AUV_RDV_DEVICE may be used: false once a trial or a real rendezvous has run out -- events from then on
+  std::vector<hipStream_t> rdv_tried; // the remote streams the device rendezvous has been tried on (auv_step_async: rdv_trial)
+  int rdv_timeouts;                   // rendezvous waits that ran out over the life of the handle (trial included)
   // captured chains (auv_graph_capture_chains): one linear graph per sub-batch, replayed on the sub-batch's stream
   std::vector<hipGraph_t> chain_graph;
   std::vector<hipGraphExec_t> chain_exec;
@@ -134,24 +137,26 @@ static void drop_graphs(auv_handle* h) {
   h->chain_exec.clear(), h->chain_graph.clear();
 }
 
-static int recover_from_timeout(auv_handle* h);
+static int recover_from_timeout(auv_handle* h, float* obs_now);
 static int probe_dispatch_order(auv_handle* h);
 
 // A wave of the one-launch step that gave up polling has left its environment's step unfinished.  The
 // next call on the handle notices (mapped host word), repairs the handle -- hand-over words cleared, EVERY
 // environment put back into its reset state, three-launch shape from now on -- and reports AUV_ESTATE once.
-#define PAIR_CHECK(h) PAIR_CHECK_ON(h, nullptr, false)
+#define PAIR_CHECK(h, obs) PAIR_CHECK_ON(h, nullptr, false, obs)
 // `st`: the stream the call will enqueue on.  While that stream is being CAPTURED (a torch CUDAGraph around auv_step /
 // auv_step_slice, examples/ppo.py) the recovery -- device synchronisation, copies, a reset launch on the null stream --
 // would be illegal and would surface as a HIP capture error: the call then only reports AUV_ESTATE; the first call
 // outside a capture recovers.
-#define PAIR_CHECK_ON(h, st, have_st)                                            \
+// `obs`: the observation buffer of THIS call (NULL if it has none): where the recovery writes the reset rows of the environments it
+// resets -- never a pointer remembered from an earlier call (the caller may have freed or rotated that buffer).
+#define PAIR_CHECK_ON(h, st, have_st, obs)                                       \
   do {                                                                           \
     if ((h)->pair_error_host && *(volatile int32_t*)(h)->pair_error_host) {      \
       if ((have_st) && stream_capturing((hipStream_t)(st)))                      \
         return fail(AUV_ESTATE, "a hand-over time-out is pending and this stream is being captured: nothing was enqueued; " \
                                 "the next call outside a capture recovers and reports");      \
-      int _rc = recover_from_timeout(h);                                         \
+      int _rc = recover_from_timeout(h, (float*)(obs));                          \
       if (_rc) return _rc;                                                       \
     }                                                                            \
   } while (0)
@@ -407,7 +412,7 @@ static int probe_dispatch_order(auv_handle* h) {
   return probe_streams(h, 1, &null_stream, false);
 }
 
-static int recover_from_timeout(auv_handle* h) {
+static int recover_from_timeout(auv_handle* h, float* obs_now) {
   AuvDev& d = h->d;
   const int code = *(volatile int32_t*)h->pair_error_host;
   const int fe0 = ((volatile int32_t*)h->pair_error_host)[1], fne = ((volatile int32_t*)h->pair_error_host)[2];
@@ -418,21 +423,21 @@ static int recover_from_timeout(auv_handle* h) {
   h->async_pending = 0;
   if (h->rdv) HIP_TRY(hipMemset(h->rdv, 0, AUV_RDV_BYTES));
   h->rdv_seq = h->rdv_target = 0;
-  if (code == 4 || code == 5) {
-    // a rendezvous kernel of auv_step_async / auv_step_wait gave up: the ordering between the caller's stream and the
-    // chains was lost for that step (a chain may have read actions that were not ready), no environment is left
-    // half-stepped and the in-launch hand-overs have nothing to do with it
-    memset(h->pair_error_host, 0, 4 * sizeof(int32_t));
-    return fail(AUV_ESTATE, "step_async / step_wait rendezvous timed out (%s): the step's ordering against the caller's stream "
-                            "was lost; environments keep their state -- reported once, carry on",
-                code == 4 ? "a chain waited in vain for the caller's stream to publish the actions"
-                          : "the caller's stream waited in vain for the chains to arrive");
+  const bool rendezvous = code == 4 || code == 5;
+  if (rendezvous) {
+    // a rendezvous kernel of auv_step_async / auv_step_wait gave up: the in-launch hand-overs have nothing to do with it and
+    // stay in use; the device-word rendezvous does not -- events from now on (they cannot run out)
+    h->rdv_timeouts += 1;
+    h->rdv_device_ok = false;
+  } else {
+    h->handover_timeouts += 1;
+    h->handover_ok = false;
   }
-  h->handover_timeouts += 1;
-  h->handover_ok = false;
-  // which environments did the waves that gave up leave unfinished?  Exactly those are reset; every other environment is
-  // consistent: it completed the steps of the launches that ran, and launches queued behind the time-out did nothing
-  // (ABORT packets, k_step_roles)
+  // Which environments were left half-stepped?  Exactly those are reset; every other environment is consistent: it completed
+  // the steps of the launches that ran, and launches queued behind the time-out did nothing (ABORT packets, k_step_roles --
+  // also behind a chain's gate that ran out: its step was NOT taken on actions that may not have been there).  The marks of
+  // the aborted launches are still up: cleared here whatever the code was (the rendezvous branch used to return
+  // with abort_flag up, and every later one-launch step then did nothing, silently).
   std::vector<uint8_t> broken(n ? n : 1, 0);
   HIP_TRY(hipMemcpy(broken.data(), d.broken, n, hipMemcpyDeviceToHost));
   int n_broken = 0;
@@ -442,20 +447,75 @@ static int recover_from_timeout(auv_handle* h) {
   HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
-  if (n_broken) auv_launch_reset(d, d.broken, nullptr, h->last_obs, nullptr);
+  if (n_broken) auv_launch_reset(d, d.broken, nullptr, obs_now, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(d.broken, 0, n));
-  HIP_TRY(hipMemset(d.abort_flag, 0, sizeof(int32_t)));
+  HIP_TRY(hipMemset(d.abort_flag, 0, 4 * sizeof(int32_t)));
   memset(h->pair_error_host, 0, 4 * sizeof(int32_t));
-  h->last_timeout_e0 = fe0, h->last_timeout_ne = fne, h->last_reset_envs = n_broken;
+  h->last_reset_envs = n_broken;
+  if (rendezvous)
+    return fail(AUV_ESTATE, "step_async / step_wait rendezvous timed out (%s).  %s  %d environment(s) were reset; the handle orders its chains "
+                            "by HIP events from now on (AUV_RDV_EVENTS); this error is reported once",
+                code == 4 ? "a chain waited in vain for the caller's stream to publish the actions" : "the caller's stream waited in vain for the chains to arrive",
+                code == 4 ? "The step of that chain, and every launch queued behind it, was NOT executed (no environment stepped on actions that were not "
+                            "there); chains whose gates had opened did step, so the slices may be one step apart."
+                          : "The chains' steps were executed; work enqueued behind step_wait may have read results that were not ready.",
+                n_broken);
+  h->last_timeout_e0 = fe0, h->last_timeout_ne = fne;
   return fail(AUV_ESTATE, "in-launch hand-over timed out (%s) in the launch over environments [%d, %d): the %d environment(s) whose step "
-                          "was left unfinished are back in their reset state (reset observation written to the caller's buffer); all "
+                          "was left unfinished are back in their reset state (reset observation in OBS64%s); all "
                           "others keep their state, but steps enqueued behind the time-out were not executed.  The handle steps in "
                           "the three-launch shape from now on (no in-launch hand-over); this error is reported once",
               code == 2 ? "a sweep or search wave waited in vain for the dynamics role's state"
                         : (code == 3 ? "a finish wave waited in vain for a state packet or a search record" : "a finish wave waited in vain for a sweep's word"),
-              fe0, fe0 + fne, n_broken);
+              fe0, fe0 + fne, n_broken, obs_now ? " and in this call's observation buffer" : "");
+}
+
+// Do the kernels of the device-word rendezvous get to run side by side on these streams RIGHT NOW?  The pattern of one
+// step_async / step_wait with nothing at stake: publish on the caller's stream, on every chain stream a gate, 20 us of a
+// do-nothing wave (standing for the step) and the count-off, one wait on the caller's stream -- every wait limited to 50 ms,
+// reporting code 6 (no abort, no recovery).  Where dispatches are serialised (a counter-collecting profiler executes one kernel
+// at a time, in an order of its own) a waiting kernel sits in front of what it waits for: the trial then costs 50-100 ms ONCE
+// and the handle orders its chains by events from then on -- round 4 lost two profiling runs to 300 s of silence instead.
+// Synchronises the streams involved (once per set of streams).
+static int rdv_trial(auv_handle* h, hipStream_t cs) {
+  const size_t nr = h->async_streams.size();
+  h->rdv_seq += 1;
+  auv_launch_rdv_publish(h->rdv, h->rdv_seq, cs);
+  for (size_t j = 0; j < nr; j++) {
+    hipStream_t st = h->async_streams[j];
+    auv_launch_rdv_wait(h->rdv, h->rdv_seq, h->d.pair_error, 6, 0.05, nullptr, h->d.abort_flag + 2, st);
+    auv_launch_spin(2000, st);
+    auv_launch_rdv_arrive(h->rdv + 16, st);
+  }
+  h->rdv_target += nr;
+  auv_launch_rdv_wait(h->rdv + 16, h->rdv_target, h->d.pair_error, 6, 0.05, nullptr, h->d.abort_flag + 2, cs);
+  HIP_TRY(hipGetLastError());
+  for (size_t j = 0; j < nr; j++) HIP_TRY(hipStreamSynchronize(h->async_streams[j]));
+  HIP_TRY(hipStreamSynchronize(cs));
+  h->rdv_tried = h->async_streams;
+  {
+    // (a hand-over time-out of a step still in flight on some chain may have crossed the trial's report on the one host word:
+    // the device-side flag is the truth)
+    int32_t up = 0;
+    HIP_TRY(hipMemcpy(&up, h->d.abort_flag, sizeof(up), hipMemcpyDeviceToHost));
+    const int32_t seen = *(volatile int32_t*)h->pair_error_host;
+    if (up && (seen == 0 || seen == 6)) {
+      h->rdv_device_ok = false;
+      *(volatile int32_t*)h->pair_error_host = 1;
+      return AUV_OK;                                   // the next call's PAIR_CHECK recovers
+    }
+  }
+  if (*(volatile int32_t*)h->pair_error_host == 6) {
+    *(volatile int32_t*)h->pair_error_host = 0;
+    HIP_TRY(hipMemset(h->d.abort_flag + 2, 0, sizeof(int32_t)));
+    HIP_TRY(hipMemset(h->rdv, 0, AUV_RDV_BYTES));
+    h->rdv_seq = h->rdv_target = 0;
+    h->rdv_device_ok = false;
+    h->rdv_timeouts += 1;
+  }
+  return AUV_OK;
 }
 
 extern "C" {
@@ -489,13 +549,18 @@ int auv_create(const auv_config_t* cfg, int32_t n_envs, int32_t device_id, auv_h
   h->probe_failures = -1;
   h->handover_timeouts = 0;
   h->last_timeout_e0 = h->last_timeout_ne = -1, h->last_reset_envs = 0;
-  h->last_obs = nullptr;
   for (auto& e : h->ev) e = nullptr;
   h->async_pending = 0;
   h->ev_actions = nullptr;
   h->rdv = nullptr;
   h->rdv_seq = h->rdv_target = 0;
-  h->rdv_limit_s = 300.0;   // (a chain's gate waits for as long as the caller's stream is busy between two steps: minutes are legitimate)
+  // A chain's gate waits for as long as the caller's stream is busy between publish and ... nothing: the publish kernel is enqueued by
+  // auv_step_async itself, behind whatever the caller's stream still has to do.  10 s covers a PPO update enqueued in front of it; a
+  // caller whose stream can be busy for longer raises the limit (auv_set_rendezvous_limit) or synchronises first.  (Round 4: 300 s --
+  // two profiling runs sat silent for 420 s behind polling kernels whose streams a counter-collecting profiler had serialised.)
+  h->rdv_limit_s = 10.0;
+  h->rdv_device_ok = true;
+  h->rdv_timeouts = 0;
   *out = h;
   return AUV_OK;
 }
@@ -805,7 +870,6 @@ static int enqueue_step(auv_handle_t* h, int mode, int e0, int ne, const void* a
   if (!capturing) d.ring_slots = 1;
   d.e0 = e0, d.ne = ne;
   d.ring_pos += chain, d.k1_done += chain;
-  h->last_obs = obs;
   if (mode == AUV_STEP_ONE_LAUNCH) {
     // dynamics, LiDAR sweep, navigation search and finish as four roles of ONE launch (csrc/k_step_fused.hip: k_step_roles;
     // inside a captured graph its dynamics role advances the action ring)
@@ -845,7 +909,7 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
   REQUIRE_READY(h);
   int rc = check_actions(actions_dev, action_dtype, "auv_step");
   if (rc) return rc;
-  PAIR_CHECK_ON(h, stream, true);
+  PAIR_CHECK_ON(h, stream, true, obs_dev);
   rc = enqueue_step(h, effective_mode(h, h->d.n), 0, h->d.n, actions_dev, action_dtype, obs_dev, reward_dev, done_dev,
                     (hipStream_t)stream, false);
   if (rc) return rc;
@@ -859,7 +923,7 @@ int auv_step_slice(auv_handle_t* h, int32_t e0, int32_t ne, const void* actions_
   int rc = check_actions(actions_dev, action_dtype, "auv_step_slice");
   if (rc) return rc;
   if (e0 < 0 || ne < 1 || (int64_t)e0 + ne > h->d.n) return fail(AUV_EINVAL, "auv_step_slice: slice [%d, %d) outside [0, %d)", e0, e0 + ne, h->d.n);
-  PAIR_CHECK_ON(h, stream, true);
+  PAIR_CHECK_ON(h, stream, true, obs_dev);
   rc = enqueue_step(h, effective_mode(h, ne), e0, ne, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, (hipStream_t)stream, false);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -873,7 +937,7 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
   if (rc) return rc;
   rc = check_slices(h, n_slices, bounds, streams, "auv_step_pipelined");
   if (rc) return rc;
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, obs_dev);
   for (int i = 0; i < n_slices && rc == AUV_OK; i++)
     rc = enqueue_step(h, effective_mode(h, bounds[i + 1] - bounds[i]), bounds[i], bounds[i + 1] - bounds[i], actions_dev, action_dtype,
                       obs_dev, reward_dev, done_dev, (hipStream_t)streams[i], false);
@@ -892,7 +956,7 @@ int auv_step_async(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, voi
   if (rendezvous != AUV_RDV_EVENTS && rendezvous != AUV_RDV_DEVICE && rendezvous != AUV_RDV_CP)
     return fail(AUV_EINVAL, "auv_step_async: rendezvous must be one of AUV_RDV_*");
   if (h->async_pending) return fail(AUV_ESTATE, "auv_step_async: the previous step has not been waited for (auv_step_wait)");
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, obs_dev);
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t cs = (hipStream_t)caller_stream;
   h->async_streams.clear();
@@ -900,6 +964,20 @@ int auv_step_async(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, voi
     if ((hipStream_t)streams[i] != cs) h->async_streams.push_back((hipStream_t)streams[i]);
   const size_t nr = h->async_streams.size();         // chains on streams of their own: the others are in stream order already
   if (nr && rendezvous != AUV_RDV_EVENTS && !h->rdv) return fail(AUV_ESTATE, "auv_step_async: rendezvous words missing (no bank loaded?)");
+  if (nr && rendezvous == AUV_RDV_DEVICE) {
+    // The device-word rendezvous needs (i) the one-launch shape for every slice -- a gate that runs out stops its step by
+    // ABORT packets, which only that shape reads -- and (ii) streams that run side by side NOW.  (ii) is tried before the
+    // first real step on a set of streams (rdv_trial: 50 ms, no step at stake); a trial or a real wait that has run out
+    // demotes the handle to events for good.
+    bool one_launch = true;
+    for (int i = 0; i < n_slices; i++) one_launch = one_launch && effective_mode(h, bounds[i + 1] - bounds[i]) == AUV_STEP_ONE_LAUNCH;
+    if (!one_launch || !h->rdv_device_ok) rendezvous = AUV_RDV_EVENTS;
+    else if (h->rdv_tried != h->async_streams && !stream_capturing(cs)) {
+      int rc_t = rdv_trial(h, cs);
+      if (rc_t) return rc_t;
+      if (!h->rdv_device_ok) rendezvous = AUV_RDV_EVENTS;
+    }
+  }
   if (nr && rendezvous == AUV_RDV_EVENTS) {
     if (!h->ev_actions) HIP_TRY(hipEventCreateWithFlags(&h->ev_actions, hipEventDisableTiming));
     while (h->ev_chain.size() < nr) {
@@ -919,7 +997,7 @@ int auv_step_async(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, voi
     const bool remote = st != cs;
     if (remote) {
       if (rendezvous == AUV_RDV_EVENTS) HIP_TRY(hipStreamWaitEvent(st, h->ev_actions, 0));
-      else if (rendezvous == AUV_RDV_DEVICE) auv_launch_rdv_wait(h->rdv, h->rdv_seq, h->d.pair_error, 4, h->rdv_limit_s, st);
+      else if (rendezvous == AUV_RDV_DEVICE) auv_launch_rdv_wait(h->rdv, h->rdv_seq, h->d.pair_error, 4, h->rdv_limit_s, h->d.abort_flag, h->d.abort_flag + 1, st);
       else HIP_TRY(hipStreamWaitValue64(st, h->rdv, h->rdv_seq, hipStreamWaitValueGte, ~0ull));
     }
     rc = enqueue_step(h, effective_mode(h, bounds[i + 1] - bounds[i]), bounds[i], bounds[i + 1] - bounds[i], actions_dev, action_dtype,
@@ -949,7 +1027,7 @@ int auv_step_wait(auv_handle_t* h, void* caller_stream) {
     if (rendezvous == AUV_RDV_EVENTS) {
       for (size_t j = 0; j < nr; j++) HIP_TRY(hipStreamWaitEvent(cs, h->ev_chain[j], 0));
     } else if (rendezvous == AUV_RDV_DEVICE) {
-      auv_launch_rdv_wait(h->rdv + 16, h->rdv_target, h->d.pair_error, 5, h->rdv_limit_s, cs);   // ONE wait for all chains
+      auv_launch_rdv_wait(h->rdv + 16, h->rdv_target, h->d.pair_error, 5, h->rdv_limit_s, nullptr, h->d.abort_flag + 1, cs);   // ONE wait for all chains
       HIP_TRY(hipGetLastError());
     } else {
       for (size_t j = 0; j < nr; j++) HIP_TRY(hipStreamWaitValue64(cs, h->rdv + 32 + 16 * j, h->rdv_seq, hipStreamWaitValueGte, ~0ull));
@@ -972,7 +1050,7 @@ int auv_graph_capture_chains(auv_handle_t* h, int32_t n_slices, const int32_t* b
   rc = check_slices(h, n_slices, bounds, bounds, "auv_graph_capture_chains");   // (the chains' streams are named at replay)
   if (rc) return rc;
   if (n_steps < 1 || n_steps > 4096) return fail(AUV_EINVAL, "auv_graph_capture_chains: n_steps must be in [1, 4096]");
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, obs_dev);
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   drop_graphs(h);
@@ -1042,7 +1120,7 @@ int auv_graph_launch_chains(auv_handle_t* h, int32_t n_slices, void* const* stre
   REQUIRE_READY(h);
   if (!streams || n_slices != (int32_t)h->chain_exec.size() || n_slices < 1)
     return fail(AUV_ESTATE, "auv_graph_launch_chains: %d streams for %d captured chains", n_slices, (int)h->chain_exec.size());
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, nullptr);
   for (int i = 0; i < n_slices; i++) HIP_TRY(hipGraphLaunch(h->chain_exec[i], (hipStream_t)streams[i]));
   return AUV_OK;
 }
@@ -1054,7 +1132,7 @@ int auv_step_pipelined_timed(auv_handle_t* h, int32_t n_slices, const int32_t* b
   if (rc) return rc;
   if (n_slices < 1 || !bounds || !streams || !out_ms) return fail(AUV_EINVAL, "auv_step_pipelined_timed: bad arguments");
   if (bounds[0] != 0 || bounds[n_slices] != h->d.n) return fail(AUV_EINVAL, "auv_step_pipelined_timed: bounds must run from 0 to %d", h->d.n);
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, obs_dev);
   while ((int)h->slice_ev.size() < 2 * n_slices) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
@@ -1134,7 +1212,7 @@ int auv_health(auv_handle_t* h, int32_t* out8) {
   out8[2] = h->handover_timeouts;
   out8[3] = (h->pair_error_host && *(volatile int32_t*)h->pair_error_host) ? 1 : 0;   // a time-out not yet recovered from
   out8[4] = h->last_timeout_e0, out8[5] = h->last_timeout_ne, out8[6] = h->last_reset_envs;
-  out8[7] = 0;
+  out8[7] = h->rdv_device_ok ? 0 : (h->rdv_timeouts > 0 ? h->rdv_timeouts : 1);   // > 0: rendezvous waits that ran out (trial or real): events from then on
   return AUV_OK;
 }
 
@@ -1334,7 +1412,7 @@ int auv_policy_rollout(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
     if (rc) return rc;
     if (t0 && (t0[i] < 0 || gstep0[i] < 0)) return fail(AUV_EINVAL, "auv_policy_rollout: negative counter for slice %d", i);
   }
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, obs_dev);
   HIP_TRY(auv_policy_prepare(ios[0].obs_dim));
   // t0 / gstep0 (per slice; both or neither): the host names every launch's rollout position and generator step (this is a
   // plain loop of launches, the values are known here) -- the launches then neither read nor count off on io.ctr, which
@@ -1369,7 +1447,7 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
     int rc_a = check_actions(actions_dev, action_dtype, "auv_graph_capture");
     if (rc_a) return rc_a;
   }
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, obs_dev);
   if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
   drop_graphs(h);
   if (h->graph) {
@@ -1399,7 +1477,7 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
 int auv_graph_launch(auv_handle_t* h, void* stream) {
   REQUIRE_READY(h);
   if (!h->graph_exec) return fail(AUV_ESTATE, "auv_graph_launch: no captured graph");
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, nullptr);
   HIP_TRY(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
   return AUV_OK;
 }
@@ -1412,7 +1490,7 @@ int auv_step_timed(auv_handle_t* h, const void* actions_dev, int32_t action_dtyp
     int rc_a = check_actions(actions_dev, action_dtype, "auv_step_timed");
     if (rc_a) return rc_a;
   }
-  PAIR_CHECK(h);
+  PAIR_CHECK(h, obs_dev);
   hipStream_t st = (hipStream_t)stream;
   for (auto& e : h->ev)
     if (!e) HIP_TRY(hipEventCreate(&e));

@@ -78,6 +78,7 @@ namespace {
 __device__ __forceinline__ void roles_give_up(const AuvDev& d, const int e0, const int ne, const int code, const int lane) {
   if (lane == 0) {
     __hip_atomic_store(d.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d.abort_flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // "a report is out": a rendezvous kernel that runs out later keeps its code to itself (k_rdv_wait)
     __hip_atomic_store(d.pair_error + 1, e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(d.pair_error + 2, ne, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(d.pair_error, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -120,8 +121,10 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
   } else {
     const int e = auv_uniform(d.e0 + (int)blockIdx.x);
     // next action slot of a captured graph's ring: the dynamics kernel of this step has read the position, the
-    // one of the next step has not been launched yet (a captured step covers the whole batch: e0 = 0)
-    if (e == 0 && lane == 0 && dk.ring_slots > 1 && dk.ring_slot_host == -1) *dk.ring_pos = (*dk.ring_pos + 1) % dk.ring_slots;
+    // one of the next step has not been launched yet.  The first environment of the LAUNCH advances it: a captured chain
+    // covers a slice [e0, e0 + ne) and keeps a ring position of its own (`e == 0` left the chains with e0 > 0
+    // on slot 0 for good when a captured chain stepped in this shape)
+    if (e == d.e0 && lane == 0 && dk.ring_slots > 1 && dk.ring_slot_host == -1) *dk.ring_pos = (*dk.ring_pos + 1) % dk.ring_slots;
     const Slice L = carve(smem, S, d.k_max, d.m_max);
     AUV_STAMP_DECL
 #ifdef AUV_STAMPS
@@ -686,13 +689,22 @@ __global__ void k_rdv_publish(unsigned long long* word, unsigned long long seq) 
 __global__ void k_rdv_arrive(unsigned long long* word) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void k_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, unsigned long long limit_ticks) {
+__global__ void k_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, unsigned long long limit_ticks,
+                           int32_t* abort_flag, int32_t* report) {
   if (threadIdx.x != 0) return;
   const unsigned long long t0 = wall_clock64();                    // 100 MHz
   int polls = 0;
   while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     if (wall_clock64() - t0 > limit_ticks) {
-      __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // A chain's gate that runs out (abort_flag given: code 4) must not let its step run on actions that may not be there:
+      // the device-wide abort flag goes up FIRST, so the launch behind this kernel -- and every launch queued behind it, on
+      // any stream -- hands out ABORT packets and leaves its environments untouched (k_step_roles), exactly as behind a
+      // hand-over time-out.  The code is published only if no other report is pending: a hand-over time-out (codes 1-3)
+      // reported by an earlier launch must reach the host as such -- its recovery is the superset.
+      if (abort_flag) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (arbitrated on a DEVICE word, `report`: no read-modify-write on the mapped host word)
+      if (__hip_atomic_exchange(report, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
     // eager for the first few microseconds (a step's rendezvous), then a poll per ~2 us: a chain's gate may sit here for as long
@@ -708,8 +720,9 @@ void auv_launch_rdv_publish(unsigned long long* word, unsigned long long seq, hi
   hipLaunchKernelGGL(k_rdv_publish, dim3(1), dim3(AUV_WAVE), 0, st, word, seq);
 }
 void auv_launch_rdv_arrive(unsigned long long* word, hipStream_t st) { hipLaunchKernelGGL(k_rdv_arrive, dim3(1), dim3(AUV_WAVE), 0, st, word); }
-void auv_launch_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, double limit_s, hipStream_t st) {
-  hipLaunchKernelGGL(k_rdv_wait, dim3(1), dim3(AUV_WAVE), 0, st, word, target, err, code, (unsigned long long)(limit_s * 1e8));
+void auv_launch_rdv_wait(const unsigned long long* word, unsigned long long target, int32_t* err, int code, double limit_s, int32_t* abort_flag,
+                         int32_t* report, hipStream_t st) {
+  hipLaunchKernelGGL(k_rdv_wait, dim3(1), dim3(AUV_WAVE), 0, st, word, target, err, code, (unsigned long long)(limit_s * 1e8), abort_flag, report);
 }
 
 void auv_launch_spin(unsigned long long ticks, hipStream_t st) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(AUV_WAVE), 0, st, ticks); }

@@ -289,3 +289,35 @@ def test_config4_shard_captured_chains_8192x256(one_graph):
     assert int(eager.read("COUNTERS")[:, 2].sum()) >= n     # every env turned over at least once
     assert chains.health()["timeouts"] == 0
     eager.close(), chains.close()
+
+
+def test_captured_chains_in_the_side_by_side_shape_walk_their_own_ring_positions():
+    """a captured chain whose slice steps in the three-launch shape (set_step_mode('side_by_side'), no LiDAR, or
+    hand-overs disabled after a failed probe) must advance ITS ring position -- the k23 launch used to advance it only for
+    the chain that holds environment 0, the other chains then replayed slot 0 for good.  Four captured chains, four steps per
+    replay, distinct actions per ring slot: bitwise what eager steps of the same shape compute."""
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    n, steps, ring, per = 1024, 24, 8, 4
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = 8, 8
+    cfg.episode.max_timesteps = 11
+    bank = _bank("mixed47", 32)
+    rs = np.random.RandomState(5)
+    acts = torch.as_tensor(rs.uniform([-1, -0.15], [1, 0.15], (ring, n, 2)), dtype=torch.float32, device="cuda:0")
+    eager = BatchedAuvEnv(cfg, bank, n, device="cuda:0", auto_reset=True)
+    chains = BatchedAuvEnv(cfg, bank, n, device="cuda:0", auto_reset=True)
+    eager.set_step_mode("side_by_side"), chains.set_step_mode("side_by_side")
+    eager.reset(), chains.reset()
+    chains.set_sub_batches(4, strict=True)
+    assert chains.effective_step_mode(n // 4) == "side_by_side"
+    chains.capture_graph_chains(torch.float32, slots=ring, steps=per).copy_(acts)
+    for t in range(steps):
+        obs, rew, done, _ = eager.step(acts[t % ring])
+        if t % per == per - 1:
+            o, r, d, _ = chains.step_graph()
+            torch.cuda.synchronize()
+            assert torch.equal(obs, o) and torch.equal(rew, r) and torch.equal(done, d), "captured side-by-side chains, step %d" % t
+    for f in ("STATE", "LIDAR_D", "OBS64", "INFO64", "COUNTERS", "WORLD_IDX"):
+        assert torch.equal(eager.read(f), chains.read(f)), f
+    assert int(eager.read("COUNTERS")[:, 2].sum()) >= n
+    eager.close(), chains.close()

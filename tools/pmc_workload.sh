@@ -9,14 +9,24 @@ mkdir -p $OUT
 cd $ROOT
 sha256sum gym_auv_amd/csrc/libauv_hip.so > $OUT/lib_sha256.txt
 B="$ROOT/bench.py --bank-cache /tmp/bank --workload $WL --sub-batches $SUB --probe-streams 0 --cpu-baseline 0"
-python $B --steps 20 "$@" > /dev/null 2>&1
+# Every pass says when it starts AND when it ends, and its stderr is APPENDED to $OUT/pmc_stderr.log (round 4: both went to
+# /dev/null, and a pass that sat behind a polling kernel for 300 s was killed for silence with nothing to read afterwards)
+ERR=$OUT/pmc_stderr.log
+: > $ERR
+pass() {   # pass <name> <stdout file> <command ...>
+  local name=$1 out=$2; shift 2
+  echo "  start $name $(date +%T)"
+  echo "==== $name: $*" >> $ERR
+  "$@" > $out 2>> $ERR
+  local rc=$?
+  echo "  done  $name rc=$rc $(date +%T)"
+  [ $rc = 0 ] || { tail -5 $ERR; exit $rc; }
+}
+pass warm_bank /dev/null python $B --steps 20 "$@"
 cd /tmp && export TMPDIR=/tmp
-echo "  pmc pass 1/3 (FETCH_SIZE)"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $B --steps 100 --warmup 100 "$@" > $OUT/pmc_fetch_bench.json 2>/dev/null
-echo "  pmc pass 2/3 (WRITE_SIZE)"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $B --steps 100 --warmup 100 "$@" > $OUT/pmc_write_bench.json 2>/dev/null
-echo "  pmc pass 3/3 (SQ counters)"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $B --steps 300 --warmup 1900 "$@" > $OUT/pmc_sq_bench.json 2>/dev/null
+pass "pmc pass 1/3 (FETCH_SIZE)" $OUT/pmc_fetch_bench.json rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $B --steps 100 --warmup 100 "$@"
+pass "pmc pass 2/3 (WRITE_SIZE)" $OUT/pmc_write_bench.json rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $B --steps 100 --warmup 100 "$@"
+pass "pmc pass 3/3 (SQ counters)" $OUT/pmc_sq_bench.json rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $B --steps 300 --warmup 1900 "$@"
 echo "  pmc passes done"
 cd $ROOT
 python tools/pmc_step_summary.py $OUT $SUB > $OUT/pmc_step_summary.json   # (checks $SUB against config.sub_batches of the passes)

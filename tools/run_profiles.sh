@@ -4,64 +4,59 @@
 # (FETCH_SIZE / WRITE_SIZE for HBM traffic, SQ counters for the VALU leg) of the headline configuration.
 # Usage: bash tools/run_profiles.sh <tag>   (outputs under gpurun_out/<tag>/; tools/publish_profiles.py copies what is judged)
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 sha256sum gym_auv_amd/csrc/libauv_hip.so > $OUT/lib_sha256.txt
+# Every pass says when it starts AND when it ends (a long pass otherwise looks hung to the GPU runner: round 4 lost two calls
+# to 420 s of silence), and the benches' stderr is APPENDED to $OUT/stderr.log under the pass's name -- never /dev/null.
+ERR=$OUT/stderr.log
+: > $ERR
+run() {   # run <name> <stdout file> <command ...>
+  local name=$1 out=$2; shift 2
+  echo "  start $name $(date +%T)"
+  echo "==== $name: $*" >> $ERR
+  "$@" > $out 2>> $ERR
+  local rc=$?
+  echo "  done  $name rc=$rc $(date +%T)"
+  [ $rc = 0 ] || tail -3 $ERR
+  return 0
+}
 B="python bench.py --bank-cache /tmp/bank"
-$B > $OUT/bench_polygons50.json 2> $OUT/bench_polygons50.err
-echo "  done bench_polygons50"
+run bench_polygons50 $OUT/bench_polygons50.json $B
 echo "headline: $(cut -c1-140 $OUT/bench_polygons50.json)"
-python bench.py --gpus 1 --steps 20 --warmup 5 --bank-cache /tmp/bank --cpu-baseline 0 > $OUT/bench_driver_command.json 2>/dev/null
-echo "  done bench_driver_command"
-for k in 1 2; do $B --sub-batches $k --cpu-baseline 0 > $OUT/bench_polygons50_sub$k.json 2>/dev/null; done
+run bench_driver_command $OUT/bench_driver_command.json python bench.py --gpus 1 --steps 20 --warmup 5 --bank-cache /tmp/bank --cpu-baseline 0
+for k in 1 2; do run bench_polygons50_sub$k $OUT/bench_polygons50_sub$k.json $B --sub-batches $k --cpu-baseline 0; done
 # the VecEnv protocol: a full rendezvous per step (round 4), by mechanism and chain count; one chain on the caller's stream
-$B --api async --sub-batches 1 --inline-first 1 --cpu-baseline 0 > $OUT/bench_polygons50_async_inline_sub1.json 2>/dev/null
-echo "  done bench_polygons50_async_inline_sub1"
+run bench_polygons50_async_inline_sub1 $OUT/bench_polygons50_async_inline_sub1.json $B --api async --sub-batches 1 --inline-first 1 --cpu-baseline 0
 for k in 2 4; do for r in device events cp; do
-  $B --api async --sub-batches $k --rendezvous $r --inline-first 1 --cpu-baseline 0 > $OUT/bench_polygons50_async_${r}_sub$k.json 2>/dev/null
+  run bench_polygons50_async_${r}_sub$k $OUT/bench_polygons50_async_${r}_sub$k.json $B --api async --sub-batches $k --rendezvous $r --inline-first 1 --cpu-baseline 0
 done; done
-$B --actions pilot --api step --cpu-baseline 0 > $OUT/bench_polygons50_pilot_step.json 2>/dev/null
-echo "  done bench_polygons50_pilot_step"
-$B --actions pilot --api async --sub-batches 2 --inline-first 1 --cpu-baseline 0 > $OUT/bench_polygons50_pilot_async_device_sub2.json 2>/dev/null
-echo "  done bench_polygons50_pilot_async_device_sub2"
-$B --actions pilot --sub-batches 2 --cpu-baseline 0 > $OUT/bench_polygons50_pilot_per_chain_sub2.json 2>/dev/null
-echo "  done bench_polygons50_pilot_per_chain_sub2"
-$B --step-mode side_by_side --sub-batches 1 --cpu-baseline 0 > $OUT/bench_polygons50_side_by_side_sub1.json 2>/dev/null
-echo "  done bench_polygons50_side_by_side_sub1"
+run bench_polygons50_pilot_step $OUT/bench_polygons50_pilot_step.json $B --actions pilot --api step --cpu-baseline 0
+run bench_polygons50_pilot_async_device_sub2 $OUT/bench_polygons50_pilot_async_device_sub2.json $B --actions pilot --api async --sub-batches 2 --inline-first 1 --cpu-baseline 0
+run bench_polygons50_pilot_per_chain_sub2 $OUT/bench_polygons50_pilot_per_chain_sub2.json $B --actions pilot --sub-batches 2 --cpu-baseline 0
+run bench_polygons50_side_by_side_sub1 $OUT/bench_polygons50_side_by_side_sub1.json $B --step-mode side_by_side --sub-batches 1 --cpu-baseline 0
 # captured steps: one chain (three-launch shape with the fused launch), captured chains (round 4), one graph with four branches
-$B --graph 16 --sub-batches 1 --steps 1920 --warmup 192 --cpu-baseline 0 > $OUT/bench_polygons50_graph16_sub1.json 2>/dev/null
-echo "  done bench_polygons50_graph16_sub1"
-$B --graph 16 --sub-batches 4 --steps 1920 --warmup 192 --cpu-baseline 0 > $OUT/bench_polygons50_graph16_chains4.json 2>/dev/null
-echo "  done bench_polygons50_graph16_chains4"
-$B --graph 16 --sub-batches 4 --one-graph 1 --steps 1920 --warmup 192 --cpu-baseline 0 > $OUT/bench_polygons50_graph16_one_graph4.json 2>/dev/null
-echo "  done bench_polygons50_graph16_one_graph4"
-$B --worlds-per-env 1 --cpu-baseline 0 > $OUT/bench_polygons50_worlds1.json 2>/dev/null
-echo "  done bench_polygons50_worlds1"
-$B --workload circles20 --cpu-baseline 0 > $OUT/bench_circles20.json 2>/dev/null
-echo "  done bench_circles20"
-$B --workload moving28 --cpu-baseline 0 > $OUT/bench_moving28.json 2>/dev/null
-echo "  done bench_moving28"
-$B --workload mixed47 --envs 8192 --cpu-baseline 0 > $OUT/bench_mixed47_8192.json 2>/dev/null
-echo "  done bench_mixed47_8192"
-$B --workload mixed47 --envs 8192 --graph 16 --sub-batches 1 --steps 1920 --warmup 192 --cpu-baseline 0 > $OUT/bench_mixed47_8192_graph16_sub1.json 2>/dev/null
-echo "  done bench_mixed47_8192_graph16_sub1"
-$B --workload mixed47 --envs 8192 --graph 16 --sub-batches 4 --steps 1920 --warmup 192 --cpu-baseline 0 > $OUT/bench_mixed47_8192_graph16_chains4.json 2>/dev/null
-echo "  done bench_mixed47_8192_graph16_chains4"
-$B --envs 32768 --steps 100 --warmup 20 --worlds-per-env 1 --cpu-baseline 0 > $OUT/bench_polygons50_32768.json 2>/dev/null
-echo "  done bench_polygons50_32768"
+run bench_polygons50_graph16_sub1 $OUT/bench_polygons50_graph16_sub1.json $B --graph 16 --sub-batches 1 --steps 1920 --warmup 192 --cpu-baseline 0
+run bench_polygons50_graph16_chains4 $OUT/bench_polygons50_graph16_chains4.json $B --graph 16 --sub-batches 4 --steps 1920 --warmup 192 --cpu-baseline 0
+run bench_polygons50_graph16_one_graph4 $OUT/bench_polygons50_graph16_one_graph4.json $B --graph 16 --sub-batches 4 --one-graph 1 --steps 1920 --warmup 192 --cpu-baseline 0
+run bench_polygons50_worlds1 $OUT/bench_polygons50_worlds1.json $B --worlds-per-env 1 --cpu-baseline 0
+run bench_circles20 $OUT/bench_circles20.json $B --workload circles20 --cpu-baseline 0
+run bench_moving28 $OUT/bench_moving28.json $B --workload moving28 --cpu-baseline 0
+run bench_mixed47_8192 $OUT/bench_mixed47_8192.json $B --workload mixed47 --envs 8192 --cpu-baseline 0
+run bench_mixed47_8192_graph16_sub1 $OUT/bench_mixed47_8192_graph16_sub1.json $B --workload mixed47 --envs 8192 --graph 16 --sub-batches 1 --steps 1920 --warmup 192 --cpu-baseline 0
+run bench_mixed47_8192_graph16_chains4 $OUT/bench_mixed47_8192_graph16_chains4.json $B --workload mixed47 --envs 8192 --graph 16 --sub-batches 4 --steps 1920 --warmup 192 --cpu-baseline 0
+run bench_polygons50_32768 $OUT/bench_polygons50_32768.json $B --envs 32768 --steps 100 --warmup 20 --worlds-per-env 1 --cpu-baseline 0
 # two ranks started by bench.py itself, sharing the one GPU of this box (gloo instead of RCCL): the N > 1 code path on hardware
-python bench.py --gpus 2 --rehearse 1 --steps 500 --warmup 100 --bank-cache /tmp/bank --cpu-baseline 0 > $OUT/bench_2ranks_rehearsal_1gpu.json 2> $OUT/bench_2ranks_rehearsal_1gpu.err
-echo "  done bench_2ranks_rehearsal_1gpu"
+run bench_2ranks_rehearsal_1gpu $OUT/bench_2ranks_rehearsal_1gpu.json python bench.py --gpus 2 --rehearse 1 --steps 500 --warmup 100 --bank-cache /tmp/bank --cpu-baseline 0
 python bench.py --gpus 2 --steps 10 > $OUT/bench_2ranks_refused.out 2>&1; echo "exit code $? (two ranks without --rehearse on a 1-GPU box must be refused)" >> $OUT/bench_2ranks_refused.out
-python tools/policy_bench.py 4096 > $OUT/policy_bench.log 2>&1
-python examples/ppo.py --envs 4096 --updates 6 --rollout 128 > $OUT/ppo_colav_fused_4096x128.log 2>&1
+run policy_bench $OUT/policy_bench.log python tools/policy_bench.py 4096
+run ppo_colav_fused_4096x128 $OUT/ppo_colav_fused_4096x128.log python examples/ppo.py --envs 4096 --updates 6 --rollout 128
 echo "benches done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --bank-cache /tmp/bank --cpu-baseline 0 > $OUT/bench_under_rocprof.json 2>/dev/null
-echo "  done bench_under_rocprof"
+run bench_under_rocprof $OUT/bench_under_rocprof.json rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --bank-cache /tmp/bank --cpu-baseline 0
 cd $ROOT
 python tools/trace_summary.py $OUT/trace/*/*_kernel_trace.csv > $OUT/kernel_trace_summary.txt
 python tools/trace_overlap.py $OUT/trace/*/*_kernel_trace.csv k_step_roles 4000 > $OUT/kernel_trace_overlap.txt
