@@ -14,7 +14,7 @@ from .config import Config
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libauv_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 AUV_REWARD_COLAV, AUV_REWARD_PATHFOLLOW = 0, 1
 AUV_CULL_REFERENCE, AUV_CULL_EXACT = 0, 1
@@ -22,11 +22,12 @@ AUV_F32, AUV_F64 = 0, 1
 AUV_RDV_EVENTS, AUV_RDV_DEVICE, AUV_RDV_CP = 0, 1, 2
 
 FIELDS = dict(STATE=0, LIDAR_D=1, OBS64=2, REWARD64=3, INFO64=4, WORLD_IDX=5, COUNTERS=6,
-              MOVER_STATE=7, NEARBY=8, EPISODE=9, CULL_LIMITS=10, NAV64=11, COLLISION=12, STAMPS=13, STEP_INFO=14, BROKEN=15)
+              MOVER_STATE=7, NEARBY=8, EPISODE=9, CULL_LIMITS=10, NAV64=11, COLLISION=12, STAMPS=13, STEP_INFO=14, BROKEN=15, FW_STATE=16, FW_SERIAL=17)
 FIELD_DTYPES = dict(STATE=np.float64, LIDAR_D=np.float64, OBS64=np.float64, REWARD64=np.float64,
                     INFO64=np.float64, WORLD_IDX=np.int32, COUNTERS=np.int32, MOVER_STATE=np.float64,
                     NEARBY=np.uint8, EPISODE=np.float64, CULL_LIMITS=np.int32, NAV64=np.float64,
-                    COLLISION=np.uint8, STAMPS=np.int64, STEP_INFO=np.float64, BROKEN=np.uint8)
+                    COLLISION=np.uint8, STAMPS=np.int64, STEP_INFO=np.float64, BROKEN=np.uint8,
+                    FW_STATE=np.int32, FW_SERIAL=np.int32)
 
 
 class AuvLibraryError(RuntimeError):
@@ -178,6 +179,10 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_set_step_mode": (C.c_int, [vp, i32]),
         "auv_feasibility_pooling": (C.c_int, [vp, vp, i32, C.c_double, vp, vp, vp]),
         "auv_generate_worlds": (C.c_int, [vp, i32, i32, i32, vp, i32, vp, vp, i32]),
+        "auv_fresh_worlds_create": (C.c_int, [vp, i32, i32, i32, C.c_uint64, C.c_int64, i32, i32, vp, vp, i32]),
+        "auv_fresh_worlds_refill": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), i32]),
+        "auv_fresh_worlds_stats": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+        "auv_fresh_worlds_draws": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), i32, vp, vp]),
         "auv_bank_bytes": (sz, [vp, i32]),
         "auv_read_bank": (C.c_int, [vp, i32, vp, sz, vp]),
         "auv_abi_version": (i32, []),
@@ -204,6 +209,7 @@ EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",
                     "auv_generate_worlds", "auv_bank_bytes", "auv_read_bank",
+                    "auv_fresh_worlds_create", "auv_fresh_worlds_refill", "auv_fresh_worlds_stats", "auv_fresh_worlds_draws",
                     "auv_abi_version", "auv_last_error"]
 
 # tables of a generated bank (auv_read_bank): id, dtype, trailing shape ('P' = AUV_GEN_POLY_CAP,

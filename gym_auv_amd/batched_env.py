@@ -20,7 +20,7 @@ import torch
 from . import _capi
 from ._capi import FIELD_DTYPES, FIELDS, AuvLibraryError, load_library, make_bank_struct, make_config
 from .config import Config
-from .devgen import GeneratedWorlds
+from .devgen import FreshWorlds, GeneratedWorlds
 from .spaces import Box
 from .world import BuiltWorld, build_world, pack_bank
 from .worldspec import WorldSpec
@@ -55,7 +55,11 @@ class BatchedAuvEnv:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _check(_LIB.auv_create(C.byref(self._cfg_struct), self.n_envs, idx, C.byref(self._h)), "auv_create")
         self._gen = None
-        if isinstance(worlds, GeneratedWorlds):
+        self._fresh = None
+        if isinstance(worlds, FreshWorlds):
+            # a fresh world on every reset: `depth` slots per environment, regenerated on the device as they are left
+            self.fresh_worlds(worlds)
+        elif isinstance(worlds, GeneratedWorlds):
             # worlds built on the device from random draws (devgen.py); no host-side bank at all
             self.generate(worlds)
         else:
@@ -69,12 +73,12 @@ class BatchedAuvEnv:
             bs, keep = make_bank_struct(bank)
             _check(_LIB.auv_load_worlds(self._h, C.byref(bs)), "auv_load_worlds")
             del keep
-        if auto_reset and self.n_worlds <= self.n_envs:
+        if auto_reset and self.n_worlds <= self.n_envs and self._fresh is None:
             # auto-reset rebinds env e to world (w + n_envs) % n_worlds: with no more worlds than envs that is the
             # world it has just finished (the reference draws a new scenario on every reset, movingobstacles.py:28-95)
             import warnings
             warnings.warn("BatchedAuvEnv: %d worlds for %d auto-resetting envs -- a finished episode restarts in the SAME world; "
-                          "give the bank at least 2 worlds per env (or regenerate it with env.generate()) for new scenarios"
+                          "give the bank at least 2 worlds per env, or pass worlds=FreshWorlds() for a new scenario on every reset"
                           % (self.n_worlds, self.n_envs), stacklevel=2)
         # observation_space / action_space exactly as environment.py:101-106, :139-143
         self.action_space = Box(low=np.array([-1, -0.15]), high=np.array([1, 0.15]), dtype=np.float32)
@@ -119,6 +123,7 @@ class BatchedAuvEnv:
         _check(_LIB.auv_load_worlds(self._h, C.byref(bs)), "auv_load_worlds")
         del keep
         self._gen = None
+        self._fresh = None
         self.n_worlds = int(bank["n_worlds"])
         self.k_max = max(1, int(bank["k_max"]))
         self.m_max = max(1, int(bank["m_max"]))
@@ -144,6 +149,8 @@ class BatchedAuvEnv:
             if m.numel() != self.n_envs:
                 raise ValueError("mask must have %d entries, got %d" % (self.n_envs, m.numel()))
         wi = None
+        if world_idx is not None and self._fresh is not None:
+            raise ValueError("reset(world_idx=...): with FreshWorlds the library binds an environment to its next unseen world")
         if world_idx is not None:
             wi = torch.as_tensor(world_idx).to(device=self.device, dtype=torch.int32).contiguous()
             if wi.numel() != self.n_envs:
@@ -488,12 +495,71 @@ class BatchedAuvEnv:
                                         C.c_void_p(draws.data_ptr()), nd, unit.ctypes.data_as(C.c_void_p),
                                         nseg.ctypes.data_as(C.c_void_p), len(nseg)), "auv_generate_worlds")
         self._gen = spec
+        self._fresh = None
         self._log_first = 0
         self.n_worlds = spec.n_worlds
         self.k_max = max(1, spec.n_moving + spec.n_static)
         self.m_max = max(1, spec.n_moving)
         self._graph_actions = None
         return draws
+
+    def fresh_worlds(self, spec: "FreshWorlds"):
+        """Switch to a fresh world on every reset (auv_fresh_worlds_create): builds the bank of depth * n_envs slots on the
+        device from the counter-based draws of (seed, global environment index, serial) and resets every environment."""
+        from . import devgen
+        if not self._cfg_struct.auto_reset:
+            raise ValueError("FreshWorlds needs auto_reset=True")
+        unit, nseg = devgen.ring_tables()
+        unit = np.ascontiguousarray(unit, dtype=np.float64)
+        nseg = np.ascontiguousarray(nseg, dtype=np.int32)
+        torch.cuda.synchronize(self.device)
+        _check(_LIB.auv_fresh_worlds_create(self._h, int(spec.depth), int(spec.n_moving), int(spec.n_static), int(spec.seed),
+                                            int(spec.env_index_base), int(spec.batch_cap), int(spec.period),
+                                            unit.ctypes.data_as(C.c_void_p), nseg.ctypes.data_as(C.c_void_p), len(nseg)),
+               "auv_fresh_worlds_create")
+        self._fresh = spec
+        self._gen = GeneratedWorlds(n_worlds=spec.depth * self.n_envs, n_moving=spec.n_moving, n_static=spec.n_static, seed=spec.seed)
+        self._log_first = 0
+        self.n_worlds = spec.depth * self.n_envs
+        self.k_max = max(1, spec.n_moving + spec.n_static)
+        self.m_max = max(1, spec.n_moving)
+        self._graph_actions = None
+
+    def _chains(self):
+        """(n_slices, bounds, streams) of the way the batch is being stepped: the sub-batch chains, or the caller's stream."""
+        if self._slices is not None:
+            return self.sub_batches, self._bounds_c, self._streams_c
+        return 1, (C.c_int32 * 2)(0, self.n_envs), (C.c_void_p * 1)(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def refill(self, flush: bool = False):
+        """Fresh worlds: publish the refill passes that have completed and start another (auv_fresh_worlds_refill).  The step
+        calls of the whole batch do this by themselves every `period` calls; a loop that steps slices one by one
+        (step_slice) calls it.  `flush`: synchronise, then run passes until every slot left so far is ready again."""
+        if self._fresh is None:
+            raise RuntimeError("refill(): the env was not built with worlds=FreshWorlds(...)")
+        k, b, st = self._chains()
+        _check(_LIB.auv_fresh_worlds_refill(self._h, k, b, st, int(bool(flush))), "auv_fresh_worlds_refill")
+
+    def fresh_stats(self) -> Dict[str, int]:
+        """`regenerated` worlds built and published since the mode was entered, `reused`: episodes that started in the world
+        they had just finished because their next slot was not ready (should stay 0), `queued` slots waiting for a pass,
+        `passes_issued` / `passes_published`, `depth`, `batch_cap`.  Synchronising (one small device-to-host copy)."""
+        out = (C.c_int64 * 8)()
+        _check(_LIB.auv_fresh_worlds_stats(self._h, out), "auv_fresh_worlds_stats")
+        return dict(on=int(out[0]), regenerated=int(out[1]), reused=int(out[2]), queued=int(out[3]), passes_issued=int(out[4]),
+                    passes_published=int(out[5]), depth=int(out[6]), batch_cap=int(out[7]))
+
+    def fresh_draws(self, envs, serials) -> torch.Tensor:
+        """[k, n_draws] float64: the draws of the worlds (environment envs[i] of this handle, serial serials[i]) -- what
+        devgen.world_from_draws rebuilds the world from on the host."""
+        from . import devgen
+        envs = np.ascontiguousarray(envs, dtype=np.int32)
+        serials = np.ascontiguousarray(serials, dtype=np.int32)
+        nd = devgen.n_draws(self._fresh.n_moving, self._fresh.n_static)
+        out = torch.empty((len(envs), nd), dtype=torch.float64, device=self.device)
+        _check(_LIB.auv_fresh_worlds_draws(self._h, envs.ctypes.data_as(C.POINTER(C.c_int32)), serials.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           len(envs), C.c_void_p(out.data_ptr()), self._stream()), "auv_fresh_worlds_draws")
+        return out
 
     def read_bank(self, name: str) -> torch.Tensor:
         """A table of the generated bank, [W, ...] in slot layout (see _capi.BANK_TABLES)."""
@@ -513,7 +579,8 @@ class BatchedAuvEnv:
         n, S = self.n_envs, self.n_sensors
         return dict(STATE=(6, n), LIDAR_D=(n, S), OBS64=(n, 6 + S), REWARD64=(n,), INFO64=(n, 8),
                     WORLD_IDX=(n,), COUNTERS=(n, 4), MOVER_STATE=(n, self.m_max, 4), NEARBY=(n, self.k_max),
-                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,), STAMPS=(n, 16), STEP_INFO=(n, 4), BROKEN=(n,))[name]
+                    EPISODE=(n, 4), CULL_LIMITS=(n, self.k_max, 2), NAV64=(n, 8), COLLISION=(n,), STAMPS=(n, 16), STEP_INFO=(n, 4), BROKEN=(n,),
+                    FW_STATE=(self.n_worlds,), FW_SERIAL=(self.n_worlds,))[name]
 
     def read(self, name: str) -> torch.Tensor:
         t = torch.empty(self.field_shape(name), dtype=_TORCH_DTYPES[FIELD_DTYPES[name]], device=self.device)

@@ -24,7 +24,8 @@ void auv_launch_k3_nav(const AuvDev& d, float* obs, hipStream_t st);
 void auv_launch_k3_reward(const AuvDev& d, float* obs, float* reward, uint8_t* done, int lidar_obs, hipStream_t st,
                           hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_reset(const AuvDev& d, const uint8_t* mask, const int32_t* world_idx, float* obs, hipStream_t st);
-void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st);
+void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st, const int32_t* count_dev = nullptr);
+void auv_launch_fw_shadow_reset(const AuvDev& d, const int32_t* count_dev, hipStream_t st);
 void auv_launch_refresh_desc(const AuvDev& d, hipStream_t st);
 void auv_launch_derive(const AuvDev& d, hipStream_t st);
 size_t auv_k2_lds_bytes(const AuvDev& d);
@@ -104,9 +105,29 @@ struct auv_handle {
   std::vector<hipGraph_t> chain_graph;
   std::vector<hipGraphExec_t> chain_exec;
   std::vector<hipStream_t> fork_streams;   // side streams of the one-graph (fork / join) form
+  std::vector<int32_t> chain_bounds;       // the slices of the captured chains
+  int chain_steps = 1, graph_steps = 1;    // steps per replay of the captured chains / of the one graph
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
   GenOut gen;
+  // a fresh world on every reset (auv_fresh_worlds_create): the refill pass and its bookkeeping
+  struct Fresh {
+    bool on = false;
+    int depth = 0, cap = 0, period = 0, n_draws = 0;
+    unsigned long long seed = 0;
+    long long env_base = 0;
+    hipStream_t side = nullptr;               // the refill pass's stream (lowest priority: a queue of its own)
+    std::vector<void*> allocs;                // shadow environments + queue / state words
+    AuvDev shadow;                            // `cap` environments nobody steps: where a regenerated slot's reset rows are computed
+    FwBatch batch;                            // device: the pass in flight on `side`
+    int32_t* batch_block = nullptr;           // [1 + 3 cap]: count, slot[], env[], serial[] (one D2H copy per pass)
+    double* draws = nullptr;                  // [cap][n_draws]
+    int32_t* env_next_serial = nullptr;       // [N]
+    static const int NB = 4;                  // passes the host may have in flight (pinned read-back buffers)
+    int32_t* pinned[NB] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done[NB] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long issued = 0, published = 0, calls = 0, regenerated = 0;
+  } fw;
 };
 
 // From how many environments per launch on the three-launch shape is used by AUV_STEP_AUTO.  With the four-role step
@@ -138,6 +159,7 @@ static void drop_graphs(auv_handle* h) {
 }
 
 static int recover_from_timeout(auv_handle* h, float* obs_now);
+static int check_slices(const auv_handle* h, int32_t n_slices, const int32_t* bounds, const void* streams, const char* who);
 static int probe_dispatch_order(auv_handle* h);
 
 // A wave of the one-launch step that gave up polling has left its environment's step unfinished.  The
@@ -518,6 +540,100 @@ static int rdv_trial(auv_handle* h, hipStream_t cs) {
   return AUV_OK;
 }
 
+// ---- a fresh world on every reset: the refill pass (host side) -------------------------------------------------------------
+// The reference builds a new scenario whenever an episode ends (environment.py:176-218 reset -> _generate,
+// envs/movingobstacles.py:28-95).  Here (auv_device.h: auv_next_world) a finished environment moves to its next bank slot and
+// queues the slot it leaves; this pass -- enqueued on a low-priority side stream every `period` step calls, never waited for by
+// the step path -- pops up to `cap` queued slots ON THE DEVICE, draws their worlds from the counter-based generator
+// (seed, global environment index, serial), rebuilds their tables (k5_generate) and their reset rows (the step's own fresh-list
+// kernels on `cap` shadow environments), and copies the list of what it did to pinned host memory.  When the host SEES the
+// pass complete (hipEventQuery at a later step call: no wait), it enqueues a publish kernel on the stream of every chain that
+// owns one of the slots; only that kernel makes a slot bindable.  So every launch that can bind a regenerated slot was
+// enqueued -- and therefore started -- after the slot's tables were complete in memory: visibility rides on kernel boundaries,
+// nothing in the step path fences, and the step path never waits for the generator.
+static void fw_disable(auv_handle* h) {
+  auv_handle::Fresh& f = h->fw;
+  if (f.side) (void)hipStreamSynchronize(f.side);
+  for (int b = 0; b < auv_handle::Fresh::NB; b++) {
+    if (f.done[b]) (void)hipEventDestroy(f.done[b]);
+    if (f.pinned[b]) (void)hipHostFree(f.pinned[b]);
+    f.done[b] = nullptr, f.pinned[b] = nullptr;
+  }
+  if (f.side) (void)hipStreamDestroy(f.side);
+  f.side = nullptr;
+  free_pool(f.allocs);
+  f.on = false;
+  f.issued = f.published = f.calls = f.regenerated = 0;
+  h->d.fw_state = nullptr, h->d.fw_serial = nullptr, h->d.fw_queue = nullptr, h->d.fw_ctl = nullptr, h->d.fw_cap = 0;
+}
+
+static int fw_enqueue_pass(auv_handle* h) {
+  auv_handle::Fresh& f = h->fw;
+  const int b = (int)(f.issued % auv_handle::Fresh::NB);
+  const AuvDev& d = h->d;
+  const int grid = f.cap < h->gen_grid ? f.cap : h->gen_grid;
+  auv_launch_fw_bind(f.batch, d.fw_queue, d.fw_ctl, d.fw_cap, d.n, f.cap, f.env_next_serial, f.shadow.world_idx, f.shadow.fresh_count, f.side);
+  auv_launch_draws(f.draws, f.n_draws, h->gen_moving, h->gen_static, f.seed, f.env_base, f.batch.env, f.batch.serial, f.cap, f.batch.count, grid, f.side);
+  auv_launch_generate(h->gen, f.draws, 0, f.cap, grid, f.side, f.batch.slot, f.batch.count);
+  auv_launch_fw_shadow_reset(f.shadow, f.batch.count, f.side);
+  auv_launch_k2_fresh(f.shadow, f.side);
+  auv_launch_k3_fresh(f.shadow, nullptr, f.side);
+  auv_launch_harvest(f.shadow, f.cap, f.side, f.batch.count);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(f.pinned[b], f.batch_block, (size_t)(1 + 3 * f.cap) * sizeof(int32_t), hipMemcpyDeviceToHost, f.side));
+  HIP_TRY(hipEventRecord(f.done[b], f.side));
+  f.issued += 1;
+  return AUV_OK;
+}
+
+// passes the host can see complete -> publish kernels on the chains' streams (slice i = [bounds[i], bounds[i + 1]) runs on streams[i])
+static int fw_publish_ready(auv_handle* h, int n_slices, const int32_t* bounds, void* const* streams) {
+  auv_handle::Fresh& f = h->fw;
+  while (f.published < f.issued) {
+    const int b = (int)(f.published % auv_handle::Fresh::NB);
+    const hipError_t q = hipEventQuery(f.done[b]);
+    if (q == hipErrorNotReady) {
+      (void)hipGetLastError();
+      break;
+    }
+    HIP_TRY(q);
+    const int32_t* blk = f.pinned[b];
+    const int count = blk[0];
+    for (int c0 = 0; c0 < count; c0 += AUV_FW_LIST) {
+      FwList l;
+      l.count = count - c0 < AUV_FW_LIST ? count - c0 : AUV_FW_LIST;
+      for (int i = 0; i < l.count; i++) l.slot[i] = blk[1 + c0 + i], l.serial[i] = blk[1 + 2 * f.cap + c0 + i];
+      for (int s = 0; s < n_slices; s++) {
+        bool any = false;
+        for (int i = 0; i < l.count && !any; i++) {
+          const int e = blk[1 + f.cap + c0 + i];
+          any = e >= bounds[s] && e < bounds[s + 1];
+        }
+        if (any) auv_launch_fw_publish(l, bounds[s], bounds[s + 1] - bounds[s], h->d.n, h->d.fw_state, h->d.fw_serial, (hipStream_t)streams[s]);
+      }
+    }
+    HIP_TRY(hipGetLastError());
+    f.regenerated += (unsigned long long)count;
+    f.published += 1;
+  }
+  return AUV_OK;
+}
+
+// once per step call of the whole batch (the callers name the chains' streams): publish what is complete; every `period`-th call
+// start a new pass if a read-back buffer is free.  Never waits.  Skipped while a stream is being captured.
+static int fw_tick(auv_handle* h, int n_slices, const int32_t* bounds, void* const* streams, int n_steps = 1) {
+  auv_handle::Fresh& f = h->fw;
+  if (!f.on) return AUV_OK;
+  for (int s = 0; s < n_slices; s++)
+    if (stream_capturing((hipStream_t)streams[s])) return AUV_OK;
+  int rc = fw_publish_ready(h, n_slices, bounds, streams);
+  if (rc) return rc;
+  const unsigned long long before = f.calls / (unsigned long long)f.period;
+  f.calls += (unsigned long long)n_steps;
+  if (f.calls / (unsigned long long)f.period != before && f.issued - f.published < (unsigned long long)auv_handle::Fresh::NB) rc = fw_enqueue_pass(h);
+  return rc;
+}
+
 extern "C" {
 
 int32_t auv_abi_version(void) { return AUV_ABI_VERSION; }
@@ -569,6 +685,7 @@ int auv_destroy(auv_handle_t* h) {
   if (!h) return AUV_OK;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+  fw_disable(h);
   drop_graphs(h);
   if (h->graph) (void)hipGraphDestroy(h->graph);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -593,6 +710,7 @@ int auv_load_worlds(auv_handle_t* h, const auv_world_bank_t* b) {
   if (!h || !b || b->n_worlds <= 0) return fail(AUV_EINVAL, "auv_load_worlds: bad arguments");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
+  fw_disable(h);
   free_pool(h->bank_allocs);
   AuvDev& d = h->d;
   const int W = b->n_worlds;
@@ -730,6 +848,7 @@ int auv_generate_worlds(auv_handle_t* h, int32_t n_worlds, int32_t n_moving, int
     return fail(AUV_EINVAL, "auv_generate_worlds: draws must be device memory");
   }
   HIP_TRY(hipDeviceSynchronize());
+  fw_disable(h);
   AuvDev& d = h->d;
   GenOut& g = h->gen;
   const int W = n_worlds, K = n_moving + n_static, M = n_moving;
@@ -808,6 +927,172 @@ int auv_generate_worlds(auv_handle_t* h, int32_t n_worlds, int32_t n_moving, int
   return AUV_OK;
 }
 
+int auv_fresh_worlds_create(auv_handle_t* h, int32_t depth, int32_t n_moving, int32_t n_static, uint64_t seed, int64_t env_index_base,
+                            int32_t batch_cap, int32_t period, const double* ring_unit, const int32_t* nseg_by_radius, int32_t n_radius) {
+  if (!h || depth < 2 || depth > 8 || batch_cap < 1 || batch_cap > 4096 || period < 1 || env_index_base < 0)
+    return fail(AUV_EINVAL, "auv_fresh_worlds_create: depth in [2, 8], batch_cap in [1, 4096], period >= 1, env_index_base >= 0");
+  if (!h->d.cfg.auto_reset) return fail(AUV_EINVAL, "auv_fresh_worlds_create: needs auto_reset (the turn-over is the auto-reset's)");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  fw_disable(h);
+  const int n = h->d.n;
+  const long long Wll = (long long)depth * n;
+  if (Wll > (1ll << 30)) return fail(AUV_EINVAL, "auv_fresh_worlds_create: %lld world slots", Wll);
+  const int W = (int)Wll;
+  const int nd = 11 + n_moving * (3 * GEN_CAND + 2) + n_static * 3 * GEN_CAND;
+  // ---- the initial bank: slot e + j N holds the world of (seed, env_index_base + e, serial j) ----
+  {
+    std::vector<void*> tmp;
+    double* draws = nullptr;
+    int32_t *envs = nullptr, *serials = nullptr;
+    int rc = dev_alloc(tmp, &draws, (size_t)W * nd);
+    rc |= dev_alloc(tmp, &envs, (size_t)W);
+    rc |= dev_alloc(tmp, &serials, (size_t)W);
+    if (rc) {
+      free_pool(tmp);
+      return AUV_ENOMEM;
+    }
+    std::vector<int32_t> he(W), hs(W);
+    for (int s = 0; s < W; s++) he[s] = s % n, hs[s] = s / n;
+    hipError_t e1 = hipMemcpy(envs, he.data(), (size_t)W * 4, hipMemcpyHostToDevice), e2 = hipMemcpy(serials, hs.data(), (size_t)W * 4, hipMemcpyHostToDevice);
+    auv_launch_draws(draws, nd, n_moving, n_static, seed, env_index_base, envs, serials, W, nullptr, W < 1024 ? W : 1024, nullptr);
+    hipError_t e3 = hipDeviceSynchronize();
+    rc = (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) ? fail(AUV_EHIP, "auv_fresh_worlds_create: draws: %s", hipGetErrorString(e3))
+                                                                   : auv_generate_worlds(h, W, n_moving, n_static, draws, nd, ring_unit, nseg_by_radius, n_radius);
+    free_pool(tmp);
+    if (rc) return rc;
+  }
+  // ---- the mode's own state ----
+  auv_handle::Fresh& f = h->fw;
+  AuvDev& d = h->d;
+  f.depth = depth, f.cap = batch_cap, f.period = period, f.n_draws = nd, f.seed = seed, f.env_base = env_index_base;
+  auto& ap = f.allocs;
+  int rc = 0;
+  rc |= dev_alloc(ap, &d.fw_state, (size_t)W);
+  rc |= dev_alloc(ap, &d.fw_serial, (size_t)W);
+  rc |= dev_alloc(ap, &d.fw_queue, (size_t)W);
+  rc |= dev_alloc(ap, &d.fw_ctl, 8);
+  rc |= dev_alloc(ap, &f.env_next_serial, (size_t)n);
+  rc |= dev_alloc(ap, &f.batch_block, (size_t)(1 + 3 * batch_cap));
+  rc |= dev_alloc(ap, &f.draws, (size_t)batch_cap * nd);
+  d.fw_cap = W;
+  f.batch.count = f.batch_block, f.batch.slot = f.batch_block + 1, f.batch.env = f.batch_block + 1 + batch_cap, f.batch.serial = f.batch_block + 1 + 2 * batch_cap;
+  // shadow environments: the handle's descriptor with `cap` environments of their own and w_ready = 0 (restore -> fresh list)
+  AuvDev& sh = f.shadow;
+  sh = d;
+  const size_t c = (size_t)batch_cap, S = (size_t)d.cfg.n_sensors;
+  sh.n = batch_cap, sh.e0 = 0, sh.ne = batch_cap, sh.w_ready = 0, sh.self = nullptr;
+  sh.fw_state = nullptr, sh.fw_serial = nullptr, sh.fw_queue = nullptr, sh.fw_ctl = nullptr;
+  rc |= dev_alloc(ap, &sh.state, 6 * c);
+  rc |= dev_alloc(ap, &sh.world_idx, c);
+  rc |= dev_alloc(ap, &sh.env_desc, c);
+  rc |= dev_alloc(ap, &sh.counters, c);
+  rc |= dev_alloc(ap, &sh.lidar_d, c * S);
+  rc |= dev_alloc(ap, &sh.obs64, c * (6 + S));
+  rc |= dev_alloc(ap, &sh.reward64, c);
+  rc |= dev_alloc(ap, &sh.info64, c * 8);
+  rc |= dev_alloc(ap, &sh.nav64, c * 8);
+  rc |= dev_alloc(ap, &sh.mover, c * d.m_max);
+  rc |= dev_alloc(ap, &sh.nearby, c * d.k_max);
+  rc |= dev_alloc(ap, &sh.episode, c * 4);
+  rc |= dev_alloc(ap, &sh.limits, c * d.k_max);
+  rc |= dev_alloc(ap, &sh.collision, c);
+  rc |= dev_alloc(ap, &sh.step_info, c * 4);
+  rc |= dev_alloc(ap, &sh.fresh_count, 4);
+  rc |= dev_alloc(ap, &sh.fresh_list, c);
+  rc |= dev_alloc(ap, &sh.stamps, c * 16);
+  rc |= dev_alloc(ap, &sh.rew_path, c);
+  rc |= dev_alloc(ap, &sh.rew_lidar, c);
+  if (rc) {
+    fw_disable(h);
+    return AUV_ENOMEM;
+  }
+  {
+    std::vector<int32_t> st(W), se(W), q(W, -1), ns(n, depth);
+    for (int s = 0; s < W; s++) st[s] = s < n ? AUV_FW_IN_USE : AUV_FW_READY, se[s] = s / n;
+    HIP_TRY(hipMemcpy(d.fw_state, st.data(), (size_t)W * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.fw_serial, se.data(), (size_t)W * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.fw_queue, q.data(), (size_t)W * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(f.env_next_serial, ns.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  int lo = 0, hi = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo: the numerically greatest = least priority
+  HIP_TRY(hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, lo));
+  for (int b = 0; b < auv_handle::Fresh::NB; b++) {
+    HIP_TRY(hipHostMalloc((void**)&f.pinned[b], (size_t)(1 + 3 * batch_cap) * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&f.done[b], hipEventDisableTiming));
+  }
+  HIP_TRY(hipMemcpy((void*)d.self, &d, sizeof(AuvDev), hipMemcpyHostToDevice));   // the one-launch step reads its tables through this copy
+  HIP_TRY(hipDeviceSynchronize());
+  f.on = true;
+  return AUV_OK;
+}
+
+int auv_fresh_worlds_refill(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, int32_t flush) {
+  REQUIRE_READY(h);
+  if (!h->fw.on) return fail(AUV_ESTATE, "auv_fresh_worlds_refill: auv_fresh_worlds_create first");
+  int rc = check_slices(h, n_slices, bounds, streams, "auv_fresh_worlds_refill");
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  auv_handle::Fresh& f = h->fw;
+  if (!flush) {
+    rc = fw_publish_ready(h, n_slices, bounds, streams);
+    if (rc == AUV_OK && f.issued - f.published < (unsigned long long)auv_handle::Fresh::NB) rc = fw_enqueue_pass(h);
+    return rc;
+  }
+  // flush: until the queue is empty -- every slot an environment has left so far is READY again when this returns (the
+  // chains' streams are synchronised first: their finish waves have queued what they will queue)
+  for (int s = 0; s < n_slices; s++) HIP_TRY(hipStreamSynchronize((hipStream_t)streams[s]));
+  for (int pass = 0; pass < (1 << 20); pass++) {
+    HIP_TRY(hipStreamSynchronize(f.side));
+    rc = fw_publish_ready(h, n_slices, bounds, streams);
+    if (rc) return rc;
+    unsigned int ctl[2] = {0, 0};
+    HIP_TRY(hipMemcpy(ctl, h->d.fw_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+    if (ctl[0] == ctl[1] && f.issued == f.published) break;
+    if (f.issued == f.published) {
+      rc = fw_enqueue_pass(h);
+      if (rc) return rc;
+    }
+  }
+  for (int s = 0; s < n_slices; s++) HIP_TRY(hipStreamSynchronize((hipStream_t)streams[s]));
+  return AUV_OK;
+}
+
+int auv_fresh_worlds_stats(auv_handle_t* h, int64_t* out8) {
+  if (!h || !out8) return fail(AUV_EINVAL, "auv_fresh_worlds_stats: bad arguments");
+  for (int i = 0; i < 8; i++) out8[i] = 0;
+  const auv_handle::Fresh& f = h->fw;
+  if (!f.on) return AUV_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  unsigned int ctl[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(ctl, h->d.fw_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+  out8[0] = 1, out8[1] = (int64_t)f.regenerated, out8[2] = (int64_t)ctl[2], out8[3] = (int64_t)(unsigned int)(ctl[0] - ctl[1]);
+  out8[4] = (int64_t)f.issued, out8[5] = (int64_t)f.published, out8[6] = f.depth, out8[7] = f.cap;
+  return AUV_OK;
+}
+
+int auv_fresh_worlds_draws(auv_handle_t* h, const int32_t* envs_host, const int32_t* serials_host, int32_t n_rows, double* dst_dev, void* stream) {
+  REQUIRE_READY(h);
+  if (!h->fw.on) return fail(AUV_ESTATE, "auv_fresh_worlds_draws: auv_fresh_worlds_create first");
+  if (!envs_host || !serials_host || n_rows < 1 || !dst_dev) return fail(AUV_EINVAL, "auv_fresh_worlds_draws: bad arguments");
+  HIP_TRY(hipSetDevice(h->device));
+  const auv_handle::Fresh& f = h->fw;
+  int32_t* keys = nullptr;
+  HIP_TRY(hipMalloc((void**)&keys, (size_t)2 * n_rows * sizeof(int32_t)));
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(keys, envs_host, (size_t)n_rows * 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(keys + n_rows, serials_host, (size_t)n_rows * 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    auv_launch_draws(dst_dev, f.n_draws, h->gen_moving, h->gen_static, f.seed, f.env_base, keys, keys + n_rows, n_rows, nullptr, n_rows < 1024 ? n_rows : 1024, st);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(keys);
+  HIP_TRY(e);
+  return AUV_OK;
+}
+
 static const void* bank_ptr(const auv_handle_t* h, int32_t table, size_t* bytes) {
   const AuvDev& d = h->d;
   // sizes are only known for a generated (slot) bank; a packed upload is already on the host
@@ -851,6 +1136,8 @@ int auv_read_bank(auv_handle_t* h, int32_t table, void* dst_dev, size_t bytes, v
 int auv_reset(auv_handle_t* h, const uint8_t* mask_dev, const int32_t* world_idx_dev, float* obs_dev, void* stream) {
   REQUIRE_READY(h);
   hipStream_t st = (hipStream_t)stream;
+  if (h->fw.on && world_idx_dev)
+    return fail(AUV_EINVAL, "auv_reset: with a fresh world per reset the library chooses the world (an environment's next unseen slot)");
   auv_launch_reset(h->d, mask_dev, world_idx_dev, obs_dev, st);
   HIP_TRY(hipGetLastError());
   return AUV_OK;
@@ -910,6 +1197,11 @@ int auv_step(auv_handle_t* h, const void* actions_dev, int32_t action_dtype, flo
   int rc = check_actions(actions_dev, action_dtype, "auv_step");
   if (rc) return rc;
   PAIR_CHECK_ON(h, stream, true, obs_dev);
+  if (h->fw.on) {
+    const int32_t whole[2] = {0, h->d.n};
+    rc = fw_tick(h, 1, whole, &stream);
+    if (rc) return rc;
+  }
   rc = enqueue_step(h, effective_mode(h, h->d.n), 0, h->d.n, actions_dev, action_dtype, obs_dev, reward_dev, done_dev,
                     (hipStream_t)stream, false);
   if (rc) return rc;
@@ -938,6 +1230,7 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
   rc = check_slices(h, n_slices, bounds, streams, "auv_step_pipelined");
   if (rc) return rc;
   PAIR_CHECK(h, obs_dev);
+  rc = fw_tick(h, n_slices, bounds, streams);
   for (int i = 0; i < n_slices && rc == AUV_OK; i++)
     rc = enqueue_step(h, effective_mode(h, bounds[i + 1] - bounds[i]), bounds[i], bounds[i + 1] - bounds[i], actions_dev, action_dtype,
                       obs_dev, reward_dev, done_dev, (hipStream_t)streams[i], false);
@@ -958,6 +1251,8 @@ int auv_step_async(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, voi
   if (h->async_pending) return fail(AUV_ESTATE, "auv_step_async: the previous step has not been waited for (auv_step_wait)");
   PAIR_CHECK(h, obs_dev);
   HIP_TRY(hipSetDevice(h->device));
+  rc = fw_tick(h, n_slices, bounds, streams);
+  if (rc) return rc;
   hipStream_t cs = (hipStream_t)caller_stream;
   h->async_streams.clear();
   for (int i = 0; i < n_slices; i++)
@@ -1062,6 +1357,7 @@ int auv_graph_capture_chains(auv_handle_t* h, int32_t n_slices, const int32_t* b
   // every chain starts at slot 0 of the ring and keeps a position of its own (advanced by its own dynamics waves)
   HIP_TRY(hipMemset(h->d.ring_pos, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
   HIP_TRY(hipMemset(h->d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
+  h->chain_bounds.assign(bounds, bounds + n_slices + 1), h->chain_steps = n_steps, h->graph_steps = n_steps;
   if (!one_graph) {
     // K linear graphs, replayed on K streams of the caller's choice (auv_graph_launch_chains): which hardware queue a
     // chain runs on stays the caller's decision, as for eager chains
@@ -1121,6 +1417,10 @@ int auv_graph_launch_chains(auv_handle_t* h, int32_t n_slices, void* const* stre
   if (!streams || n_slices != (int32_t)h->chain_exec.size() || n_slices < 1)
     return fail(AUV_ESTATE, "auv_graph_launch_chains: %d streams for %d captured chains", n_slices, (int)h->chain_exec.size());
   PAIR_CHECK(h, nullptr);
+  {
+    int rc_t = fw_tick(h, n_slices, h->chain_bounds.data(), streams, h->chain_steps);
+    if (rc_t) return rc_t;
+  }
   for (int i = 0; i < n_slices; i++) HIP_TRY(hipGraphLaunch(h->chain_exec[i], (hipStream_t)streams[i]));
   return AUV_OK;
 }
@@ -1318,6 +1618,8 @@ static void* field_ptr(const auv_handle_t* h, int32_t field, size_t* bytes) {
     case AUV_FIELD_STAMPS: *bytes = 8 * 16 * n; return d.stamps;
     case AUV_FIELD_STEP_INFO: *bytes = 8 * 4 * n; return d.step_info;
     case AUV_FIELD_BROKEN: *bytes = n; return d.broken;
+    case AUV_FIELD_FW_STATE: *bytes = d.fw_state ? 4 * (size_t)d.n_worlds : 0; return d.fw_state;
+    case AUV_FIELD_FW_SERIAL: *bytes = d.fw_serial ? 4 * (size_t)d.n_worlds : 0; return d.fw_serial;
   }
   *bytes = 0;
   return nullptr;
@@ -1417,13 +1719,15 @@ int auv_policy_rollout(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
   // t0 / gstep0 (per slice; both or neither): the host names every launch's rollout position and generator step (this is a
   // plain loop of launches, the values are known here) -- the launches then neither read nor count off on io.ctr, which
   // is worth ~4 us per launch.  NULL: the device counters, as auv_policy_act.
-  for (int32_t k = 0; k < n_steps; k++)
+  for (int32_t k = 0; k < n_steps; k++) {
+    if (rc == AUV_OK) rc = fw_tick(h, n_slices, bounds, streams);
     for (int i = 0; i < n_slices && rc == AUV_OK; i++) {
       const int ne = bounds[i + 1] - bounds[i];
       auv_launch_policy(ios[i], bounds[i], ne, (hipStream_t)streams[i], t0 ? t0[i] + k : -1, t0 ? gstep0[i] + k : -1);
       rc = enqueue_step(h, effective_mode(h, ne), bounds[i], ne, ios[i].actions_out, AUV_F32, obs_dev, reward_dev, done_dev,
                         (hipStream_t)streams[i], false);
     }
+  }
   if (rc) return rc;
   if (flush)
     for (int i = 0; i < n_slices; i++)
@@ -1462,6 +1766,7 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
   // stack, and inside a graph of several steps the fused reward + dynamics launch makes up for more of that than the
   // one launch does -- 97.6 M against 96.6 M env-steps/s at 16 steps per graph, 95.3 against 90.6 M at 8192 x 256 --
   // and the bits are the same.  A graph of ONE step keeps the handle's own shape.)
+  h->graph_steps = n_steps;
   const bool fuse = n_steps > 1 && auv_k23_ok(h->d) && h->d.cfg.use_lidar;
   const int mode = fuse ? AUV_STEP_SIDE_BY_SIDE : effective_mode(h, h->d.n);
   for (int32_t k = 0; k < n_steps && rc == AUV_OK; k++)
@@ -1478,6 +1783,11 @@ int auv_graph_launch(auv_handle_t* h, void* stream) {
   REQUIRE_READY(h);
   if (!h->graph_exec) return fail(AUV_ESTATE, "auv_graph_launch: no captured graph");
   PAIR_CHECK(h, nullptr);
+  if (h->fw.on) {
+    const int32_t whole[2] = {0, h->d.n};
+    int rc_t = fw_tick(h, 1, whole, &stream, h->graph_steps);
+    if (rc_t) return rc_t;
+  }
   HIP_TRY(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
   return AUV_OK;
 }

@@ -118,7 +118,49 @@ struct AuvDev {
   int32_t ring_slots;   // 1 = plain action buffer
   int32_t ring_slot_host; // -1: read ring_pos and advance it; -2: read it, another kernel of the step advances it; >= 0: the host names the slot
   unsigned long long* stamps;  // [N][16] per-env phase cycle counts (diagnostic builds, -DAUV_STAMPS)
+  // ---- a fresh world on every reset (auv_fresh_worlds_create; SURVEY 8(f) F1: generation joined to auto-reset) ----
+  // The bank is D slots per environment (slot e + j N belongs to environment e); an environment whose episode ends moves
+  // to its next slot IF that slot holds a world nobody has seen (READY), marks the slot it leaves STALE and queues it; a
+  // refill pass on a side stream (auv_capi.hip: fw_refill) pops the queue, rebuilds exactly those slots -- tables
+  // (k5_generate) and reset rows (the step's own kernels on a few shadow environments) -- and a publish kernel ON THE
+  // ENVIRONMENT'S OWN STREAM, enqueued after the host has seen the pass complete, flips them to READY: every step launch that
+  // can bind a regenerated slot started after the slot's tables were complete (kernel-boundary visibility, no fences).
+  int32_t* fw_state;     // [W] AUV_FW_READY / _IN_USE / _STALE, or nullptr: the bank cycles (w + N) % W as before
+  int32_t* fw_serial;    // [W] which world of its environment the slot holds: the world of (seed, environment, serial)
+  int32_t* fw_queue;     // [fw_cap] ring of stale slots (-1: empty entry); a slot is in it at most once
+  unsigned int* fw_ctl;  // [8] [0] tail (producers: finish waves of any chain), [1] head (the refill pass), [2] episodes that had to
+                         //     start in the world they had just finished because the next slot was not READY yet (stale re-use)
+  int32_t fw_cap;
 };
+
+enum { AUV_FW_READY = 0, AUV_FW_IN_USE = 1, AUV_FW_STALE = 2 };
+
+// The world an environment whose episode has just ended is bound to next (one lane calls this; environment.py:176-218 reset ->
+// _generate: the reference builds a new scenario on every reset).  Bank cycling: (w + N) % W.  Fresh worlds: the same slot
+// arithmetic, but only onto a READY slot, and the slot left behind is queued for regeneration; if the next slot is not READY
+// (the refill pass has fallen behind an episode that lasted only a few steps) the environment starts over in the world it has
+// just finished and the event is counted -- never silently.
+__device__ __forceinline__ int auv_next_world(const AuvDev& d, const int w) {
+  const int w2 = (int)(((long long)w + d.n) % d.n_worlds);
+  if (!d.fw_state) return w2;
+  if (w2 == w) return w;
+  if (__hip_atomic_load(d.fw_state + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != AUV_FW_READY) {
+    __hip_atomic_fetch_add(d.fw_ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return w;
+  }
+  __hip_atomic_store(d.fw_state + w2, AUV_FW_IN_USE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(d.fw_state + w, AUV_FW_STALE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned int at = __hip_atomic_fetch_add(d.fw_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(d.fw_queue + (at % (unsigned int)d.fw_cap), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return w2;
+}
+// the same for a whole wave with a wave-uniform `w`: lane 0 takes the decision (and the queue entry), every lane gets it
+__device__ __forceinline__ int auv_next_world_wave(const AuvDev& d, const int w, const int lane) {
+  if (!d.fw_state) return (int)(((long long)w + d.n) % d.n_worlds);
+  int w2 = 0;
+  if (lane == 0) w2 = auv_next_world(d, w);
+  return __builtin_amdgcn_readfirstlane(w2);
+}
 
 // State handed from one phase to the next inside a launch (registers instead of
 // a global-memory round trip): the advanced vessel state and the env's counters.

@@ -58,6 +58,8 @@ struct StepTabs {
   int4* counters;
   int32_t ring_slots, ring_slot_host;
   int32_t* ring_pos;
+  const int32_t* fw_serial;   // (fresh worlds: the slot's serial, for the episode log's world column)
+  int32_t n;                  // environments of the handle (AuvDev::n)
 };
 
 // SciPy PPoly: interval search + power-basis eval.  The knots are near-uniform, so the interval
@@ -763,7 +765,11 @@ __device__ __forceinline__ int reward_apply(const D& d, const int e, const int c
     const unsigned long long slot = atomicAdd(d.ep_log_count, 1ull);        // (64-bit: never wraps; cap is a power of two)
     double2* row = (double2*)(d.ep_log + 8 * (size_t)(slot & (unsigned long long)(d.ep_log_cap - 1)));
     row[0] = make_double2((double)e, cum), row[1] = make_double2(t_step + 1, collision), row[2] = make_double2(reached_in, progress_in);
-    row[3] = make_double2(cte_sum / (double)(t_step + 1), (double)d.world_idx[e]);
+    // the world column: the bank's index -- with a fresh world per reset the index the world WOULD have in a bank that never
+    // repeats: environment + N * serial (serial: the how-manieth world of this environment), so that no two episodes of a run
+    // may ever log the same number
+    const int wl = d.world_idx[e];
+    row[3] = make_double2(cte_sum / (double)(t_step + 1), d.fw_serial ? (double)e + (double)d.n * (double)d.fw_serial[wl] : (double)wl);
   }
   const int do_reset = done && d.cfg.auto_reset;
   if (!do_reset) d.counters[e] = cnt;
@@ -822,7 +828,7 @@ __device__ void k3_reward_env(const AuvDev& d, const int e, const int lane, cons
     do_reset = __shfl(do_reset, 0, AUV_WAVE);
     if (do_reset) {
       // VecEnv auto-reset: rebind to the next world of the bank and copy its reset rows
-      restore_env(d, e, (int)(((long long)w + d.n) % d.n_worlds), lane, __shfl(cnt.z, 0, AUV_WAVE), obs_out);
+      restore_env(d, e, auv_next_world_wave(d, auv_uniform(w), lane), lane, __shfl(cnt.z, 0, AUV_WAVE), obs_out);
       return;
     }
   }
@@ -889,8 +895,8 @@ __global__ void __launch_bounds__(AUV_WAVE) k3_reward_lanes(AuvDev d, float* __r
     const int src = __ffsll((long long)m) - 1;
     m &= m - 1;
     const int er = auv_uniform(__shfl(e, src, AUV_WAVE));
-    const int wr = __shfl(w, src, AUV_WAVE), ep = __shfl(cnt.z, src, AUV_WAVE);
-    restore_env(d, er, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
+    const int wr = auv_uniform(__shfl(w, src, AUV_WAVE)), ep = __shfl(cnt.z, src, AUV_WAVE);
+    restore_env(d, er, auv_next_world_wave(d, wr, lane), lane, ep, obs_out);
   }
 }
 
@@ -918,14 +924,30 @@ __global__ void __launch_bounds__(AUV_BLOCK) k_reset(AuvDev d, const uint8_t* __
   if (mask && !mask[e]) return;
   int w = world_idx ? world_idx[e] : d.world_idx[e];
   if (w < 0 || w >= d.n_worlds) w = d.world_idx[e];        // an out-of-range request keeps the current binding
-  restore_env(d, e, w, lane, d.counters[e].z, obs_out);
+  const int4 cnt = d.counters[e];
+  // fresh worlds: reset() of an environment that has stepped in its world moves it on to its next, unseen one (the
+  // reference's reset() always builds a new scenario, environment.py:176-218); one that has not stepped keeps the world it
+  // has -- nobody has seen it.  (auv_reset refuses an explicit world_idx in that mode.)
+  if (d.fw_state && cnt.x > 0) w = auv_next_world_wave(d, auv_uniform(w), lane);
+  restore_env(d, e, w, lane, cnt.z, obs_out);
+}
+
+// refill pass of the fresh-world mode: the first *count_dev SHADOW environments (a handful of environments nobody steps,
+// `d` is their descriptor: w_ready == 0) are put into the reset state of the slots the bind kernel has just bound them to --
+// onto the fresh list, from which the fresh-list kernels of K2 / K3 compute their first observation
+__global__ void __launch_bounds__(AUV_BLOCK) k_fw_shadow_reset(AuvDev d, const int32_t* __restrict__ count_dev) {
+  const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
+  const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
+  if (e >= *count_dev || e >= d.n) return;
+  restore_env(d, e, d.world_idx[e], lane, 0, nullptr);
 }
 
 // load-time pass: after K2/K3 produced the reset observation of the worlds currently bound to
 // the first `count` env slots, keep those rows per world
-__global__ void __launch_bounds__(AUV_BLOCK) k_harvest(AuvDev d, int count) {
+__global__ void __launch_bounds__(AUV_BLOCK) k_harvest(AuvDev d, int count, const int32_t* __restrict__ count_dev) {
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
   const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
+  if (count_dev) count = *count_dev;                       // (the refill pass of the fresh-world mode: known on the device only)
   if (e >= count) return;
   const int S = d.cfg.n_sensors;
   const int w = d.world_idx[e];
@@ -997,7 +1019,11 @@ void auv_launch_refresh_desc(const AuvDev& d, hipStream_t st) {
 
 void auv_launch_ring_advance(const AuvDev& d, hipStream_t st) { hipLaunchKernelGGL(k_ring_advance, dim3(1), dim3(64), 0, st, d); }
 
-void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st) {
-  hipLaunchKernelGGL(k_harvest, dim3((count + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK), dim3(AUV_BLOCK), 0, st, d, count);
+void auv_launch_harvest(const AuvDev& d, int count, hipStream_t st, const int32_t* count_dev) {
+  hipLaunchKernelGGL(k_harvest, dim3((count + AUV_ENVS_PER_BLOCK - 1) / AUV_ENVS_PER_BLOCK), dim3(AUV_BLOCK), 0, st, d, count, count_dev);
+}
+
+void auv_launch_fw_shadow_reset(const AuvDev& d, const int32_t* count_dev, hipStream_t st) {
+  hipLaunchKernelGGL(k_fw_shadow_reset, dim3(env_grid(d)), dim3(AUV_BLOCK), 0, st, d, count_dev);
 }
 #endif

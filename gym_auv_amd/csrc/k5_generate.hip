@@ -152,7 +152,11 @@ __device__ void pchip_pass(const double* wx, const double* wy, double* ks, doubl
   }
 }
 
-__global__ void __launch_bounds__(256) k5_generate(GenOut g, const double* __restrict__ draws, int w_first, int n_worlds) {
+// `slots` / `count_dev` (both or neither): build the worlds of rows 0 .. *count_dev - 1 of `draws` into the bank slots
+// slots[row] -- the refill pass of the fresh-world mode, which learns on the device which slots are stale.  Otherwise rows
+// 0 .. n_worlds - 1 go to the slots w_first + row (whole-bank generation).
+__global__ void __launch_bounds__(256) k5_generate(GenOut g, const double* __restrict__ draws, int w_first, int n_worlds,
+                                                   const int32_t* __restrict__ slots, const int32_t* __restrict__ count_dev) {
   __shared__ double s_part[256];
   __shared__ double s_wp[2][8];      // raw waypoints
   __shared__ double s_s1[8], s_d1[2][8], s_c1[2][8][4];
@@ -168,8 +172,9 @@ __global__ void __launch_bounds__(256) k5_generate(GenOut g, const double* __res
   double* dsx = wy + GEN_NK;
   double* dsy = dsx + GEN_NK;
   const int K = g.n_moving + g.n_static;
+  if (count_dev) n_worlds = *count_dev;
   for (int wi = blockIdx.x; wi < n_worlds; wi += gridDim.x) {
-    const int w = w_first + wi;
+    const int w = slots ? slots[wi] : w_first + wi;
     const double* row = draws + (size_t)wi * g.n_draws;
     // ---- waypoints: RandomCurveThroughOrigin (path.py:96-120) ----
     if (tid == 0) {
@@ -364,10 +369,112 @@ __global__ void __launch_bounds__(256) k5_generate(GenOut g, const double* __res
   }
 }
 
+// ---- draws from a counter-based generator (fresh-world mode): the world of (seed, environment, serial) -------------------
+// The draws of auv_generate_worlds come from the caller (torch's generator); a refill pass on the device has no host to ask,
+// and the world an environment meets in its k-th episode should not depend on when the pass ran or on how the batch is
+// sharded over GPUs.  So row = f(seed, GLOBAL environment index, serial): uniform u = splitmix64(key + counter) >> 11 * 2^-53,
+// z by Box-Muller from two of them, the Poisson variates by inversion -- the layout of devgen.sample_draws (devgen.py:
+// counter_draws is the host mirror of this kernel).
+__device__ __forceinline__ double gen_u01(const unsigned long long key, const unsigned long long ctr) {
+  return (double)(gen_splitmix64(key + ctr) >> 11) * 0x1.0p-53;
+}
+__device__ __forceinline__ unsigned long long gen_world_key(const unsigned long long seed, const long long env, const int serial) {
+  const unsigned long long k0 = gen_splitmix64(seed);
+  const unsigned long long k1 = gen_splitmix64(k0 ^ (unsigned long long)env);
+  return gen_splitmix64(k1 ^ (unsigned long long)(unsigned)serial);
+}
+__device__ __forceinline__ double gen_poisson(const double mean, const double u) {
+  double pr = exp(-mean), cdf = pr;
+  int nn = 0;
+  while (u > cdf && nn < 1000) nn++, pr *= mean / nn, cdf += pr;
+  return (double)nn;
+}
+
+// rows 0 .. *count_dev - 1 (count_dev NULL: n_rows): row i = the draws of environment env_base + envs[i], serial serials[i]
+__global__ void __launch_bounds__(256) k5_draws(double* __restrict__ draws, int n_draws, int n_moving, int n_static, unsigned long long seed,
+                                                long long env_base, const int32_t* __restrict__ envs, const int32_t* __restrict__ serials,
+                                                int n_rows, const int32_t* __restrict__ count_dev) {
+  if (count_dev) n_rows = *count_dev;
+  const double PI = AUV_PI;
+  for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    const unsigned long long key = gen_world_key(seed, env_base + envs[row], serials[row]);
+    double* out = draws + (size_t)row * n_draws;
+    const int per_mover = 3 * GEN_CAND + 2, movers_end = 11 + n_moving * per_mover;
+    for (int j = threadIdx.x; j < n_draws; j += blockDim.x) {
+      int kind = 0;                                         // 0 uniform, 1 normal, 2 Poisson(10), 3 Poisson(30)
+      if (j >= 11 && j < movers_end) {
+        const int r = (j - 11) % per_mover;
+        if (r < 3 * GEN_CAND) kind = r % 3 == 0 ? 1 : (r % 3 == 2 ? 2 : 0);
+      } else if (j >= movers_end) {
+        const int r = (j - movers_end) % (3 * GEN_CAND);
+        kind = r % 3 == 0 ? 1 : (r % 3 == 2 ? 3 : 0);
+      }
+      const double u0 = gen_u01(key, 2ull * (unsigned long long)j), u1 = gen_u01(key, 2ull * (unsigned long long)j + 1ull);
+      double v = u0;
+      if (kind == 1) v = sqrt(-2.0 * log(1.0 - u0)) * cos(2.0 * PI * u1);
+      else if (kind == 2) v = gen_poisson(10.0, u0);
+      else if (kind == 3) v = gen_poisson(30.0, u0);
+      out[j] = v;
+    }
+  }
+}
+
+// ---- the refill pass's bookkeeping kernels (auv_capi.hip: fw_refill) ----
+// Pop up to `cap` stale slots off the queue, in the order they were left: batch row i <- slot, its environment, and the serial
+// of the world it is about to receive (an environment's worlds are numbered in the order it needs them).  One wave, lane 0.
+__global__ void k_fw_bind(FwBatch b, int32_t* __restrict__ queue, unsigned int* __restrict__ ctl, int q_cap, int n_envs, int cap,
+                          int32_t* __restrict__ env_next_serial, int32_t* __restrict__ shadow_world_idx, int32_t* __restrict__ shadow_fresh_count) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned int head = ctl[1];
+  const unsigned int tail = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned int avail = tail - head;
+  if (avail > (unsigned int)cap) avail = (unsigned int)cap;
+  int count = 0;
+  for (unsigned int i = 0; i < avail; i++) {
+    int32_t* q = queue + ((head + i) % (unsigned int)q_cap);
+    const int s = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s < 0) break;                                       // reserved by a finish wave, not written yet: next pass
+    const int e = s % n_envs;
+    b.slot[count] = s, b.env[count] = e, b.serial[count] = env_next_serial[e]++;
+    shadow_world_idx[count] = s;
+    __hip_atomic_store(q, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    count++;
+  }
+  ctl[1] = head + (unsigned int)count;
+  *b.count = count;
+  *shadow_fresh_count = 0;
+}
+
+// regenerated slots of the environments [e0, e0 + ne) become READY: enqueued on THEIR stream once the host has seen the refill
+// pass complete (so every launch behind this one started after the slots' tables and reset rows were complete)
+__global__ void k_fw_publish(FwList l, int e0, int ne, int n_envs, int32_t* __restrict__ state, int32_t* __restrict__ serial) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= l.count) return;
+  const int s = l.slot[i], e = s % n_envs;
+  if (e < e0 || e >= e0 + ne) return;
+  serial[s] = l.serial[i];
+  state[s] = AUV_FW_READY;
+}
+
 }  // namespace
 
 size_t auv_gen_scratch_doubles(void) { return GEN_SCRATCH; }
 
-void auv_launch_generate(const GenOut& g, const double* draws, int w_first, int n_worlds, int grid, hipStream_t st) {
-  hipLaunchKernelGGL(k5_generate, dim3(grid), dim3(256), 0, st, g, draws, w_first, n_worlds);
+void auv_launch_generate(const GenOut& g, const double* draws, int w_first, int n_worlds, int grid, hipStream_t st, const int32_t* slots,
+                         const int32_t* count_dev) {
+  hipLaunchKernelGGL(k5_generate, dim3(grid), dim3(256), 0, st, g, draws, w_first, n_worlds, slots, count_dev);
+}
+
+void auv_launch_draws(double* draws, int n_draws, int n_moving, int n_static, unsigned long long seed, long long env_base, const int32_t* envs,
+                      const int32_t* serials, int n_rows, const int32_t* count_dev, int grid, hipStream_t st) {
+  hipLaunchKernelGGL(k5_draws, dim3(grid), dim3(256), 0, st, draws, n_draws, n_moving, n_static, seed, env_base, envs, serials, n_rows, count_dev);
+}
+
+void auv_launch_fw_bind(const FwBatch& b, int32_t* queue, unsigned int* ctl, int q_cap, int n_envs, int cap, int32_t* env_next_serial,
+                        int32_t* shadow_world_idx, int32_t* shadow_fresh_count, hipStream_t st) {
+  hipLaunchKernelGGL(k_fw_bind, dim3(1), dim3(AUV_WAVE), 0, st, b, queue, ctl, q_cap, n_envs, cap, env_next_serial, shadow_world_idx, shadow_fresh_count);
+}
+
+void auv_launch_fw_publish(const FwList& l, int e0, int ne, int n_envs, int32_t* state, int32_t* serial, hipStream_t st) {
+  hipLaunchKernelGGL(k_fw_publish, dim3(1), dim3(AUV_FW_LIST), 0, st, l, e0, ne, n_envs, state, serial);
 }

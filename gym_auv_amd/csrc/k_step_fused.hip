@@ -302,6 +302,7 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
   st.info64 = dc->info64, st.nav64 = dc->nav64, st.obs64 = dc->obs64, st.rew_path = dc->rew_path, st.reward64 = dc->reward64;
   st.step_info = dc->step_info, st.episode = dc->episode, st.ep_log = dc->ep_log, st.ep_log_count = dc->ep_log_count;
   st.ep_log_cap = dc->ep_log_cap, st.world_idx = dc->world_idx, st.counters = dc->counters;
+  st.fw_serial = dc->fw_serial, st.n = dc->n;
   st.ring_slots = 1, st.ring_slot_host = 0, st.ring_pos = nullptr;          // (the dynamics role advances a captured graph's ring)
   unsigned long long* const pair_word = dc->pair_word;
   unsigned long long* const k1_pkt = dc->k1_pkt;
@@ -421,7 +422,8 @@ __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f,
       const AuvDev* dp = dk.self;
       asm volatile("" : "+s"(dp));      // (the copy's tables are fetched inside the loop: hoisted out of it they are spilled, and the
                                         // spill slots keep 36 B of scratch memory enabled for every wave of the launch)
-      restore_env(*(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)dp, er2, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
+      const AuvDev& dr = *(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)dp;
+      restore_env(dr, er2, auv_next_world_wave(dr, wr, lane), lane, ep, obs_out);
     }
   }
 #ifdef AUV_STAMPS
@@ -614,8 +616,8 @@ __global__ void __launch_bounds__(AUV_WAVE) k31_reward_dyn(AuvDev d, const void*
     const int src = __ffsll((long long)m) - 1;
     m &= m - 1;
     const int er = auv_uniform(__shfl(e, src, AUV_WAVE));
-    const int wr = __shfl(w, src, AUV_WAVE), ep = __shfl(cnt.z, src, AUV_WAVE);
-    restore_env(d, er, (int)(((long long)wr + d.n) % d.n_worlds), lane, ep, obs_out);
+    const int wr = auv_uniform(__shfl(w, src, AUV_WAVE)), ep = __shfl(cnt.z, src, AUV_WAVE);
+    restore_env(d, er, auv_next_world_wave(d, wr, lane), lane, ep, obs_out);
   }
   // a restored environment's state was written by lane 0, its dynamics below read it from another lane
   if (any_reset) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

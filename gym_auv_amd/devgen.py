@@ -43,6 +43,24 @@ class GeneratedWorlds:
     seed: int = 0
 
 
+@dataclass(frozen=True)
+class FreshWorlds:
+    """`worlds=` argument of BatchedAuvEnv asking for A FRESH WORLD ON EVERY RESET (auv_fresh_worlds_create): what the
+    reference does -- reset() -> _generate() builds a new scenario whenever an episode ends (environment.py:176-218,
+    envs/movingobstacles.py:28-95) -- with the generation on the device and off the step path.  `depth` bank slots per
+    environment (>= 2); the world of environment e's k-th episode is the world of (seed, env_index_base + e, k) whatever the
+    timing, the sub-batch chains or the sharding over GPUs.  A refill pass of up to `batch_cap` worlds is enqueued on a side
+    stream every `period` step calls; `stats()["reused"]` counts episodes that had to start in the world they had just
+    finished because the pass fell behind (0 when depth / period / batch_cap fit the turn-over rate)."""
+    depth: int = 2
+    n_moving: int = 17
+    n_static: int = 11
+    seed: int = 0
+    env_index_base: int = 0
+    batch_cap: int = 64
+    period: int = 8
+
+
 def n_draws(n_moving: int, n_static: int) -> int:
     return 11 + n_moving * (3 * CAND + 2) + n_static * 3 * CAND
 
@@ -169,3 +187,52 @@ def world_from_draws(row: np.ndarray, n_moving: int = 17, n_static: int = 11, dt
         col += 3 * CAND
     return WorldSpec(waypoints=path.init_waypoints, vessel_init=pose,
                      circles=np.asarray(circles, dtype=np.float64).reshape(-1, 3), movers=movers, name="devgen")
+
+
+# ---- host mirror of the device's counter-based draws (k5_generate.hip: k5_draws) -------------------------------------------------
+def _world_key(seed: int, env: int, serial: int) -> int:
+    k0 = _splitmix64(seed & _M64)
+    k1 = _splitmix64(k0 ^ (env & _M64))
+    return _splitmix64(k1 ^ (serial & 0xFFFFFFFF))
+
+
+def _poisson_inv(mean: float, u: float) -> float:
+    p = math.exp(-mean)
+    cdf, n = p, 0
+    while u > cdf and n < 1000:
+        n += 1
+        p *= mean / n
+        cdf += p
+    return float(n)
+
+
+def counter_draws(seed: int, env: int, serial: int, n_moving: int = 17, n_static: int = 11) -> np.ndarray:
+    """The draws row of the world environment `env` (GLOBAL index) meets in its `serial`-th episode in the fresh-world mode:
+    the same integers as the device (uniforms are bit-identical; z and the Poisson counts go through the host's libm, so they
+    agree to the last bits / except at a comparison that falls within an ulp -- the GPU tests therefore read the device's own
+    rows back, auv_fresh_worlds_draws, and use this function to pin the generator's definition)."""
+    key = _world_key(seed, env, serial)
+    nd = n_draws(n_moving, n_static)
+    per_mover = 3 * CAND + 2
+    movers_end = 11 + n_moving * per_mover
+    out = np.empty(nd, dtype=np.float64)
+    for j in range(nd):
+        kind = 0
+        if 11 <= j < movers_end:
+            r = (j - 11) % per_mover
+            if r < 3 * CAND:
+                kind = 1 if r % 3 == 0 else (2 if r % 3 == 2 else 0)
+        elif j >= movers_end:
+            r = (j - movers_end) % (3 * CAND)
+            kind = 1 if r % 3 == 0 else (3 if r % 3 == 2 else 0)
+        u0 = (_splitmix64((key + 2 * j) & _M64) >> 11) * 2.0 ** -53
+        u1 = (_splitmix64((key + 2 * j + 1) & _M64) >> 11) * 2.0 ** -53
+        if kind == 1:
+            out[j] = math.sqrt(-2.0 * math.log(1.0 - u0)) * math.cos(2.0 * math.pi * u1)
+        elif kind == 2:
+            out[j] = _poisson_inv(10.0, u0)
+        elif kind == 3:
+            out[j] = _poisson_inv(30.0, u0)
+        else:
+            out[j] = u0
+    return out

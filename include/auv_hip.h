@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AUV_ABI_VERSION 3
+#define AUV_ABI_VERSION 4
 
 enum {
   AUV_OK = 0,
@@ -138,6 +138,8 @@ enum {
                                  was built with STAMPS=1 (diagnostic)                       */
   AUV_FIELD_BROKEN = 15,     /* [N] uint8  environments whose step a wave that gave up polling has left unfinished
                                  (all zero except between a hand-over time-out and the call that recovers)     */
+  AUV_FIELD_FW_STATE = 16,   /* [W] int32  fresh-world mode only: 0 READY (unseen), 1 IN_USE, 2 STALE (queued / being rebuilt) */
+  AUV_FIELD_FW_SERIAL = 17,  /* [W] int32  fresh-world mode only: the slot holds world number `serial` of its environment    */
   AUV_FIELD_STEP_INFO = 14   /* [N][4] the `info` dict of the last step() as the reference
                                  returns it (environment.py:336-340): collision, reached_goal,
                                  goal_distance, progress -- of the step that was taken, i.e. the
@@ -190,11 +192,15 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
  *   AUV_RDV_DEVICE  one-wave kernels and two words in device memory: the caller's stream publishes "actions of step t ready",
  *                   a one-wave kernel in front of each chain's launch polls for it (bounded), a one-wave kernel behind it counts
  *                   the chain off, ONE polling kernel on the caller's stream waits for all of them (csrc/k_step_fused.hip:
- *                   k_rdv_*).  Every waiter waits for something submitted before it; a wait that runs out
- *                   (auv_set_rendezvous_limit, default 300 s) is reported like a hand-over time-out (auv_health).
- *                   Needs streams whose kernels really execute side by side (auv_streams_overlap): where dispatches are
- *                   serialised -- a counter-collecting profiler -- a polling kernel would sit in front of the kernel it
- *                   waits for until its limit; use AUV_RDV_EVENTS there (BatchedAuvEnv does for unprobed streams).
+ *                   k_rdv_*).  Every waiter waits for something submitted before it.  Needs streams whose kernels really
+ *                   execute side by side: where dispatches are serialised -- a counter-collecting profiler -- a polling
+ *                   kernel would sit in front of the kernel it waits for.  So (i) the first call on a set of streams runs a
+ *                   TRIAL of the pattern with nothing at stake (50 ms limit; synchronises those streams once): if it runs out,
+ *                   and whenever a slice is not stepped in the one-launch shape, the handle uses AUV_RDV_EVENTS instead, for
+ *                   good (auv_health [7]); (ii) a real wait that runs out (auv_set_rendezvous_limit, default 10 s: raise it if
+ *                   the caller's stream can be busy for longer between two steps) is reported by the next call (AUV_ESTATE,
+ *                   once), and a chain whose gate ran out does NOT step: the gate raises the abort flag and the launch behind
+ *                   it -- and every launch queued behind that -- hands out ABORT packets (environments untouched).
  *   AUV_RDV_CP      the same words written and awaited by the command processors (hipStreamWriteValue64 / WaitValue64).
  * Results are bit-identical to auv_step.  What a full rendezvous per step costs, and why K chains cannot beat ONE launch
  * when every step waits for all of them, is in DESIGN.md section 4.                                                      */
@@ -269,7 +275,9 @@ int auv_graph_capture_steps(auv_handle_t* h, const void* actions_dev, int32_t ac
  *                   hardware queue a chain runs on stays the caller's choice (auv_streams_overlap), as for eager chains.
  *   one_graph = 1   ONE graph whose n_slices branches are the chains (fork behind the root, join at the end), replayed
  *                   with auv_graph_launch; the runtime places the branches.
- * obs / reward / done hold the last step's values after a replay.  Needs the one-launch shape for every slice.        */
+ * obs / reward / done hold the last step's values after a replay.                                                    */
+/* (A slice stepped in the three-launch shape -- set_step_mode, no LiDAR, hand-overs disabled -- is captured in that shape and
+ * advances its own ring position just the same.)                                                                      */
 int auv_graph_capture_chains(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, const void* actions_dev,
                              int32_t action_dtype, float* obs_dev, float* reward_dev, uint8_t* done_dev, int32_t n_steps,
                              int32_t one_graph);
@@ -322,7 +330,10 @@ int auv_effective_step_mode(auv_handle_t* h, int32_t n_envs_per_launch);
 /* out8: [0] 1 = in-launch hand-overs in use, [1] polls of the last dispatch-order probe that ran out (-1: no bank yet),
  *       [2] hand-over time-outs over the life of the handle, [3] 1 = a time-out is pending (the next step call
  *       will recover and return AUV_ESTATE), [4] / [5] e0 / ne of the launch that reported the last time-out (-1: none),
- *       [6] environments the last recovery reset, [7] 0.  Reads host memory only: no synchronisation.              */
+ *       [6] environments the last recovery reset, [7] 0 while AUV_RDV_DEVICE is in use, else the number of rendezvous
+ *       waits (trial included) that ran out -- events from then on.  Reads host memory only: no synchronisation.
+ * A recovery writes the reset observation of the environments it resets into OBS64 and into the obs buffer of the CALL THAT
+ * RECOVERS (if that call has one) -- never through a pointer remembered from an earlier call.                     */
 int auv_health(auv_handle_t* h, int32_t* out8);
 /* The dispatch-order probe on the streams production uses: one probe launch per stream, all in flight together, a foreign
  * kernel behind each, two rounds (BatchedAuvEnv.set_sub_batches runs it on the chain streams it has chosen).  Updates
@@ -391,6 +402,42 @@ enum {
 };
 size_t auv_bank_bytes(const auv_handle_t* h, int32_t table);
 int auv_read_bank(auv_handle_t* h, int32_t table, void* dst_dev, size_t bytes, void* stream);
+
+/* A FRESH WORLD ON EVERY RESET (both halves joined): the reference builds a new scenario whenever an episode
+ * ends (environment.py:176-218 reset() -> _generate(); envs/movingobstacles.py:28-95).  auv_generate_worlds gives a bank that
+ * auto-reset cycles through ((w + N) % W): fine for throughput, not what the reference's learner sees.  This mode does:
+ *   - the bank is `depth` slots per environment (slot e + j N belongs to environment e; depth >= 2); the world of environment e's
+ *     k-th episode is the world of (seed, env_index_base + e, serial k): draws from a counter-based generator on the device
+ *     (k5_generate.hip: k5_draws; gym_auv_amd/devgen.py: counter_draws is the host mirror), so what an environment meets does not
+ *     depend on timing, on the sub-batch chains, or on how the batch is sharded over GPUs (env_index_base = the shard's first
+ *     GLOBAL environment index);
+ *   - an environment whose episode ends (auto-reset, or auv_reset after it has stepped) moves to its next slot and queues the one
+ *     it leaves; a refill pass on a low-priority side stream, enqueued by the step calls themselves every `period` calls and
+ *     never waited for, rebuilds exactly the queued slots (up to `batch_cap` per pass): tables (k5_generate) and reset rows (the
+ *     step's own kernels on batch_cap shadow environments nobody steps).  Once the host has SEEN a pass complete (an event
+ *     query at a later step call), a one-block publish kernel on the stream of each chain that owns a regenerated slot makes
+ *     it bindable: every launch that can bind the slot started after its tables were complete -- no fence in the step path.
+ *     Running environments are never touched.
+ *   - should an episode end before its environment's next slot is ready (the pass fell behind an episode of a few steps) the
+ *     environment starts over in the world it has just finished, and the event is COUNTED (auv_fresh_worlds_stats [2]); size
+ *     `depth` / `period` / `batch_cap` so that the count stays 0 (bench.py --fresh-worlds reports it).
+ * The episode log's `world` column then holds e + N * serial (what the world's index would be in a bank that never repeats).
+ * auv_fresh_worlds_create replaces the bank like auv_generate_worlds (same ring tables; synchronous) and resets every
+ * environment; auv_load_worlds / auv_generate_worlds leave the mode.  auv_reset refuses an explicit world_idx in this mode.
+ *   auv_fresh_worlds_refill   the step calls that cover the whole batch (auv_step, _pipelined, _async, auv_policy_rollout, graph
+ *                             launches) tick by themselves; a caller that drives slices one by one (auv_step_slice) calls this
+ *                             with the chains' slices and streams.  flush != 0: synchronises those streams, then runs passes
+ *                             until the queue is empty and everything is published (tests; a deterministic hand-over point).
+ *   auv_fresh_worlds_stats    out8: [0] mode on, [1] worlds regenerated and published, [2] episodes that re-used their world
+ *                             (see above), [3] slots queued now, [4] passes issued, [5] passes published, [6] depth, [7] batch_cap.
+ *   auv_fresh_worlds_draws    the draws row of (environment, serial) for n_rows pairs (HOST arrays of environment indices
+ *                             relative to this handle) -> dst_dev [n_rows][n_draws]: what the host mirror rebuilds a world from. */
+int auv_fresh_worlds_create(auv_handle_t* h, int32_t depth, int32_t n_moving, int32_t n_static, uint64_t seed, int64_t env_index_base,
+                            int32_t batch_cap, int32_t period, const double* ring_unit, const int32_t* nseg_by_radius, int32_t n_radius);
+int auv_fresh_worlds_refill(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, int32_t flush);
+int auv_fresh_worlds_stats(auv_handle_t* h, int64_t* out8);
+int auv_fresh_worlds_draws(auv_handle_t* h, const int32_t* envs_host, const int32_t* serials_host, int32_t n_rows, double* dst_dev,
+                           void* stream);
 
 /* ---- the policy in the loop (scripts/run.py:332-357: PPO2 with MlpPolicy, net_arch [256, 128, 64] for
  * policy and value function, tanh, diagonal Gaussian over the two actions) --------------------------------------------

@@ -108,3 +108,26 @@ def test_exhausted_candidate_pool_redraws_instead_of_placing_on_the_vessel():
     assert devgen.extra_candidate(row, 11, devgen.CAND, 10.0) == devgen.extra_candidate(row.copy(), 11, devgen.CAND, 10.0)
     zs = [devgen.extra_candidate(row, 11, devgen.CAND + i, 30.0) for i in range(devgen.EXTRA_CAND)]
     assert abs(np.mean([z[2] for z in zs]) - 30.0) < 5 and all(0 <= z[1] < 1 for z in zs)
+
+
+def test_counter_draws_layout_and_determinism():
+    """devgen.counter_draws -- the host mirror of the device's counter-based generator (k5_generate.hip: k5_draws) that the
+    fresh-world mode draws its worlds from: same key -> same row, another environment / serial / seed -> another row, the layout
+    of sample_draws (uniforms in [0, 1), N(0, 1) and Poisson(10 / 30) in the candidate triples), and a world built from a row."""
+    a = devgen.counter_draws(7, 123, 4)
+    np.testing.assert_array_equal(a, devgen.counter_draws(7, 123, 4))
+    for other in (devgen.counter_draws(8, 123, 4), devgen.counter_draws(7, 124, 4), devgen.counter_draws(7, 123, 5)):
+        assert not np.array_equal(a, other)
+    assert a.shape == (devgen.n_draws(17, 11),)
+    C = devgen.CAND
+    rows = np.stack([devgen.counter_draws(1, e, 0) for e in range(64)])
+    assert np.all((rows[:, :11] >= 0) & (rows[:, :11] < 1))
+    z = rows[:, 11:11 + 3 * C:3]
+    pois10 = rows[:, 13:11 + 3 * C:3]
+    base30 = 11 + 17 * (3 * C + 2)
+    pois30 = rows[:, base30 + 2:base30 + 3 * C:3]
+    assert abs(z.mean()) < 0.15 and 0.8 < z.std() < 1.2
+    assert np.all(pois10 == np.round(pois10)) and 9.0 < pois10.mean() < 11.0
+    assert np.all(pois30 == np.round(pois30)) and 28.5 < pois30.mean() < 31.5
+    w = devgen.world_from_draws(a)
+    assert len(w.movers) == 17 and w.circles.shape == (11, 3)
