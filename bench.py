@@ -63,6 +63,13 @@ def parse():
     ap.add_argument("--worlds-per-env", type=int, default=2,
                     help="bank size / envs: 2 (default) lets every auto-reset land on a world the env has not seen; "
                          "1 = the round-1 bench (an env is reborn in its own world)")
+    ap.add_argument("--fresh-worlds", type=int, default=0,
+                    help="1: A FRESH WORLD ON EVERY RESET (auv_fresh_worlds_create; workload moving28 = the reference's MovingObstacles "
+                         "scenario): --worlds-per-env bank slots per env, every slot an episode leaves is rebuilt on the device by a "
+                         "refill pass beside the step path, so the generator's cost is INSIDE the timed region; `comparison` then "
+                         "carries the rate of the same loop over a bank that just cycles")
+    ap.add_argument("--fresh-period", type=int, default=8, help="--fresh-worlds: a refill pass every this many step calls")
+    ap.add_argument("--fresh-batch", type=int, default=64, help="--fresh-worlds: worlds per refill pass at most")
     ap.add_argument("--graph", type=int, default=0,
                     help="0 (default): eager launches; K > 0: K consecutive steps captured in ONE hipGraph over the action "
                          "ring, one replay per K steps (steps not a multiple of K are finished eagerly)")
@@ -233,6 +240,16 @@ def spawn_ranks(args):
     return 0
 
 
+def device_bank_summary(env):
+    """What algorithmic_bytes needs of a bank that was built on the device (slot layout): vertex counts, obstacle records."""
+    cnt = env.read_bank("POLY_CNT").cpu().numpy().astype(np.int64)
+    meta = env.read_bank("OBS_META").cpu().numpy()
+    W, K = meta.shape[0], meta.shape[1]
+    M = env.m_max if env._gen.n_moving else 0
+    return dict(n_worlds=W, poly_off=np.r_[0, np.cumsum(cnt)], obs_off=np.arange(W + 1, dtype=np.int64) * K,
+                mv_off=np.arange(W + 1, dtype=np.int64) * M, obs_meta=meta.reshape(W * K, 4))
+
+
 def world_seeds(lo, n_local, total_envs, worlds_per_env):
     """Seed of world w of this rank's bank: env g = lo + (w % n_local) meets it in its (w // n_local)-th episode."""
     w = np.arange(n_local * worlds_per_env)
@@ -277,7 +294,12 @@ def main():
     procs = args.procs or max(1, min(16, host_cores() // max(1, world)))
     t0 = time.time()
     cache = ""
-    if args.bank_cache:
+    fresh = bool(args.fresh_worlds)
+    if fresh and args.workload != "moving28":
+        raise SystemExit("--fresh-worlds builds the reference's MovingObstacles scenario on the device: --workload moving28")
+    if fresh:
+        wpe = max(2, wpe)
+    if args.bank_cache and not fresh:
         import hashlib
         import tempfile
         # the key names everything the bank depends on: workload, shard, bank size and the generator's own source
@@ -294,7 +316,9 @@ def main():
             bank_from_cache = True
         except Exception:
             bank = None                                    # (a torn file of an interrupted run: regenerate)
-    if bank is None:
+    if fresh:
+        bank = None                                        # no host-side bank at all: the device builds every world
+    elif bank is None:
         bank = build_bank_parallel(gen, seeds, procs=procs, **kwargs)
         if cache:
             tmp = "%s.%d.tmp.npz" % (cache, os.getpid())
@@ -313,7 +337,17 @@ def main():
     dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))   # (modulo: single-GPU rehearsal of N ranks)
     torch.cuda.set_device(dev)
     from gym_auv_amd.batched_env import BatchedAuvEnv     # fails loudly without the HIP library
-    env = BatchedAuvEnv(cfg, bank, n_local, device=dev, auto_reset=True)
+    if fresh:
+        from gym_auv_amd.devgen import FreshWorlds
+        t0 = time.time()
+        # the world of env g's k-th episode = f(seed, GLOBAL env index, k): the shard's first global index is its base
+        env = BatchedAuvEnv(cfg, FreshWorlds(depth=wpe, seed=1000, env_index_base=lo, batch_cap=args.fresh_batch, period=args.fresh_period),
+                            n_local, device=dev, auto_reset=True)
+        torch.cuda.synchronize(dev)
+        t_gen = time.time() - t0
+        bank = device_bank_summary(env)                    # counts / offsets / obstacle records of the slots, for the byte model
+    else:
+        env = BatchedAuvEnv(cfg, bank, n_local, device=dev, auto_reset=True)
     env.set_step_mode(args.step_mode)
     S = env.n_sensors
 
@@ -542,6 +576,37 @@ def main():
                     env.step_pipelined(pool[i % n_pool])
             comparison["pipelined_sub%d" % sub] = rate(loop_pipe)
 
+    fresh_stats = None
+    if fresh:
+        torch.cuda.synchronize(dev)
+        fresh_stats = env.fresh_stats()
+        if rank == 0 and world == 1 and not K and args.probe_streams:
+            # beside it: the SAME loop (same steps, same chains) over a device-built bank of the same shape that just cycles
+            # (w + N) % W -- the difference is what a fresh world per reset costs, generator and refill bookkeeping included
+            from gym_auv_amd.devgen import GeneratedWorlds
+            cyc = BatchedAuvEnv(cfg, GeneratedWorlds(wpe * n_local, seed=1000), n_local, device=dev, auto_reset=True)
+            cyc.set_step_mode(args.step_mode)
+            cyc.reset()
+            if sub > 1:
+                cyc.set_sub_batches(sub, probe_streams=True, strict=True)
+
+            def loop_cyc(n):
+                for i in range(n):
+                    if sub > 1:
+                        cyc.step_pipelined(pool[i % n_pool])
+                    else:
+                        cyc.step(pool[i % n_pool])
+            loop_cyc(args.warmup)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            loop_cyc(args.steps)
+            torch.cuda.synchronize(dev)
+            t_cyc = time.perf_counter() - t1
+            comparison = dict(comparison or {}, bank_cycling_same_loop=round(n_local * args.steps / t_cyc, 1),
+                              fresh_worlds_timed_region=round(value, 1), steps_each=args.steps,
+                              bank_cycling_episodes=int(cyc.episode_stats()["episodes"].sum().item()))
+            cyc.close()
+
     lib_sha = library_sha256()
     cfg_key = "%s/sub%d" % (args.workload, sub)
 
@@ -609,6 +674,10 @@ def main():
                                  ms_per_step=[round(r[4], 5) for r in per_rank], episode_all_gather_ms=[round(r[5], 3) for r in per_rank]),
                    collective_backend=D.backend_name(),
                    episodes_finished=int(stats["episodes"].sum().item()))
+    if fresh_stats:
+        # `reused` must be 0: every finished episode found an unseen world waiting; `regenerated`: worlds rebuilt by the refill
+        # passes (warm-up included), i.e. the generator ran inside the timed region
+        cfg_out["fresh_worlds"] = dict(fresh_stats, period=args.fresh_period, worlds="(seed 1000, global env index, episode serial)")
     if os.environ.get("AUV_HIP_LIB"):
         cfg_out["lib_override"] = os.environ["AUV_HIP_LIB"]      # (the loader's A/B hook: say so when it is in use)
     out = dict(metric="env-steps/sec", value=round(value, 1), unit="env-steps/s", n_gpus=n_devices_used, steps=args.steps,
@@ -618,7 +687,12 @@ def main():
         out["comparison"] = comparison
 
     if rank == 0 and world == 1 and args.cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, bank, n_local)
+        if fresh:
+            # (the oracle steps host-built worlds of the same scenario: the reference's generator through scenarios.py)
+            cpu_bank = build_bank_parallel(gen, world_seeds(0, 1024, 1024, 2), procs=procs, **kwargs)
+            out["cpu_baseline"] = cpu_baseline(cfg, cpu_bank, min(1024, n_local))
+        else:
+            out["cpu_baseline"] = cpu_baseline(cfg, bank, n_local)
     if rank == 0:
         print(json.dumps(out), flush=True)
     env.close()

@@ -19,10 +19,11 @@ learns fastest here); --ret-norm 1 normalises the returns by a running mean / st
 -5000 against step rewards of order 1); --orthogonal 1 starts the last policy layer small.  Progress is read from the
 library's episode log (auv_episode_log): goal / collision / give-up rates of the episodes that ended during each update.
 
-Scenarios are generated ON THE DEVICE: every environment gets its own MovingObstacles world and the
-whole bank can be regenerated from fresh random draws every `--regen` updates (a few milliseconds); finished episodes
-in between restart on the next world of the bank.  `--worlds host` uses the host generator (bit-compatible RNG streams
-with the reference) instead.
+Scenarios are generated ON THE DEVICE, and by default EVERY FINISHED EPISODE LANDS ON A WORLD NOBODY HAS SEEN
+(`--worlds fresh`, BatchedAuvEnv(worlds=FreshWorlds(...))): what the reference's reset() -> _generate() gives its learner
+(environment.py:176-218), with the generator running beside the rollouts on a side stream.  `--worlds generated` keeps a bank
+of two worlds per environment that auto-reset cycles through (optionally rebuilt every `--regen` updates, which restarts every
+episode); `--worlds host` uses the host generator (bit-compatible RNG streams with the reference).
 
     python examples/ppo.py --envs 4096 --updates 200 --rollout 256 --graph-rollout 1
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/ppo.py   # data parallel
@@ -68,27 +69,68 @@ class ActorCritic(nn.Module):
         return (0.5 + LOG_SQRT_2PI + self.log_std).sum()
 
 
-def clip_grad_norm(params, max_norm, stacked=False):
+def clip_grad_norm(params, max_norm):
     """Global-norm gradient clipping in plain tensor operations (no host synchronisation), safe inside a captured graph.
     The norm is accumulated with 0-d additions, NOT torch.stack / torch.cat: on ROCm those stage the table of their inputs'
     addresses through pinned host memory with an asynchronous copy, a stream capture records that copy with the HOST
     address, the caching host allocator recycles the buffer, and a replay then uploads somebody else's bytes as the table --
     the "gradient norm" comes out as inf although every gradient element is finite, the clip scales the gradients to
-    zero and the policy freezes silently (what round 2 / 3's --graph-update did; `stacked` keeps the
-    old form for profiles/r04/ppo_graph_update_*stacked.log)."""
+    zero and the policy freezes silently (what round 2 / 3's --graph-update did; docs/HISTORY.md)."""
     grads = [p.grad for p in params if p.grad is not None]
-    if stacked:
-        total = torch.sqrt(torch.stack([(g * g).sum() for g in grads]).sum())
-    else:
-        sq = None
-        for g in grads:
-            s = (g * g).sum()
-            sq = s if sq is None else sq + s
-        total = torch.sqrt(sq)
+    sq = None
+    for g in grads:
+        s = (g * g).sum()
+        sq = s if sq is None else sq + s
+    total = torch.sqrt(sq)
     coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
     for g in grads:
         g.mul_(coef)
     return total
+
+
+PROBE = {} if os.environ.get("AUV_PPO_PROBE") else None
+
+
+def probe_report(probe, diag_row, log):
+    """A replayed update step has written a corrupt record: where do the record's inputs live, what do they
+    hold NOW, and which other live tensor shares their bytes?"""
+    import gc
+    torch.cuda.synchronize()
+    spans = {k: (v.data_ptr(), v.data_ptr() + max(1, v.numel()) * v.element_size()) for k, v in probe.items()}
+    for k, v in probe.items():
+        raw = v.view(torch.uint8) if v.dim() else v.reshape(1).view(torch.uint8)
+        log("probe %-10s ptr 0x%x dtype %s value now %s bytes %s" % (k, v.data_ptr(), v.dtype, v.item(), bytes(raw.cpu().tolist()).hex()))
+    log("probe diag_row ptr 0x%x now %s" % (diag_row.data_ptr(), diag_row.tolist()))
+    seen = 0
+    for obj in gc.get_objects():
+        try:
+            if not (torch.is_tensor(obj) and obj.is_cuda and obj.numel()):
+                continue
+            lo = obj.untyped_storage().data_ptr()
+            hi = lo + obj.untyped_storage().nbytes()
+        except Exception:
+            continue
+        for k, (a, b) in spans.items():
+            if lo < b and a < hi and obj is not probe[k]:
+                seen += 1
+                log("probe OVERLAP %s [0x%x, 0x%x) with live tensor storage [0x%x, 0x%x) shape %s dtype %s" % (k, a, b, lo, hi, tuple(obj.shape), obj.dtype))
+    log("probe overlaps with live tensors: %d" % seen)
+    try:
+        for seg in torch.cuda.memory_snapshot():
+            for k, (a, b) in spans.items():
+                if seg["address"] <= a < seg["address"] + seg["total_size"]:
+                    blk = [bl for bl in _blocks(seg) if bl[0] <= a < bl[0] + bl[1]]
+                    log("probe %-10s in segment 0x%x size %d pool %s stream %s; block %s" % (k, seg["address"], seg["total_size"], seg.get("segment_pool_id"), seg.get("stream"), blk))
+    except Exception as exc:
+        log("probe: no allocator snapshot (%s)" % exc)
+
+
+def _blocks(seg):
+    out, addr = [], seg["address"]
+    for bl in seg["blocks"]:
+        out.append((addr, bl["size"], bl["state"]))
+        addr += bl["size"]
+    return out
 
 
 def average_gradients(params, world):
@@ -106,14 +148,14 @@ def average_gradients(params, world):
         off += g.numel()
 
 
-def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="generated", regen=0, log_every=1,
+def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print, worlds="fresh", regen=0, log_every=1,
           task="colav", step_mode=None, graph_rollout=False, sub_batches=4, minibatches=32,
           reward_scale=0.01, reward_clip=0.0, min_cumulative_reward=None, act_space="raw", ret_norm=False, orthogonal=False, ent_coef=0.01, log_std=-0.5, lr=2e-4,
           fused_policy=True, graph_update=False, policy_bf16=False):
     from gym_auv_amd import distributed as D
     from gym_auv_amd.batched_env import BatchedAuvEnv
     from gym_auv_amd.config import effective_reference_config
-    from gym_auv_amd.devgen import GeneratedWorlds
+    from gym_auv_amd.devgen import FreshWorlds, GeneratedWorlds
     from gym_auv_amd.world import build_bank_parallel
     rank, world = D.rank(), D.world_size()
     torch.manual_seed(seed + rank)
@@ -124,7 +166,11 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     if min_cumulative_reward is not None:       # (diagnosis only: the reference ends an episode below -2000, config.py:16)
         cfg.episode.min_cumulative_reward = float(min_cumulative_reward)
     nm, ns = (17, 11) if colav else (0, 0)
-    if worlds == "generated":
+    if worlds == "fresh":
+        # a new scenario on every reset; the world of an episode = f(seed, GLOBAL environment index, serial): data-parallel ranks
+        # own disjoint index ranges
+        bank = FreshWorlds(depth=2, n_moving=nm, n_static=ns, seed=1000 * seed, env_index_base=rank * envs, batch_cap=64, period=8)
+    elif worlds == "generated":
         bank = GeneratedWorlds(2 * envs, nm, ns, seed=1000 * seed + rank)
     else:
         bank = build_bank_parallel("moving_obstacles_world", range(5000 + 512 * rank, 5000 + 512 * rank + min(envs, 512)),
@@ -152,9 +198,7 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     if world > 1:   # data parallel over GPUs: same initial weights, gradients averaged over RCCL
         for prm in params:
             torch.distributed.broadcast(prm.data, 0)
-    graph_update = int(graph_update) if world == 1 else 0      # (the gradient all-reduce of data parallelism stays eager)
-    # (graph_update == 2: the captured update with round 3's torch.stack-based gradient norm; 3: that, a stack-built record and
-    # per-update concatenations outside the graph -- the configuration that froze the weights, kept to SHOW the failure)
+    graph_update = int(bool(graph_update)) if world == 1 else 0      # (the gradient all-reduce of data parallelism stays eager)
     opt = torch.optim.Adam(params, lr=lr, capturable=bool(graph_update))
     # --graph-update: a device-side record of every minibatch step (the two gradient norms before clipping, the loss, the
     # largest |advantage| and probability ratio, counts of non-finite inputs and gradient elements), written by the step
@@ -249,7 +293,9 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             for i in range(K):
                 buf[i]["t"].zero_()                       # (on the caller's stream, BEFORE the chain is told to wait for it)
                 streams[i].wait_stream(cur)               # (the update of the previous round wrote the weights there)
-            for _ in range(T):
+            for t_roll_step in range(T):
+                if worlds == "fresh" and t_roll_step % 8 == 0:
+                    env.refill()                              # (this loop steps slice by slice: the library cannot tick by itself)
                 for i in range(K):
                     with torch.cuda.stream(streams[i]):
                         if graphs is not None:
@@ -266,13 +312,6 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             if fused is not None:
                 O, A, LP, V, R, Dn = fused.buffers()
                 V = V * ret_std + ret_mean
-                if graph_update >= 3:
-                    # (the configuration that froze in profiles/r04/ppo_graph_update_colav_stacked_frozen.log: stack-based
-                    # norms inside the captured update, fresh concatenations of the chains' buffers as the update's inputs and
-                    # the advantage recursion as T x 6 small tensor operations outside it, every update; 4: the same around the
-                    # stack-free norms)
-                    O, A, LP, R, Dn = (torch.cat([x[:, lo:lo + cnt] for lo, cnt in slices], 1) for x in (O, A, LP, R, Dn))
-                    V = torch.cat([fused.V[:, lo:lo + cnt] for lo, cnt in slices], 1) * ret_std + ret_mean
             else:
                 O = torch.cat([b["O"] for b in buf], 1)
                 A = torch.cat([b["A"] for b in buf], 1)
@@ -281,7 +320,7 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
                 R = torch.cat([b["R"] for b in buf], 1)
                 Dn = torch.cat([b["Dn"] for b in buf], 1)
             last_v = net.v(env.obs).squeeze(-1) * ret_std + ret_mean
-            if fused is not None and graph_update < 3:
+            if fused is not None:
                 adv, RET = fused.gae(V, last_v, gamma, lam)            # one launch (auv_gae) instead of T x 6 small ones
             else:
                 adv = torch.zeros_like(R)
@@ -291,7 +330,7 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
                     delta = R[t] + gamma * nv * (1 - Dn[t]) - V[t]
                     gae = delta + gamma * lam * (1 - Dn[t]) * gae
                     adv[t] = gae
-            if fused is None or graph_update >= 3:
+            if fused is None:
                 RET = adv + V
             # running statistics of the returns (one pass of exponential averaging per update)
             m, s = RET.mean(), RET.std()
@@ -323,20 +362,26 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             average_gradients(params, world)
             # (policy and value net are separate networks: clipped separately, so that a value loss swollen by a rare
             # -5000 collision return cannot scale the policy's gradient away under a shared norm)
-            bad_in = sum((~torch.isfinite(x)).sum() for x in (o, a, lp, advn, retn))
-            bad_g = sum((~torch.isfinite(q.grad)).sum() for q in params if q.grad is not None)
-            n_pi = clip_grad_norm(pi_params, 0.5, stacked=graph_update in (2, 3))
-            n_v = clip_grad_norm(v_params, 0.5, stacked=graph_update in (2, 3))
+            # counts of non-finite inputs / gradient elements (float accumulation)
+            bad_in = torch.zeros((), device=device)
+            for x in (o, a, lp, advn, retn):
+                bad_in = bad_in + (~torch.isfinite(x)).sum(dtype=torch.float32)
+            bad_g = torch.zeros((), device=device)
+            for q in params:
+                if q.grad is not None:
+                    bad_g = bad_g + (~torch.isfinite(q.grad)).sum(dtype=torch.float32)
+            n_pi = clip_grad_norm(pi_params, 0.5)
+            n_v = clip_grad_norm(v_params, 0.5)
             # (the record is filled element by element: no stack / cat inside a region that may be captured, see clip_grad_norm)
-            if graph_update == 3:
-                diag_row.copy_(torch.stack([n_pi, n_v, loss.detach(), advn.abs().max(), ratio.detach().max(), bad_in.float(), bad_g.float(),
-                                            torch.ones((), device=device)]).unsqueeze(0))
-            else:
-                for j, x in enumerate((n_pi, n_v, loss.detach(), advn.abs().max(), ratio.detach().max(), bad_in, bad_g)):
-                    diag_row[0, j].copy_(x)
+            for j, x in enumerate((n_pi, n_v, loss.detach(), advn.abs().max(), ratio.detach().max(), bad_in, bad_g)):
+                diag_row[0, j].copy_(x)
             diag.index_copy_(0, diag_pos % DIAG, diag_row)
             diag_pos.add_(1)
             opt.step()
+            if PROBE is not None and torch.cuda.is_current_stream_capturing():
+                # (AUV_PPO_PROBE=1, tools/graph_update_probe.sh: keep the captured step's record inputs alive so that their
+                # addresses can be compared with every other live tensor once a replay shows a corrupt record)
+                PROBE.update(bad_in=bad_in, bad_g=bad_g, n_pi=n_pi, n_v=n_v, loss=loss, max_adv=advn.abs().max(), ratio_max=ratio.detach().max())
             return loss
 
         # --graph-update: a minibatch's forward, backward, clipping and Adam step as ONE captured device graph with static input
@@ -360,8 +405,12 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
                             minibatch_step(*upd_in)
                     torch.cuda.current_stream(device).wait_stream(side)
                     upd_graph = torch.cuda.CUDAGraph()
+                    if PROBE is not None:
+                        upd_graph.enable_debug_mode()
                     with torch.cuda.graph(upd_graph):
                         upd_loss = minibatch_step(*upd_in)
+                    if PROBE is not None:               # (the captured graph's nodes and edges: is it ONE chain?)
+                        upd_graph.debug_dump(os.environ.get("AUV_PPO_PROBE_DOT", "/tmp/ppo_update_graph.dot"))
                     continue
                 for dst, src in zip(upd_in, (O, A, LP, ADV, RETn)):
                     torch.index_select(src, 0, mb, out=dst)
@@ -387,6 +436,9 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
                             weight_l1=float(sum(p_.detach().abs().sum() for p_ in pi_params)),
                             cross_track=cte, episodes=int(ep.shape[0]), goal_rate=goal, collision_rate=col, ep_return=ep_ret,
                             ep_len=ep_len, ep_progress=ep_prog, rollout_sps=world * n_total / t_roll_only, rollout_gae_sps=world * n_total / t_roll, sps=world * n_total / dt_all))
+        if PROBE and steps_bad:
+            probe_report(PROBE, diag_row, log)
+            PROBE.clear()
         if graph_update and steps_bad:
             # The captured update's own record shows values that cannot come from its inputs (a gradient norm of inf over
             # finite gradient elements, or a count of non-finite inputs far beyond the number of inputs): the replayed
@@ -421,6 +473,10 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
             % (avg(first, "mean_step_reward"), avg(last, "mean_step_reward"), avg(first, "surge"), avg(last, "surge"),
                avg(first, "heading_error"), avg(last, "heading_error"), avg(first, "goal_rate"), avg(last, "goal_rate"),
                avg(first, "collision_rate"), avg(last, "collision_rate"), k))
+    if worlds == "fresh" and rank == 0:
+        st = env.fresh_stats()
+        log("fresh worlds: %d rebuilt beside the rollouts, %d episode(s) had to re-use their world (0 = every reset met an unseen one)"
+            % (st["regenerated"], st["reused"]))
     env.close()
     return history
 
@@ -430,7 +486,7 @@ if __name__ == "__main__":
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--updates", type=int, default=10)
     ap.add_argument("--rollout", type=int, default=32)
-    ap.add_argument("--worlds", default="generated", choices=["generated", "host"])
+    ap.add_argument("--worlds", default="fresh", choices=["fresh", "generated", "host"])
     ap.add_argument("--regen", type=int, default=0, help="regenerate the world bank on the device every this many updates (0: never)")
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--task", default="colav", choices=["colav", "pathfollow"])
@@ -439,7 +495,8 @@ if __name__ == "__main__":
     ap.add_argument("--minibatches", type=int, default=32)
     ap.add_argument("--graph-rollout", type=int, default=0, help="1: one captured device graph per chain and rollout step (torch-module policy only)")
     ap.add_argument("--graph-update", type=int, default=0,
-                    help="1: a minibatch's forward, backward, clipping and Adam step as one captured device graph (single rank)")
+                    help="1 (EXPERIMENTAL): a minibatch's forward, backward, clipping and Adam step as one captured device graph (single "
+                         "rank).  Every replay writes a record; the update falls back to eager the moment a record is corrupt")
     ap.add_argument("--policy-bf16", type=int, default=0,
                     help="1: the fused policy launch multiplies with bf16 weights on the bf16 matrix cores (faster rollouts, ~1e-2 on the "
                          "action means: the PPO ratio then compares log-probabilities of slightly different policies); default 0 = exact f32")
