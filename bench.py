@@ -68,7 +68,7 @@ def parse():
                          "scenario): --worlds-per-env bank slots per env, every slot an episode leaves is rebuilt on the device by a "
                          "refill pass beside the step path, so the generator's cost is INSIDE the timed region; `comparison` then "
                          "carries the rate of the same loop over a bank that just cycles")
-    ap.add_argument("--fresh-period", type=int, default=8, help="--fresh-worlds: a refill pass every this many step calls")
+    ap.add_argument("--fresh-period", type=int, default=16, help="--fresh-worlds: a refill pass every this many step calls")
     ap.add_argument("--fresh-batch", type=int, default=64, help="--fresh-worlds: worlds per refill pass at most")
     ap.add_argument("--graph", type=int, default=0,
                     help="0 (default): eager launches; K > 0: K consecutive steps captured in ONE hipGraph over the action "
@@ -298,7 +298,7 @@ def main():
     if fresh and args.workload != "moving28":
         raise SystemExit("--fresh-worlds builds the reference's MovingObstacles scenario on the device: --workload moving28")
     if fresh:
-        wpe = max(2, wpe)
+        wpe = 3 if args.worlds_per_env == 2 else max(2, wpe)     # (the mode's default depth; an explicit value is honoured)
     if args.bank_cache and not fresh:
         import hashlib
         import tempfile
@@ -367,6 +367,8 @@ def main():
     if sub <= 0:
         want4 = n_local >= 2048 and env.effective_step_mode(n_local // 4) == "one_launch"
         sub = 4 if (want4 and api in ("pipelined", "async") and args.actions == "uniform") else 1
+        if sub == 4 and fresh:
+            sub = 3      # (at most four kernels run side by side on this GPU: three chains and the refill passes' stream)
     if api == "step":
         sub = 1
     t_probe = 0.0

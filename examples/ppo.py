@@ -169,7 +169,7 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
     if worlds == "fresh":
         # a new scenario on every reset; the world of an episode = f(seed, GLOBAL environment index, serial): data-parallel ranks
         # own disjoint index ranges
-        bank = FreshWorlds(depth=2, n_moving=nm, n_static=ns, seed=1000 * seed, env_index_base=rank * envs, batch_cap=64, period=8)
+        bank = FreshWorlds(n_moving=nm, n_static=ns, seed=1000 * seed, env_index_base=rank * envs)
     elif worlds == "generated":
         bank = GeneratedWorlds(2 * envs, nm, ns, seed=1000 * seed + rank)
     else:
@@ -294,7 +294,7 @@ def train(envs=4096, updates=10, rollout=32, device="cuda:0", seed=0, log=print,
                 buf[i]["t"].zero_()                       # (on the caller's stream, BEFORE the chain is told to wait for it)
                 streams[i].wait_stream(cur)               # (the update of the previous round wrote the weights there)
             for t_roll_step in range(T):
-                if worlds == "fresh" and t_roll_step % 8 == 0:
+                if worlds == "fresh" and t_roll_step % 16 == 0:
                     env.refill()                              # (this loop steps slice by slice: the library cannot tick by itself)
                 for i in range(K):
                     with torch.cuda.stream(streams[i]):

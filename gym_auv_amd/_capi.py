@@ -182,6 +182,7 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_fresh_worlds_create": (C.c_int, [vp, i32, i32, i32, C.c_uint64, C.c_int64, i32, i32, vp, vp, i32]),
         "auv_fresh_worlds_refill": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), i32]),
         "auv_fresh_worlds_stats": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+        "auv_fresh_worlds_set_stream": (C.c_int, [vp, vp]),
         "auv_fresh_worlds_draws": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), i32, vp, vp]),
         "auv_bank_bytes": (sz, [vp, i32]),
         "auv_read_bank": (C.c_int, [vp, i32, vp, sz, vp]),
@@ -209,7 +210,7 @@ EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",
                     "auv_set_action_ring", "auv_set_step_mode", "auv_feasibility_pooling",
                     "auv_generate_worlds", "auv_bank_bytes", "auv_read_bank",
-                    "auv_fresh_worlds_create", "auv_fresh_worlds_refill", "auv_fresh_worlds_stats", "auv_fresh_worlds_draws",
+                    "auv_fresh_worlds_create", "auv_fresh_worlds_refill", "auv_fresh_worlds_stats", "auv_fresh_worlds_draws", "auv_fresh_worlds_set_stream",
                     "auv_abi_version", "auv_last_error"]
 
 # tables of a generated bank (auv_read_bank): id, dtype, trailing shape ('P' = AUV_GEN_POLY_CAP,

@@ -217,13 +217,19 @@ class BatchedAuvEnv:
         t0 = time.perf_counter()
         # (probe_streams = False: any k streams -- under a counter-collecting profiler dispatches are serialised, the
         # probe would find no two streams side by side and the batch would not be split at all)
-        if k > 1 and probe_streams:
+        # fresh worlds: the refill passes need a stream that shares no hardware queue with a chain -- one MORE stream than chains
+        # out of the same mutually-overlapping set (at most four kernels run side by side here: ask for three chains then)
+        extra = 1 if (self._fresh is not None and probe_streams) else 0
+        if k + extra > 1 and probe_streams:
             # (the probe times two 300 us kernels against the wall clock: a busy host -- eight ranks starting at once -- can
             # make a pair look serialised, so a short selection is tried again before it is believed)
             for _attempt in range(3):
-                streams = self._concurrent_streams(k, first=cur if inline_first else None)
-                if len(streams) >= k:
+                streams = self._concurrent_streams(k + extra, first=cur if inline_first else None)
+                if len(streams) >= k + extra:
                     break
+            if extra and len(streams) >= 2:
+                self._fresh_stream = streams.pop()            # (kept alive here: the library only borrows it)
+                _check(_LIB.auv_fresh_worlds_set_stream(self._h, C.c_void_p(self._fresh_stream.cuda_stream)), "auv_fresh_worlds_set_stream")
         else:
             streams = ([cur] if inline_first else []) + [torch.cuda.Stream(device=self.device) for _ in range(k - int(inline_first))]
         self.stream_probe_s = time.perf_counter() - t0
@@ -518,6 +524,11 @@ class BatchedAuvEnv:
                                             unit.ctypes.data_as(C.c_void_p), nseg.ctypes.data_as(C.c_void_p), len(nseg)),
                "auv_fresh_worlds_create")
         self._fresh = spec
+        # the passes' stream: one that runs side by side with the caller's current stream (set_sub_batches picks again for chains)
+        pair = self._concurrent_streams(2, first=torch.cuda.current_stream(self.device))
+        if len(pair) == 2:
+            self._fresh_stream = pair[1]
+            _check(_LIB.auv_fresh_worlds_set_stream(self._h, C.c_void_p(self._fresh_stream.cuda_stream)), "auv_fresh_worlds_set_stream")
         self._gen = GeneratedWorlds(n_worlds=spec.depth * self.n_envs, n_moving=spec.n_moving, n_static=spec.n_static, seed=spec.seed)
         self._log_first = 0
         self.n_worlds = spec.depth * self.n_envs
@@ -532,18 +543,18 @@ class BatchedAuvEnv:
         return 1, (C.c_int32 * 2)(0, self.n_envs), (C.c_void_p * 1)(torch.cuda.current_stream(self.device).cuda_stream)
 
     def refill(self, flush: bool = False):
-        """Fresh worlds: publish the refill passes that have completed and start another (auv_fresh_worlds_refill).  The step
-        calls of the whole batch do this by themselves every `period` calls; a loop that steps slices one by one
-        (step_slice) calls it.  `flush`: synchronise, then run passes until every slot left so far is ready again."""
+        """Fresh worlds: enqueue a refill pass (auv_fresh_worlds_refill).  The step calls of the whole batch do this by themselves
+        every `period` calls; a loop that steps slices one by one (step_slice) calls it.  `flush`: synchronise, then run passes
+        until every slot left so far is ready again."""
         if self._fresh is None:
             raise RuntimeError("refill(): the env was not built with worlds=FreshWorlds(...)")
         k, b, st = self._chains()
         _check(_LIB.auv_fresh_worlds_refill(self._h, k, b, st, int(bool(flush))), "auv_fresh_worlds_refill")
 
     def fresh_stats(self) -> Dict[str, int]:
-        """`regenerated` worlds built and published since the mode was entered, `reused`: episodes that started in the world
-        they had just finished because their next slot was not ready (should stay 0), `queued` slots waiting for a pass,
-        `passes_issued` / `passes_published`, `depth`, `batch_cap`.  Synchronising (one small device-to-host copy)."""
+        """`regenerated` worlds rebuilt since the mode was entered, `reused`: episodes that started in the world they had just
+        finished because their next slot was not ready (should stay 0), `queued` slots waiting for a pass, `passes_issued` /
+        `passes_published` (enqueued / completed), `depth`, `batch_cap`.  One small device-to-host copy."""
         out = (C.c_int64 * 8)()
         _check(_LIB.auv_fresh_worlds_stats(self._h, out), "auv_fresh_worlds_stats")
         return dict(on=int(out[0]), regenerated=int(out[1]), reused=int(out[2]), queued=int(out[3]), passes_issued=int(out[4]),

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <chrono>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "auv_device.h"
@@ -116,17 +117,19 @@ struct auv_handle {
     int depth = 0, cap = 0, period = 0, n_draws = 0;
     unsigned long long seed = 0;
     long long env_base = 0;
-    hipStream_t side = nullptr;               // the refill pass's stream (lowest priority: a queue of its own)
+    hipStream_t side = nullptr;               // the refill pass's stream: a plain stream of the library's, or the caller's choice
+    bool side_owned = false;                  // (auv_fresh_worlds_set_stream: one that shares no hardware queue with the chains)
     std::vector<void*> allocs;                // shadow environments + queue / state words
     AuvDev shadow;                            // `cap` environments nobody steps: where a regenerated slot's reset rows are computed
     FwBatch batch;                            // device: the pass in flight on `side`
     int32_t* batch_block = nullptr;           // [1 + 3 cap]: count, slot[], env[], serial[] (one D2H copy per pass)
     double* draws = nullptr;                  // [cap][n_draws]
     int32_t* env_next_serial = nullptr;       // [N]
-    static const int NB = 4;                  // passes the host may have in flight (pinned read-back buffers)
-    int32_t* pinned[NB] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t done[NB] = {nullptr, nullptr, nullptr, nullptr};
-    unsigned long long issued = 0, published = 0, calls = 0, regenerated = 0;
+    static const int NEV = 64;                // pacing events (ring): a pass starts when chain 0 has reached the step it was enqueued behind
+    hipEvent_t pace[NEV];
+    unsigned long long issued = 0, calls = 0;
+    hipGraphExec_t pass_exec = nullptr;       // the pass as ONE graph launch (captured at create)
+    hipGraph_t pass_graph = nullptr;
   } fw;
 };
 
@@ -543,95 +546,79 @@ static int rdv_trial(auv_handle* h, hipStream_t cs) {
 // ---- a fresh world on every reset: the refill pass (host side) -------------------------------------------------------------
 // The reference builds a new scenario whenever an episode ends (environment.py:176-218 reset -> _generate,
 // envs/movingobstacles.py:28-95).  Here (auv_device.h: auv_next_world) a finished environment moves to its next bank slot and
-// queues the slot it leaves; this pass -- enqueued on a low-priority side stream every `period` step calls, never waited for by
-// the step path -- pops up to `cap` queued slots ON THE DEVICE, draws their worlds from the counter-based generator
+// queues the slot it leaves; this pass -- one graph launch on a side stream every `period` step calls, never waited for by the
+// step path -- pops up to `cap` queued slots ON THE DEVICE, draws their worlds from the counter-based generator
 // (seed, global environment index, serial), rebuilds their tables (k5_generate) and their reset rows (the step's own fresh-list
-// kernels on `cap` shadow environments), and copies the list of what it did to pinned host memory.  When the host SEES the
-// pass complete (hipEventQuery at a later step call: no wait), it enqueues a publish kernel on the stream of every chain that
-// owns one of the slots; only that kernel makes a slot bindable.  So every launch that can bind a regenerated slot was
-// enqueued -- and therefore started -- after the slot's tables were complete in memory: visibility rides on kernel boundaries,
-// nothing in the step path fences, and the step path never waits for the generator.
+// kernels on `cap` shadow environments), and its last kernel flips them to READY.  No host round trip anywhere: the host may
+// be thousands of launches ahead of the GPU (a first version published READY by a kernel on the chains' own streams once the
+// host had seen the pass complete -- behind an open-loop backlog that was 100+ steps too late for the episodes that end
+// within a few dozen steps of their reset, a quarter of them under a random policy).  Coherence: see restore_env<COH>.
+// A pass is paced in GPU time: it waits for an event recorded on the first chain's stream at the call that enqueued it.
 static void fw_disable(auv_handle* h) {
   auv_handle::Fresh& f = h->fw;
   if (f.side) (void)hipStreamSynchronize(f.side);
-  for (int b = 0; b < auv_handle::Fresh::NB; b++) {
-    if (f.done[b]) (void)hipEventDestroy(f.done[b]);
-    if (f.pinned[b]) (void)hipHostFree(f.pinned[b]);
-    f.done[b] = nullptr, f.pinned[b] = nullptr;
+  if (f.on || f.side) {
+    for (int b = 0; b < auv_handle::Fresh::NEV; b++)
+      if (f.pace[b]) (void)hipEventDestroy(f.pace[b]), f.pace[b] = nullptr;
   }
-  if (f.side) (void)hipStreamDestroy(f.side);
-  f.side = nullptr;
+  if (f.pass_exec) (void)hipGraphExecDestroy(f.pass_exec);
+  if (f.pass_graph) (void)hipGraphDestroy(f.pass_graph);
+  f.pass_exec = nullptr, f.pass_graph = nullptr;
+  if (f.side && f.side_owned) (void)hipStreamDestroy(f.side);
+  f.side = nullptr, f.side_owned = false;
   free_pool(f.allocs);
   f.on = false;
-  f.issued = f.published = f.calls = f.regenerated = 0;
+  f.issued = f.calls = 0;
   h->d.fw_state = nullptr, h->d.fw_serial = nullptr, h->d.fw_queue = nullptr, h->d.fw_ctl = nullptr, h->d.fw_cap = 0;
 }
 
-static int fw_enqueue_pass(auv_handle* h) {
+// the kernels of one pass, in order, on `st` (captured once into a graph; also launchable one by one)
+static void fw_pass_kernels(auv_handle* h, hipStream_t st) {
   auv_handle::Fresh& f = h->fw;
-  const int b = (int)(f.issued % auv_handle::Fresh::NB);
   const AuvDev& d = h->d;
   const int grid = f.cap < h->gen_grid ? f.cap : h->gen_grid;
-  auv_launch_fw_bind(f.batch, d.fw_queue, d.fw_ctl, d.fw_cap, d.n, f.cap, f.env_next_serial, f.shadow.world_idx, f.shadow.fresh_count, f.side);
-  auv_launch_draws(f.draws, f.n_draws, h->gen_moving, h->gen_static, f.seed, f.env_base, f.batch.env, f.batch.serial, f.cap, f.batch.count, grid, f.side);
-  auv_launch_generate(h->gen, f.draws, 0, f.cap, grid, f.side, f.batch.slot, f.batch.count);
-  auv_launch_fw_shadow_reset(f.shadow, f.batch.count, f.side);
-  auv_launch_k2_fresh(f.shadow, f.side);
-  auv_launch_k3_fresh(f.shadow, nullptr, f.side);
-  auv_launch_harvest(f.shadow, f.cap, f.side, f.batch.count);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(f.pinned[b], f.batch_block, (size_t)(1 + 3 * f.cap) * sizeof(int32_t), hipMemcpyDeviceToHost, f.side));
-  HIP_TRY(hipEventRecord(f.done[b], f.side));
+  auv_launch_fw_bind(f.batch, d.fw_queue, d.fw_ctl, d.fw_cap, d.n, f.cap, f.env_next_serial, f.shadow.world_idx, f.shadow.fresh_count, st);
+  auv_launch_draws(f.draws, f.n_draws, h->gen_moving, h->gen_static, f.seed, f.env_base, f.batch.env, f.batch.serial, f.cap, f.batch.count, grid, st);
+  auv_launch_generate(h->gen, f.draws, 0, f.cap, grid, st, f.batch.slot, f.batch.count);
+  auv_launch_fw_shadow_reset(f.shadow, f.batch.count, st);
+  auv_launch_k2_fresh(f.shadow, st);
+  auv_launch_k3_fresh(f.shadow, nullptr, st);
+  auv_launch_harvest(f.shadow, f.cap, st, f.batch.count);
+  auv_launch_fw_ready(f.batch, d.fw_state, d.fw_serial, d.fw_ctl, f.cap, st);
+}
+
+// One refill pass on the side stream.  `behind` (nullable): the pass starts when THAT stream has reached this point -- the
+// host may run thousands of launches ahead of the GPU (open-loop chains, a whole rollout enqueued by one call), and a pass
+// that ran at enqueue time would find an empty queue long before the episodes it is meant for have ended.
+static int fw_enqueue_pass(auv_handle* h, hipStream_t behind, bool paced) {
+  auv_handle::Fresh& f = h->fw;
+  static const bool no_pace = getenv("AUV_FW_NO_PACE") != nullptr;     // (experiments: tools/side_stream_ab.sh)
+  if (paced && !no_pace) {
+    hipEvent_t ev = f.pace[f.issued % auv_handle::Fresh::NEV];
+    HIP_TRY(hipEventRecord(ev, behind));
+    HIP_TRY(hipStreamWaitEvent(f.side, ev, 0));
+  }
+  if (f.pass_exec) HIP_TRY(hipGraphLaunch(f.pass_exec, f.side));
+  else {
+    fw_pass_kernels(h, f.side);
+    HIP_TRY(hipGetLastError());
+  }
   f.issued += 1;
   return AUV_OK;
 }
 
-// passes the host can see complete -> publish kernels on the chains' streams (slice i = [bounds[i], bounds[i + 1]) runs on streams[i])
-static int fw_publish_ready(auv_handle* h, int n_slices, const int32_t* bounds, void* const* streams) {
-  auv_handle::Fresh& f = h->fw;
-  while (f.published < f.issued) {
-    const int b = (int)(f.published % auv_handle::Fresh::NB);
-    const hipError_t q = hipEventQuery(f.done[b]);
-    if (q == hipErrorNotReady) {
-      (void)hipGetLastError();
-      break;
-    }
-    HIP_TRY(q);
-    const int32_t* blk = f.pinned[b];
-    const int count = blk[0];
-    for (int c0 = 0; c0 < count; c0 += AUV_FW_LIST) {
-      FwList l;
-      l.count = count - c0 < AUV_FW_LIST ? count - c0 : AUV_FW_LIST;
-      for (int i = 0; i < l.count; i++) l.slot[i] = blk[1 + c0 + i], l.serial[i] = blk[1 + 2 * f.cap + c0 + i];
-      for (int s = 0; s < n_slices; s++) {
-        bool any = false;
-        for (int i = 0; i < l.count && !any; i++) {
-          const int e = blk[1 + f.cap + c0 + i];
-          any = e >= bounds[s] && e < bounds[s + 1];
-        }
-        if (any) auv_launch_fw_publish(l, bounds[s], bounds[s + 1] - bounds[s], h->d.n, h->d.fw_state, h->d.fw_serial, (hipStream_t)streams[s]);
-      }
-    }
-    HIP_TRY(hipGetLastError());
-    f.regenerated += (unsigned long long)count;
-    f.published += 1;
-  }
-  return AUV_OK;
-}
-
-// once per step call of the whole batch (the callers name the chains' streams): publish what is complete; every `period`-th call
-// start a new pass if a read-back buffer is free.  Never waits.  Skipped while a stream is being captured.
+// once per step call of the whole batch (the callers name the chains' streams): every `period`-th call a pass is enqueued,
+// paced behind the first chain.  Never waits; skipped while a stream is being captured.
 static int fw_tick(auv_handle* h, int n_slices, const int32_t* bounds, void* const* streams, int n_steps = 1) {
   auv_handle::Fresh& f = h->fw;
   if (!f.on) return AUV_OK;
+  (void)bounds;
   for (int s = 0; s < n_slices; s++)
     if (stream_capturing((hipStream_t)streams[s])) return AUV_OK;
-  int rc = fw_publish_ready(h, n_slices, bounds, streams);
-  if (rc) return rc;
   const unsigned long long before = f.calls / (unsigned long long)f.period;
   f.calls += (unsigned long long)n_steps;
-  if (f.calls / (unsigned long long)f.period != before && f.issued - f.published < (unsigned long long)auv_handle::Fresh::NB) rc = fw_enqueue_pass(h);
-  return rc;
+  if (f.calls / (unsigned long long)f.period != before) return fw_enqueue_pass(h, (hipStream_t)streams[0], true);
+  return AUV_OK;
 }
 
 extern "C" {
@@ -974,6 +961,7 @@ int auv_fresh_worlds_create(auv_handle_t* h, int32_t depth, int32_t n_moving, in
   rc |= dev_alloc(ap, &d.fw_ctl, 8);
   rc |= dev_alloc(ap, &f.env_next_serial, (size_t)n);
   rc |= dev_alloc(ap, &f.batch_block, (size_t)(1 + 3 * batch_cap));
+  for (int b = 0; b < auv_handle::Fresh::NEV; b++) f.pace[b] = nullptr;
   rc |= dev_alloc(ap, &f.draws, (size_t)batch_cap * nd);
   d.fw_cap = W;
   f.batch.count = f.batch_block, f.batch.slot = f.batch_block + 1, f.batch.env = f.batch_block + 1 + batch_cap, f.batch.serial = f.batch_block + 1 + 2 * batch_cap;
@@ -1015,12 +1003,28 @@ int auv_fresh_worlds_create(auv_handle_t* h, int32_t depth, int32_t n_moving, in
     HIP_TRY(hipMemcpy(d.fw_queue, q.data(), (size_t)W * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(f.env_next_serial, ns.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   }
-  int lo = 0, hi = 0;
-  HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo: the numerically greatest = least priority
-  HIP_TRY(hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, lo));
-  for (int b = 0; b < auv_handle::Fresh::NB; b++) {
-    HIP_TRY(hipHostMalloc((void**)&f.pinned[b], (size_t)(1 + 3 * batch_cap) * sizeof(int32_t), hipHostMallocDefault));
-    HIP_TRY(hipEventCreateWithFlags(&f.done[b], hipEventDisableTiming));
+  // The pass's stream: a PLAIN stream.  (Measured, tools/side_stream_ab.sh: merely creating a stream with a non-default
+  // priority -- lowest or highest -- halves the throughput of four sub-batch chains on this stack, 68 M against 139 M env-steps/s
+  // with the stream idle: two of the four chains then share a hardware queue.)
+  HIP_TRY(hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking));
+  f.side_owned = true;
+  for (int b = 0; b < auv_handle::Fresh::NEV; b++) HIP_TRY(hipEventCreateWithFlags(&f.pace[b], hipEventDisableTiming));
+  f.issued = f.calls = 0;
+  {
+    // the eight kernels of a pass as ONE graph: a pass costs the host one launch, not eight (every argument is a fixed
+    // device buffer of this mode; what a pass works on it learns on the device)
+    f.on = true;                                                   // (fw_disable below tears down whatever exists on failure)
+    HIP_TRY(hipStreamBeginCapture(f.side, hipStreamCaptureModeThreadLocal));
+    fw_pass_kernels(h, f.side);
+    hipGraph_t g = nullptr;
+    hipError_t ce = hipStreamEndCapture(f.side, &g);
+    if (ce == hipSuccess && getenv("AUV_FW_NO_GRAPH") == nullptr) {
+      f.pass_graph = g;
+      HIP_TRY(hipGraphInstantiate(&f.pass_exec, g, nullptr, nullptr, 0));
+    } else {
+      (void)hipGetLastError();
+      if (g) (void)hipGraphDestroy(g);
+    }
   }
   HIP_TRY(hipMemcpy((void*)d.self, &d, sizeof(AuvDev), hipMemcpyHostToDevice));   // the one-launch step reads its tables through this copy
   HIP_TRY(hipDeviceSynchronize());
@@ -1035,27 +1039,30 @@ int auv_fresh_worlds_refill(auv_handle_t* h, int32_t n_slices, const int32_t* bo
   if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));
   auv_handle::Fresh& f = h->fw;
-  if (!flush) {
-    rc = fw_publish_ready(h, n_slices, bounds, streams);
-    if (rc == AUV_OK && f.issued - f.published < (unsigned long long)auv_handle::Fresh::NB) rc = fw_enqueue_pass(h);
-    return rc;
-  }
-  // flush: until the queue is empty -- every slot an environment has left so far is READY again when this returns (the
-  // chains' streams are synchronised first: their finish waves have queued what they will queue)
+  if (!flush) return fw_enqueue_pass(h, (hipStream_t)streams[0], true);
+  // flush: the chains' streams are synchronised first (their finish waves have queued what they will queue), then passes run
+  // until the queue is empty -- every slot an environment has left so far is READY again when this returns
   for (int s = 0; s < n_slices; s++) HIP_TRY(hipStreamSynchronize((hipStream_t)streams[s]));
   for (int pass = 0; pass < (1 << 20); pass++) {
     HIP_TRY(hipStreamSynchronize(f.side));
-    rc = fw_publish_ready(h, n_slices, bounds, streams);
-    if (rc) return rc;
     unsigned int ctl[2] = {0, 0};
     HIP_TRY(hipMemcpy(ctl, h->d.fw_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
-    if (ctl[0] == ctl[1] && f.issued == f.published) break;
-    if (f.issued == f.published) {
-      rc = fw_enqueue_pass(h);
-      if (rc) return rc;
-    }
+    if (ctl[0] == ctl[1]) break;
+    rc = fw_enqueue_pass(h, nullptr, false);
+    if (rc) return rc;
   }
-  for (int s = 0; s < n_slices; s++) HIP_TRY(hipStreamSynchronize((hipStream_t)streams[s]));
+  return AUV_OK;
+}
+
+int auv_fresh_worlds_set_stream(auv_handle_t* h, void* stream) {
+  REQUIRE_READY(h);
+  auv_handle::Fresh& f = h->fw;
+  if (!f.on) return fail(AUV_ESTATE, "auv_fresh_worlds_set_stream: auv_fresh_worlds_create first");
+  if (!stream) return fail(AUV_EINVAL, "auv_fresh_worlds_set_stream: a stream of the caller's (not the NULL stream)");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(f.side));
+  if (f.side_owned) HIP_TRY(hipStreamDestroy(f.side));
+  f.side = (hipStream_t)stream, f.side_owned = false;
   return AUV_OK;
 }
 
@@ -1065,10 +1072,12 @@ int auv_fresh_worlds_stats(auv_handle_t* h, int64_t* out8) {
   const auv_handle::Fresh& f = h->fw;
   if (!f.on) return AUV_OK;
   HIP_TRY(hipSetDevice(h->device));
-  unsigned int ctl[4] = {0, 0, 0, 0};
+  unsigned int ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(hipMemcpy(ctl, h->d.fw_ctl, sizeof(ctl), hipMemcpyDeviceToHost));
-  out8[0] = 1, out8[1] = (int64_t)f.regenerated, out8[2] = (int64_t)ctl[2], out8[3] = (int64_t)(unsigned int)(ctl[0] - ctl[1]);
-  out8[4] = (int64_t)f.issued, out8[5] = (int64_t)f.published, out8[6] = f.depth, out8[7] = f.cap;
+  unsigned long long regen = 0, done = 0;
+  memcpy(&regen, ctl + 4, 8), memcpy(&done, ctl + 6, 8);
+  out8[0] = 1, out8[1] = (int64_t)regen, out8[2] = (int64_t)ctl[2], out8[3] = (int64_t)(unsigned int)(ctl[0] - ctl[1]);
+  out8[4] = (int64_t)f.issued, out8[5] = (int64_t)done, out8[6] = f.depth, out8[7] = f.cap;
   return AUV_OK;
 }
 

@@ -202,10 +202,19 @@ struct EnvPre {
 // and fetch it through the scalar cache.
 __device__ __forceinline__ int auv_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ EnvDesc auv_make_desc(const AuvDev& d, int w) {
+// COH: every load agent-scope (sc1) -- the tables of a slot that a refill pass on another stream may have rebuilt while this
+// launch was already running (fresh-world mode; see restore_env)
+template <bool COH = false> __device__ __forceinline__ EnvDesc auv_make_desc(const AuvDev& d, int w) {
   EnvDesc ed;
-  ed.k0 = d.obs_off[w], ed.m0 = d.mv_off[w], ed.p0 = d.poly_off[w], ed.c0 = d.chunk_off[w], ed.kn0 = d.knot_off[w];
-  ed.K = d.obs_cnt[w], ed.M = d.mv_cnt[w], ed.P = d.poly_cnt[w], ed.nch = d.chunk_cnt[w], ed.nk = d.knot_cnt[w];
+  if constexpr (COH) {
+    ed.k0 = d.obs_off[w], ed.m0 = d.mv_off[w], ed.p0 = d.poly_off[w], ed.c0 = d.chunk_off[w], ed.kn0 = d.knot_off[w];   // (slot offsets never change)
+    ed.K = __hip_atomic_load(d.obs_cnt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ed.M = __hip_atomic_load(d.mv_cnt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ed.P = __hip_atomic_load(d.poly_cnt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ed.nch = __hip_atomic_load(d.chunk_cnt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ed.nk = __hip_atomic_load(d.knot_cnt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    ed.k0 = d.obs_off[w], ed.m0 = d.mv_off[w], ed.p0 = d.poly_off[w], ed.c0 = d.chunk_off[w], ed.kn0 = d.knot_off[w];
+    ed.K = d.obs_cnt[w], ed.M = d.mv_cnt[w], ed.P = d.poly_cnt[w], ed.nch = d.chunk_cnt[w], ed.nk = d.knot_cnt[w];
+  }
   ed.w = w;
   return ed;
 }
@@ -308,6 +317,18 @@ template <bool WT> __device__ __forceinline__ void auv_st(double4* p, const doub
 template <bool WT, typename T> __device__ __forceinline__ T auv_ld(const T* p) {
   if constexpr (WT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
 }
+template <bool WT> __device__ __forceinline__ double4 auv_ld4(const double4* p) {
+  if constexpr (WT)
+    return make_double4(__hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        __hip_atomic_load(&p->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&p->w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+}
+template <bool WT> __device__ __forceinline__ int2 auv_ld2i(const int2* p) {
+  if constexpr (WT) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
+  } else return *p;
+}
 // every global store this wave has issued so far is complete (for the sc1 forms: visible to the whole device)
 __device__ __forceinline__ void auv_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -342,6 +363,21 @@ __device__ __forceinline__ int auv_wave_scan_incl(int v) {
   return v;
 }
 __device__ __forceinline__ int auv_wave_last(const int v) { return __builtin_amdgcn_readlane(v, AUV_WAVE - 1); }
+// the same for doubles (k5_generate's block-wide prefix sums): lanes shifted in from outside a row contribute +0.0
+template <int CTRL, int ROWS, bool BOUND> __device__ __forceinline__ double auv_dpp_f64_rows(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xF, BOUND);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xF, BOUND);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double auv_wave_scan_incl_f64(double v) {
+  v += auv_dpp_f64_rows<0x111, 0xF, true>(v);    // row_shr:1
+  v += auv_dpp_f64_rows<0x112, 0xF, true>(v);    // row_shr:2
+  v += auv_dpp_f64_rows<0x114, 0xF, true>(v);    // row_shr:4
+  v += auv_dpp_f64_rows<0x118, 0xF, true>(v);    // row_shr:8
+  v += auv_dpp_f64_rows<0x142, 0xA, false>(v);   // row_bcast:15 -> rows 1, 3
+  v += auv_dpp_f64_rows<0x143, 0xC, false>(v);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
 __device__ __forceinline__ double auv_wave_sum(double v) {
   v += auv_dpp_f64<0xB1>(v);
   v += auv_dpp_f64<0x4E>(v);

@@ -30,19 +30,11 @@ struct GenOut {              // writable views of the bank tables (fixed-capacit
 
 #define GEN_SCRATCH ((GEN_NK + GEN_NK * 8) + 4 * GEN_NK)
 
-// fresh-world mode: one refill pass's batch in device memory (rows filled by k_fw_bind) ...
+// fresh-world mode: one refill pass's batch in device memory (rows filled by k_fw_bind)
 struct FwBatch {
   int32_t *slot, *env, *serial;   // [cap]
   int32_t* count;                 // [1]
 };
-// ... and what the host hands a publish launch BY VALUE once it has read the batch back (no device buffer whose reuse would
-// have to be ordered against launches on other streams)
-#define AUV_FW_LIST 64
-struct FwList {
-  int32_t count;
-  int32_t slot[AUV_FW_LIST], serial[AUV_FW_LIST];
-};
-
 size_t auv_gen_scratch_doubles(void);
 void auv_launch_generate(const GenOut& g, const double* draws, int w_first, int n_worlds, int grid, hipStream_t st,
                          const int32_t* slots = nullptr, const int32_t* count_dev = nullptr);
@@ -50,4 +42,4 @@ void auv_launch_draws(double* draws, int n_draws, int n_moving, int n_static, un
                       const int32_t* serials, int n_rows, const int32_t* count_dev, int grid, hipStream_t st);
 void auv_launch_fw_bind(const FwBatch& b, int32_t* queue, unsigned int* ctl, int q_cap, int n_envs, int cap, int32_t* env_next_serial,
                         int32_t* shadow_world_idx, int32_t* shadow_fresh_count, hipStream_t st);
-void auv_launch_fw_publish(const FwList& l, int e0, int ne, int n_envs, int32_t* state, int32_t* serial, hipStream_t st);
+void auv_launch_fw_ready(const FwBatch& b, int32_t* state, int32_t* serial, unsigned int* ctl, int cap, hipStream_t st);

@@ -224,6 +224,13 @@ __global__ void k_derive(AuvDev d) {
 // The reset observation (navigate + perceive at the initial pose) is a per-world constant that
 // was computed once at load time; here it is copied.  While those rows are being computed
 // (w_ready == 0) the env is put on the fresh list instead.
+// COH (fresh-world mode): the world's tables and reset rows are read with agent-scope (sc1) loads.  A refill pass on a side
+// stream may have rebuilt slot w2 and flipped it to READY while THIS launch was already running -- kernel-boundary visibility
+// does not cover that, and this XCD's L2 / this CU's L1 may still hold lines of the slot's previous world (or lines shared
+// with a neighbouring slot's small records).  sc1 loads are served coherently across the XCDs; the pass's stores were complete
+// (its kernels had ended) before its last kernel made the slot READY, and READY was read with an agent-scope load too.  The
+// environment's NEXT step is another launch: its waves start behind a kernel boundary and read the tables the plain way.
+template <bool COH>
 __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int lane, int episodes,
                                             float* __restrict__ obs_out) {
   const int S = d.cfg.n_sensors;
@@ -236,24 +243,24 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
     // critical path and the compiler must assume that the rows alias, so the copy is written as:
     // every load that depends only on the world index (one trip to memory), the mover states (their
     // offset comes with the first trip), then all stores.
-    const EnvDesc nd = auv_make_desc(d, w2);
-    const double ix = ws2[3], iy = ws2[4], ipsi = ws2[5];
-    const uint8_t wcol = d.w_collision[w2];
+    const EnvDesc nd = auv_make_desc<COH>(d, w2);
+    const double ix = auv_ld<COH>(ws2 + 3), iy = auv_ld<COH>(ws2 + 4), ipsi = auv_ld<COH>(ws2 + 5);
+    const uint8_t wcol = auv_ld<COH>(d.w_collision + w2);
     double lv[4], ov[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int i = q * AUV_WAVE + lane;
-      lv[q] = (i < S) ? d.w_lidar[(size_t)w2 * S + i] : 0.0;
-      ov[q] = (i < 6 + S) ? d.w_obs64[(size_t)w2 * (6 + S) + i] : 0.0;
+      lv[q] = (i < S) ? auv_ld<COH>(d.w_lidar + (size_t)w2 * S + i) : 0.0;
+      ov[q] = (i < 6 + S) ? auv_ld<COH>(d.w_obs64 + (size_t)w2 * (6 + S) + i) : 0.0;
     }
     double row = 0.0;
-    if (lane < 8) row = d.w_info[8 * (size_t)w2 + lane];
-    else if (lane < 16) row = d.w_nav[8 * (size_t)w2 + lane - 8];
+    if (lane < 8) row = auv_ld<COH>(d.w_info + 8 * (size_t)w2 + lane);
+    else if (lane < 16) row = auv_ld<COH>(d.w_nav + 8 * (size_t)w2 + lane - 8);
     uint8_t nb = 0;
     int2 lm = make_int2(0, 0);
-    if (lane < d.k_max) nb = d.w_nearby[(size_t)w2 * d.k_max + lane], lm = d.w_limits[(size_t)w2 * d.k_max + lane];
+    if (lane < d.k_max) nb = auv_ld<COH>(d.w_nearby + (size_t)w2 * d.k_max + lane), lm = auv_ld2i<COH>(d.w_limits + (size_t)w2 * d.k_max + lane);
     double4 mv0 = make_double4(0.0, 0.0, 0.0, 0.0);
-    if (lane < nd.M) mv0 = d.mv_init[nd.m0 + lane];
+    if (lane < nd.M) mv0 = auv_ld4<COH>(d.mv_init + nd.m0 + lane);
     if (lane == 0) {
       d.world_idx[e] = w2;
       d.env_desc[e] = nd;
@@ -263,7 +270,7 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
       d.collision[e] = wcol;
     }
     if (lane < nd.M) d.mover[(size_t)e * d.m_max + lane] = mv0;
-    for (int m = AUV_WAVE + lane; m < nd.M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = d.mv_init[nd.m0 + m];
+    for (int m = AUV_WAVE + lane; m < nd.M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = auv_ld4<COH>(d.mv_init + nd.m0 + m);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int i = q * AUV_WAVE + lane;
@@ -280,8 +287,8 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
   }
   if (lane == 0) {
     d.world_idx[e] = w2;
-    d.env_desc[e] = auv_make_desc(d, w2);
-    d.state[0 * n + e] = ws2[3], d.state[1 * n + e] = ws2[4], d.state[2 * n + e] = ws2[5];
+    d.env_desc[e] = auv_make_desc<COH>(d, w2);
+    d.state[0 * n + e] = auv_ld<COH>(ws2 + 3), d.state[1 * n + e] = auv_ld<COH>(ws2 + 4), d.state[2 * n + e] = auv_ld<COH>(ws2 + 5);
     d.state[3 * n + e] = 0.0, d.state[4 * n + e] = 0.0, d.state[5 * n + e] = 0.0;
     d.counters[e] = make_int4(0, 0, episodes, 0);
     if (!d.w_ready) {
@@ -291,29 +298,34 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
       d.collision[e] = 0;
       d.fresh_list[atomicAdd(d.fresh_count, 1)] = e;
     } else {
-      d.collision[e] = d.w_collision[w2];
+      d.collision[e] = auv_ld<COH>(d.w_collision + w2);
     }
   }
   const long long m0 = d.mv_off[w2];
-  const int M = d.mv_cnt[w2];
-  for (int m = lane; m < M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = d.mv_init[m0 + m];
+  const int M = auv_ld<COH>(d.mv_cnt + w2);
+  for (int m = lane; m < M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = auv_ld4<COH>(d.mv_init + m0 + m);
   if (!d.w_ready) {
     for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
     for (int k = lane; k < d.k_max; k += AUV_WAVE) d.nearby[(size_t)e * d.k_max + k] = 0;
     return;
   }
-  for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.w_lidar[(size_t)w2 * S + i];
+  for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = auv_ld<COH>(d.w_lidar + (size_t)w2 * S + i);
   for (int i = lane; i < 6 + S; i += AUV_WAVE) {
-    const double v = d.w_obs64[(size_t)w2 * (6 + S) + i];
+    const double v = auv_ld<COH>(d.w_obs64 + (size_t)w2 * (6 + S) + i);
     d.obs64[(size_t)e * (6 + S) + i] = v;
     if (obs_out && i < DL) obs_out[(size_t)e * D + i] = (float)v;
   }
-  if (lane < 8) d.info64[8 * (size_t)e + lane] = d.w_info[8 * (size_t)w2 + lane];
-  else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = d.w_nav[8 * (size_t)w2 + lane - 8];
+  if (lane < 8) d.info64[8 * (size_t)e + lane] = auv_ld<COH>(d.w_info + 8 * (size_t)w2 + lane);
+  else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = auv_ld<COH>(d.w_nav + 8 * (size_t)w2 + lane - 8);
   for (int k = lane; k < d.k_max; k += AUV_WAVE) {
-    d.nearby[(size_t)e * d.k_max + k] = d.w_nearby[(size_t)w2 * d.k_max + k];
-    d.limits[(size_t)e * d.k_max + k] = d.w_limits[(size_t)w2 * d.k_max + k];
+    d.nearby[(size_t)e * d.k_max + k] = auv_ld<COH>(d.w_nearby + (size_t)w2 * d.k_max + k);
+    d.limits[(size_t)e * d.k_max + k] = auv_ld2i<COH>(d.w_limits + (size_t)w2 * d.k_max + k);
   }
+}
+// the plain form, or the coherent one where a refill pass may be rebuilding slots beside the launch
+__device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int lane, int episodes, float* __restrict__ obs_out) {
+  if (d.fw_state) restore_env<true>(d, e, w2, lane, episodes, obs_out);
+  else restore_env<false>(d, e, w2, lane, episodes, obs_out);
 }
 
 // ---- navigation part (Vessel.navigate + the six navigation observations) ----------------------

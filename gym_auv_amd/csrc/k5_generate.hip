@@ -90,9 +90,11 @@ __device__ __forceinline__ double linspace_at(double a, double b, int n, int k) 
   return k * ((b - a) / (n - 1)) + a;
 }
 
-// out[0] = 0, out[i+1] = out[i] + len(i) for i < n (block-wide; chunked per thread)
+// out[0] = 0, out[i+1] = out[i] + len(i) for i < n (block-wide; chunked per thread).  256 threads: the 256 chunk sums are
+// turned into their exclusive prefixes by ONE wave -- four consecutive sums per lane, a DPP scan over the 64 lane totals --
+// instead of one thread walking all 256 through LDS (25 us of every world's ~265, three times per world).
 template <typename LenFn>
-__device__ void block_cumsum(double* out, int n, LenFn len, double* s_part) {
+__device__ __forceinline__ void block_cumsum(double* out, int n, LenFn len, double* s_part) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int chunk = (n + nt - 1) / nt;
   const int i0 = tid * chunk, i1 = min(n, i0 + chunk);
@@ -100,13 +102,13 @@ __device__ void block_cumsum(double* out, int n, LenFn len, double* s_part) {
   for (int i = i0; i < i1; i++) acc += len(i);
   s_part[tid] = acc;
   __syncthreads();
-  if (tid == 0) {
-    double run = 0.0;
-    for (int t = 0; t < nt; t++) {
-      const double v = s_part[t];
-      s_part[t] = run;
-      run += v;
-    }
+  if (tid < AUV_WAVE) {
+    const double a0 = s_part[4 * tid], a1 = s_part[4 * tid + 1], a2 = s_part[4 * tid + 2], a3 = s_part[4 * tid + 3];
+    const double p0 = a0, p1 = p0 + a1, p2 = p1 + a2, p3 = p2 + a3;
+    const double incl = auv_wave_scan_incl_f64(p3);
+    double excl = __shfl_up(incl, 1, AUV_WAVE);
+    if (tid == 0) excl = 0.0;
+    s_part[4 * tid] = excl, s_part[4 * tid + 1] = excl + p0, s_part[4 * tid + 2] = excl + p1, s_part[4 * tid + 3] = excl + p2;
   }
   __syncthreads();
   double run = s_part[tid];
@@ -118,10 +120,12 @@ __device__ void block_cumsum(double* out, int n, LenFn len, double* s_part) {
   __syncthreads();
 }
 
-// one PCHIP re-parameterisation pass (path.py:24-31): from GEN_NK points (wx, wy) build knots ks
-// (chord arclengths) and coefficient rows coef; optionally resample to (ox, oy)
-__device__ void pchip_pass(const double* wx, const double* wy, double* ks, double* coef, double* dsx, double* dsy,
-                           double* ox, double* oy, double* s_part) {
+// one PCHIP re-parameterisation pass (path.py:24-31): from GEN_NK points (wx, wy) build knots ks (chord arclengths) and
+// coefficient rows coef; optionally resample to (wx, wy) in place.  ks, wx, wy, dsx, dsy live in LDS (the interval search of
+// every evaluation walks the knots: ten dependent reads that were ten trips to L2 while they sat in global scratch -- the
+// 10 000 evaluations of the dense polyline were 3/4 of a world's build time); the coefficient rows stay in global memory.
+__device__ __forceinline__ void pchip_pass(double* wx, double* wy, double* ks, double* coef, double* dsx, double* dsy, const bool resample,
+                                           double* s_part) {
   const int tid = threadIdx.x, nt = blockDim.x;
   block_cumsum(ks, GEN_NK - 1, [&](int i) {
     const double dx = wx[i + 1] - wx[i], dy = wy[i + 1] - wy[i];
@@ -142,11 +146,12 @@ __device__ void pchip_pass(const double* wx, const double* wy, double* ks, doubl
     }
   }
   __syncthreads();
-  if (ox) {
+  if (resample) {
+    // (in place: the evaluation reads knots and coefficient rows only)
     for (int k = tid; k < GEN_NK; k += nt) {
       double xy[2], dxy[2];
       eval_xy(ks, coef, GEN_NK, linspace_at(ks[0], ks[GEN_NK - 1], GEN_NK, k), xy, dxy);
-      ox[k] = xy[0], oy[k] = xy[1];
+      wx[k] = xy[0], wy[k] = xy[1];
     }
     __syncthreads();
   }
@@ -158,19 +163,16 @@ __device__ void pchip_pass(const double* wx, const double* wy, double* ks, doubl
 __global__ void __launch_bounds__(256) k5_generate(GenOut g, const double* __restrict__ draws, int w_first, int n_worlds,
                                                    const int32_t* __restrict__ slots, const int32_t* __restrict__ count_dev) {
   __shared__ double s_part[256];
+  __shared__ double s_ks[GEN_NK], s_wx[GEN_NK], s_wy[GEN_NK], s_dx[GEN_NK], s_dy[GEN_NK];   // 40 KB: knots, points, slopes of the pass in hand
   __shared__ double s_wp[2][8];      // raw waypoints
   __shared__ double s_s1[8], s_d1[2][8], s_c1[2][8][4];
   __shared__ double s_pose[3], s_goal[2], s_L;
   __shared__ int s_n1, s_P;
   const int tid = threadIdx.x, nt = blockDim.x;
   const double PI = AUV_PI;
-  double* scr = g.scratch + (size_t)blockIdx.x * GEN_SCRATCH;
-  double* ksA = scr;                         // [NK]
-  double* cfA = ksA + GEN_NK;                // [NK][8]
-  double* wx = cfA + GEN_NK * 8;             // [NK] each
-  double* wy = wx + GEN_NK;
-  double* dsx = wy + GEN_NK;
-  double* dsy = dsx + GEN_NK;
+  double* cfA = g.scratch + (size_t)blockIdx.x * GEN_SCRATCH;   // [NK][8] coefficient rows of the second pass
+  double* const wx = s_wx;
+  double* const wy = s_wy;
   const int K = g.n_moving + g.n_static;
   if (count_dev) n_worlds = *count_dev;
   for (int wi = blockIdx.x; wi < n_worlds; wi += gridDim.x) {
@@ -219,10 +221,14 @@ __global__ void __launch_bounds__(256) k5_generate(GenOut g, const double* __res
     }
     __syncthreads();
     // ---- passes 2 and 3 (path.py:24-31); the third interpolant is the path ----
-    pchip_pass(wx, wy, ksA, cfA, dsx, dsy, wx, wy, s_part);           // pass 2 (resample in place after the pass)
-    double* ks = g.knot_s + (size_t)w * GEN_NK;
+    pchip_pass(wx, wy, s_ks, cfA, s_dx, s_dy, true, s_part);          // pass 2 (resample in place after the pass)
     double* cf = g.knot_coef + (size_t)w * GEN_NK * 8;
-    pchip_pass(wx, wy, ks, cf, dsx, dsy, nullptr, nullptr, s_part);   // pass 3 -> bank
+    pchip_pass(wx, wy, s_ks, cf, s_dx, s_dy, false, s_part);          // pass 3 -> bank (coefficient rows) ...
+    {
+      double* ks_bank = g.knot_s + (size_t)w * GEN_NK;                // ... and its knots; every evaluation below walks the LDS copy
+      for (int i = tid; i < GEN_NK; i += nt) ks_bank[i] = s_ks[i];
+    }
+    const double* const ks = s_ks;
     if (tid == 0) {
       const double L = ks[GEN_NK - 1];
       int P = (int)(10.0 * L);
@@ -445,15 +451,22 @@ __global__ void k_fw_bind(FwBatch b, int32_t* __restrict__ queue, unsigned int* 
   *shadow_fresh_count = 0;
 }
 
-// regenerated slots of the environments [e0, e0 + ne) become READY: enqueued on THEIR stream once the host has seen the refill
-// pass complete (so every launch behind this one started after the slots' tables and reset rows were complete)
-__global__ void k_fw_publish(FwList l, int e0, int ne, int n_envs, int32_t* __restrict__ state, int32_t* __restrict__ serial) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= l.count) return;
-  const int s = l.slot[i], e = s % n_envs;
-  if (e < e0 || e >= e0 + ne) return;
-  serial[s] = l.serial[i];
-  state[s] = AUV_FW_READY;
+// The pass's LAST kernel: the slots it has rebuilt become READY.  Every kernel of the pass before this one has ended (stream
+// order), i.e. the slots' tables and reset rows are complete in memory; the serial and the state go out as agent-scope stores,
+// the state last.  A finish wave that reads READY (agent-scope load) reads the slot's tables with agent-scope loads in the
+// same launch (restore_env<true>) and the plain way, behind a kernel boundary, ever after.
+__global__ void k_fw_ready(FwBatch b, int32_t* __restrict__ state, int32_t* __restrict__ serial, unsigned int* __restrict__ ctl) {
+  const int count = *b.count;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const int s = b.slot[i];
+    __hip_atomic_store(serial + s, b.serial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // (vmcnt(0): the serial is out before the state)
+    __hip_atomic_store(state + s, AUV_FW_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_fetch_add((unsigned long long*)(ctl + 4), (unsigned long long)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // worlds rebuilt so far
+    __hip_atomic_fetch_add((unsigned long long*)(ctl + 6), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                        // passes completed
+  }
 }
 
 }  // namespace
@@ -475,6 +488,6 @@ void auv_launch_fw_bind(const FwBatch& b, int32_t* queue, unsigned int* ctl, int
   hipLaunchKernelGGL(k_fw_bind, dim3(1), dim3(AUV_WAVE), 0, st, b, queue, ctl, q_cap, n_envs, cap, env_next_serial, shadow_world_idx, shadow_fresh_count);
 }
 
-void auv_launch_fw_publish(const FwList& l, int e0, int ne, int n_envs, int32_t* state, int32_t* serial, hipStream_t st) {
-  hipLaunchKernelGGL(k_fw_publish, dim3(1), dim3(AUV_FW_LIST), 0, st, l, e0, ne, n_envs, state, serial);
+void auv_launch_fw_ready(const FwBatch& b, int32_t* state, int32_t* serial, unsigned int* ctl, int cap, hipStream_t st) {
+  hipLaunchKernelGGL(k_fw_ready, dim3((cap + 255) / 256), dim3(256), 0, st, b, state, serial, ctl);
 }

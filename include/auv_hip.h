@@ -412,12 +412,12 @@ int auv_read_bank(auv_handle_t* h, int32_t table, void* dst_dev, size_t bytes, v
  *     depend on timing, on the sub-batch chains, or on how the batch is sharded over GPUs (env_index_base = the shard's first
  *     GLOBAL environment index);
  *   - an environment whose episode ends (auto-reset, or auv_reset after it has stepped) moves to its next slot and queues the one
- *     it leaves; a refill pass on a low-priority side stream, enqueued by the step calls themselves every `period` calls and
- *     never waited for, rebuilds exactly the queued slots (up to `batch_cap` per pass): tables (k5_generate) and reset rows (the
- *     step's own kernels on batch_cap shadow environments nobody steps).  Once the host has SEEN a pass complete (an event
- *     query at a later step call), a one-block publish kernel on the stream of each chain that owns a regenerated slot makes
- *     it bindable: every launch that can bind the slot started after its tables were complete -- no fence in the step path.
- *     Running environments are never touched.
+ *     it leaves; a refill pass -- ONE graph launch on a side stream, enqueued by the step calls themselves every `period` calls,
+ *     paced in GPU time behind the first chain's stream and never waited for -- rebuilds exactly the queued slots (up to
+ *     `batch_cap` per pass): tables (k5_generate), reset rows (the step's own kernels on batch_cap shadow environments nobody
+ *     steps), and its last kernel makes them bindable.  No host round trip: the host may be thousands of launches ahead.
+ *     A finish wave that binds a slot reads its tables with agent-scope loads in that launch (the pass may have completed
+ *     while the launch was running); every later launch starts behind a kernel boundary.  Running environments are never touched.
  *   - should an episode end before its environment's next slot is ready (the pass fell behind an episode of a few steps) the
  *     environment starts over in the world it has just finished, and the event is COUNTED (auv_fresh_worlds_stats [2]); size
  *     `depth` / `period` / `batch_cap` so that the count stays 0 (bench.py --fresh-worlds reports it).
@@ -428,13 +428,22 @@ int auv_read_bank(auv_handle_t* h, int32_t table, void* dst_dev, size_t bytes, v
  *                             launches) tick by themselves; a caller that drives slices one by one (auv_step_slice) calls this
  *                             with the chains' slices and streams.  flush != 0: synchronises those streams, then runs passes
  *                             until the queue is empty and everything is published (tests; a deterministic hand-over point).
- *   auv_fresh_worlds_stats    out8: [0] mode on, [1] worlds regenerated and published, [2] episodes that re-used their world
- *                             (see above), [3] slots queued now, [4] passes issued, [5] passes published, [6] depth, [7] batch_cap.
+ *   auv_fresh_worlds_stats    out8: [0] mode on, [1] worlds rebuilt, [2] episodes that re-used their world (see above), [3] slots
+ *                             queued now, [4] passes enqueued, [5] passes completed, [6] depth, [7] batch_cap.  One small D2H copy.
  *   auv_fresh_worlds_draws    the draws row of (environment, serial) for n_rows pairs (HOST arrays of environment indices
- *                             relative to this handle) -> dst_dev [n_rows][n_draws]: what the host mirror rebuilds a world from. */
+ *                             relative to this handle) -> dst_dev [n_rows][n_draws]: what the host mirror rebuilds a world from.
+ * (The pass's stream is a plain stream: creating one with a non-default priority halves the throughput of four sub-batch chains
+ * on this stack even while it idles -- tools/side_stream_ab.sh.)                                                       */
 int auv_fresh_worlds_create(auv_handle_t* h, int32_t depth, int32_t n_moving, int32_t n_static, uint64_t seed, int64_t env_index_base,
                             int32_t batch_cap, int32_t period, const double* ring_unit, const int32_t* nseg_by_radius, int32_t n_radius);
 int auv_fresh_worlds_refill(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, int32_t flush);
+/* The stream the refill passes run on (default: a plain stream the library creates).  This GPU runs at most FOUR kernels side by
+ * side and HIP multiplexes streams onto four hardware queues (FIFO each): a pass on a stream that shares a queue with a chain
+ * stalls that chain for the pass's duration, and beside four busy chains a pass takes a slot from one of them whatever its
+ * queue (tools/side_queue_probe.py: 153 -> 70 / 95 M env-steps/s).  So: three chains plus a pass stream chosen to run side by
+ * side with all three (auv_streams_overlap) -- what BatchedAuvEnv.set_sub_batches does in this mode.  The stream stays the
+ * caller's; it must outlive the mode.                                                                              */
+int auv_fresh_worlds_set_stream(auv_handle_t* h, void* stream);
 int auv_fresh_worlds_stats(auv_handle_t* h, int64_t* out8);
 int auv_fresh_worlds_draws(auv_handle_t* h, const int32_t* envs_host, const int32_t* serials_host, int32_t n_rows, double* dst_dev,
                            void* stream);

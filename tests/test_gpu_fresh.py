@@ -199,7 +199,8 @@ def test_fresh_mode_is_bitwise_a_bank_that_never_repeats(mode):
 
 
 def test_chains_and_shards_meet_the_same_worlds():
-    """Four open-loop sub-batch chains with refill passes every 2 calls == ONE chain, bit for bit, after 150 steps with ~6
+    """Three open-loop sub-batch chains (the fourth of the GPU's four concurrent kernels is the refill pass's) with passes
+    every 2 calls == ONE chain, bit for bit, after 150 steps with ~6
     turn-overs per environment (all 512 at once: every episode hits the time limit together -- one pass takes them all); and a handle over the second half of the batch (env_index_base = n / 2) == those environments
     of the whole batch: the world of an episode is a function of (seed, global environment index, serial)."""
     n, steps, T = 512, 150, 23
@@ -207,7 +208,7 @@ def test_chains_and_shards_meet_the_same_worlds():
     one = _env(cfg, FreshWorlds(depth=2, seed=9, period=2, batch_cap=512), n)
     four = _env(cfg, FreshWorlds(depth=2, seed=9, period=2, batch_cap=512), n)
     half = _env(cfg, FreshWorlds(depth=2, seed=9, period=2, batch_cap=512, env_index_base=n // 2), n // 2)
-    four.set_sub_batches(4, strict=True)
+    four.set_sub_batches(3, strict=True)
     for e in (one, four, half):
         e.reset()
     g = torch.Generator(device="cuda:0")
