@@ -577,6 +577,32 @@ def main():
                 for i in range(n):
                     env.step_pipelined(pool[i % n_pool])
             comparison["pipelined_sub%d" % sub] = rate(loop_pipe)
+        # the closed loop a PPO run lives in (scripts/run.py:332-357: MlpPolicy [256, 128, 64] for policy and value): the fused
+        # policy launch (csrc/k6_policy.hip, exact f32 on the matrix cores, random-init weights) and the environment's step of
+        # every chain back to back, T transitions stored per environment, one C call (auv_policy_rollout) -- so that a
+        # driver-run record carries the figure a learner sees
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "examples"))
+            import ppo as ppo_example
+            from gym_auv_amd.policy import FusedActorCritic
+            if env._slices is None:
+                env.set_sub_batches(1)
+            torch.manual_seed(0)
+            net = ppo_example.ActorCritic(env.obs_dim).to(dev)
+            T_roll = 128
+            fused = FusedActorCritic(net, env, rollout=T_roll, reward_scale=0.01)
+            fused.begin_rollout()
+            fused.rollout(16, flush=False)
+            torch.cuda.synchronize(dev)
+            fused.begin_rollout()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            fused.rollout(T_roll)
+            torch.cuda.synchronize(dev)
+            comparison["policy_rollout_sub%d" % env.sub_batches] = round(n_local * T_roll / (time.perf_counter() - t1), 1)
+            comparison["policy_rollout_steps"] = T_roll
+        except Exception as exc:                              # (reported, never fatal: the headline does not depend on it)
+            comparison["policy_rollout_error"] = repr(exc)[:200]
 
     fresh_stats = None
     if fresh:

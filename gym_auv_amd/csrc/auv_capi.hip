@@ -134,7 +134,7 @@ struct auv_handle {
 };
 
 // From how many environments per launch on the three-launch shape is used by AUV_STEP_AUTO.  With the four-role step
-// the one launch is ahead at every size measured (one chain, tools/auto_threshold.sh: 139.3 against 129.5 M env-steps/s
+// the one launch is ahead at every size measured (one chain, tools/archive/auto_threshold.sh: 139.3 against 129.5 M env-steps/s
 // at 8192 environments per launch, 149.1 / 141.4 M at 16384, 149.9 / 145.8 M at 32768): the margin halves with every
 // doubling -- many rounds of waves per slot leave little to gain by hiding a launch boundary -- so beyond what was
 // measured the fence-free shape is the default.  (With three roles the crossover was at 16384.)

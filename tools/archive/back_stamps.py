@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic (scratch STAMPS build csrc_stampsb, tools/build_stampsb.sh): where the LiDAR wave's time goes after the pair sweep.
-    AUV_HIP_LIB=gym_auv_amd/csrc_stampsb/libauv_hip.so SUB=4 python tools/back_stamps.py"""
+"""Diagnostic (scratch STAMPS build csrc_stampsb, tools/archive/build_stampsb.sh): where the LiDAR wave's time goes after the pair sweep.
+    AUV_HIP_LIB=gym_auv_amd/csrc_stampsb/libauv_hip.so SUB=4 python tools/archive/back_stamps.py"""
 import os
 import sys
 

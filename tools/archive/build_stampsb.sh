@@ -1,5 +1,5 @@
 #!/bin/bash
-# Scratch diagnostic build for tools/back_stamps.py: a STAMPS copy of csrc/ (gym_auv_amd/csrc_stampsb/, git-ignored) in which five stamp
+# Scratch diagnostic build for tools/archive/back_stamps.py: a STAMPS copy of csrc/ (gym_auv_amd/csrc_stampsb/, git-ignored) in which five stamp
 # slots of the search / finish roles are re-used for stamps INSIDE k2_back (after the compaction, after the wait for the beam weights,
 # after the free rows, before / after the wave sum).  Patches the copies by exact string replacement: it asserts when the source has moved on.
 set -e

@@ -7,7 +7,7 @@ episode log: goal rate, collision rate, what else ends episodes, return, length.
   avoid     the same plus a reactive term: the closeness-weighted bearing of what the forward beams see pushes the rudder
             away from it
 
-    python tools/pilot_eval.py --envs 4096 --steps 12000
+    python tools/archive/pilot_eval.py --envs 4096 --steps 12000
 """
 import argparse
 import json

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 sweep of the ways of driving the batch (open loop, VecEnv rendezvous by each mechanism, captured chains), one
-# JSON line per run into $OUT (default gpurun_out/r04/sweep_api.jsonl).  Usage: tools/r04_sweep.sh [steps] [warmup]
+# JSON line per run into $OUT (default gpurun_out/r04/sweep_api.jsonl).  Usage: tools/archive/r04_sweep.sh [steps] [warmup]
 set -u
 STEPS=${1:-2000}; WARM=${2:-200}
 OUT=${OUT:-gpurun_out/r04/sweep_api.jsonl}

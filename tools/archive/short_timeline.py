@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the driver's short command (--steps 20 --warmup 5): when does step i of chain c complete, relative to
 the start of the timed region?  One event per chain and step, recorded on the chain's stream behind its launch.
-    python tools/short_timeline.py [--steps 20] [--warmup 5] [--sub 4]"""
+    python tools/archive/short_timeline.py [--steps 20] [--warmup 5] [--sub 4]"""
 import argparse
 import os
 import sys

@@ -2,7 +2,7 @@
 """Where do the ~80-200 us go that a 20-step timed region carries beyond 20 x the sustained step time?
 For warm-ups of 5 and 200 steps: host time to enqueue the 20 steps, time until all chains are done seen by polling
 stream.query() from the host, and seen by torch.cuda.synchronize() (the contract's bracket).
-    python tools/short_timing.py [--steps 20]"""
+    python tools/archive/short_timing.py [--steps 20]"""
 import argparse
 import os
 import sys

@@ -3,7 +3,7 @@
 streams (BatchedAuvEnv.set_sub_batches / step_slice), K from the command line; for every K the rate over `--steps`
 steps and whether the final state equals the K = 1 run bit for bit (same actions, same start).
 
-    python tools/subbatch_sweep.py --ks 1,2,3,4,6,8 --steps 2000 [--envs 4096] [--workload polygons50]
+    python tools/archive/subbatch_sweep.py --ks 1,2,3,4,6,8 --steps 2000 [--envs 4096] [--workload polygons50]
 """
 import argparse
 import json

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (STAMPS build, three-launch shape): staging / item-prefix / pair-sweep cycles of every sweep, and what they scale with.
-    AUV_HIP_LIB=gym_auv_amd/csrc_stamps/libauv_hip.so python tools/sweep_substamps.py"""
+    AUV_HIP_LIB=gym_auv_amd/csrc_stamps/libauv_hip.so python tools/archive/sweep_substamps.py"""
 import os
 import sys
 

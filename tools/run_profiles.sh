@@ -45,6 +45,14 @@ run bench_polygons50_graph16_one_graph4 $OUT/bench_polygons50_graph16_one_graph4
 run bench_polygons50_worlds1 $OUT/bench_polygons50_worlds1.json $B --worlds-per-env 1 --cpu-baseline 0
 run bench_circles20 $OUT/bench_circles20.json $B --workload circles20 --cpu-baseline 0
 run bench_moving28 $OUT/bench_moving28.json $B --workload moving28 --cpu-baseline 0
+# a fresh world on every reset (round 5): the generator inside the timed region, the bank-cycling rate of the same loop beside it
+run bench_moving28_fresh_worlds $OUT/bench_moving28_fresh_worlds.json $B --workload moving28 --fresh-worlds 1 --steps 2000 --warmup 3000 --cpu-baseline 0
+run bench_moving28_fresh_worlds_depth2 $OUT/bench_moving28_fresh_worlds_depth2.json $B --workload moving28 --fresh-worlds 1 --worlds-per-env 4 --fresh-period 8 --steps 2000 --warmup 3000 --cpu-baseline 0
+run host_bound_probe $OUT/host_bound_probe.jsonl python tools/host_bound_probe.py
+run side_queue_probe $OUT/side_queue_probe_default.json python tools/side_queue_probe.py
+run side_queue_probe2 $OUT/side_queue_probe2.json python tools/side_queue_probe2.py
+run fma_issue_all_cus $OUT/fma_issue_all_cus.jsonl ./tools/fma_issue_bench
+run fma_issue_one_cu $OUT/fma_issue_one_cu.jsonl ./tools/fma_issue_bench 1
 run bench_mixed47_8192 $OUT/bench_mixed47_8192.json $B --workload mixed47 --envs 8192 --cpu-baseline 0
 run bench_mixed47_8192_graph16_sub1 $OUT/bench_mixed47_8192_graph16_sub1.json $B --workload mixed47 --envs 8192 --graph 16 --sub-batches 1 --steps 1920 --warmup 192 --cpu-baseline 0
 run bench_mixed47_8192_graph16_chains4 $OUT/bench_mixed47_8192_graph16_chains4.json $B --workload mixed47 --envs 8192 --graph 16 --sub-batches 4 --steps 1920 --warmup 192 --cpu-baseline 0
@@ -54,6 +62,7 @@ run bench_2ranks_rehearsal_1gpu $OUT/bench_2ranks_rehearsal_1gpu.json python ben
 python bench.py --gpus 2 --steps 10 > $OUT/bench_2ranks_refused.out 2>&1; echo "exit code $? (two ranks without --rehearse on a 1-GPU box must be refused)" >> $OUT/bench_2ranks_refused.out
 run policy_bench $OUT/policy_bench.log python tools/policy_bench.py 4096
 run ppo_colav_fused_4096x128 $OUT/ppo_colav_fused_4096x128.log python examples/ppo.py --envs 4096 --updates 6 --rollout 128
+run ppo_colav_fused_4096x128_generated_bank $OUT/ppo_colav_fused_4096x128_generated_bank.log python examples/ppo.py --envs 4096 --updates 6 --rollout 128 --worlds generated
 echo "benches done"
 cd /tmp && export TMPDIR=/tmp
 run bench_under_rocprof $OUT/bench_under_rocprof.json rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --bank-cache /tmp/bank --cpu-baseline 0
