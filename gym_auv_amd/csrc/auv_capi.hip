@@ -9,7 +9,6 @@
 #include <cmath>
 #include <chrono>
 #include <cstring>
-#include <cstdlib>
 #include <vector>
 
 #include "auv_device.h"
@@ -592,8 +591,7 @@ static void fw_pass_kernels(auv_handle* h, hipStream_t st) {
 // that ran at enqueue time would find an empty queue long before the episodes it is meant for have ended.
 static int fw_enqueue_pass(auv_handle* h, hipStream_t behind, bool paced) {
   auv_handle::Fresh& f = h->fw;
-  static const bool no_pace = getenv("AUV_FW_NO_PACE") != nullptr;     // (experiments: tools/side_stream_ab.sh)
-  if (paced && !no_pace) {
+  if (paced) {
     hipEvent_t ev = f.pace[f.issued % auv_handle::Fresh::NEV];
     HIP_TRY(hipEventRecord(ev, behind));
     HIP_TRY(hipStreamWaitEvent(f.side, ev, 0));
@@ -1018,7 +1016,7 @@ int auv_fresh_worlds_create(auv_handle_t* h, int32_t depth, int32_t n_moving, in
     fw_pass_kernels(h, f.side);
     hipGraph_t g = nullptr;
     hipError_t ce = hipStreamEndCapture(f.side, &g);
-    if (ce == hipSuccess && getenv("AUV_FW_NO_GRAPH") == nullptr) {
+    if (ce == hipSuccess) {
       f.pass_graph = g;
       HIP_TRY(hipGraphInstantiate(&f.pass_exec, g, nullptr, nullptr, 0));
     } else {

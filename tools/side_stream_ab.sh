@@ -1,4 +1,6 @@
-# A/B of the fresh-world refill pass (round 5): chains, period, batch, depth -- moving28, 4096 envs
+# A/B of the fresh-world refill pass (round 5): chains, period, batch, depth -- moving28, 4096 envs.
+# (The *_nopace / *_nograph rows under profiles/r05 came from a diagnostic build that read AUV_FW_NO_PACE / AUV_FW_NO_GRAPH; the
+# shipped library reads no environment variable.  Neither made a difference: 122-125 M env-steps/s in all four combinations.)
 mkdir -p gpurun_out/r05
 run() {  # run <tag> <env assignments...> -- <bench flags...>
   tag=$1; shift
@@ -11,7 +13,7 @@ fw=d["config"].get("fresh_worlds", {})
 print("%-28s %6.1f M  sub %d slices %s  cycling %s  fresh %s gen %.2fs" % ("$tag", d["value"]/1e6, d["config"]["sub_batches"], d["roofline"]["kernels"]["k_step_roles"].get("per_slice_ms"), d.get("comparison", {}).get("bank_cycling_same_loop"), {k: fw.get(k) for k in ("regenerated","reused","queued","passes_issued","passes_published")}, d["config"]["world_gen_s"]))
 PY
 }
-run sub3_p8_nopace AUV_FW_NO_PACE=1 -- --fresh-worlds 1 --steps 2000 --warmup 3000
-run sub3_p8_nograph AUV_FW_NO_GRAPH=1 -- --fresh-worlds 1 --steps 2000 --warmup 3000
-run sub3_p8_nopace_nograph AUV_FW_NO_PACE=1 AUV_FW_NO_GRAPH=1 -- --fresh-worlds 1 --steps 2000 --warmup 3000
-run sub3_p8 X=1 -- --fresh-worlds 1 --steps 2000 --warmup 3000
+run sub3_p8 X=1 -- --fresh-worlds 1 --steps 2000 --warmup 3000 --fresh-period 8
+run sub3_p16 X=1 -- --fresh-worlds 1 --steps 2000 --warmup 3000
+run sub3_p16_d2 X=1 -- --fresh-worlds 1 --steps 2000 --warmup 3000 --worlds-per-env 4
+run nofresh_sub3 X=1 -- --steps 2000 --warmup 3000 --sub-batches 3
