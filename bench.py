@@ -70,6 +70,14 @@ def parse():
                          "carries the rate of the same loop over a bank that just cycles")
     ap.add_argument("--fresh-period", type=int, default=16, help="--fresh-worlds: a refill pass every this many step calls")
     ap.add_argument("--fresh-batch", type=int, default=64, help="--fresh-worlds: worlds per refill pass at most")
+    ap.add_argument("--multi", type=int, default=-1,
+                    help="T: the open-loop loop enqueues T consecutive steps of every chain as ONE launch per chain (auv_step_multi: an "
+                         "environment's step t + 1 starts when ITS step t is through, no barrier over the slice, no launch turn-around; "
+                         "bit-identical to T single-step launches).  1: one launch per step and chain.  -1 (default): 64 on ONE chain where the "
+                         "loop is open (api pipelined, resident actions, no fresh worlds, no graph) and --steps >= 256, else 1")
+    ap.add_argument("--multi-order", default="cohorts", choices=["cohorts", "steps"], help="--multi: workgroup order of a launch (include/auv_hip.h, auv_set_multi_order)")
+    ap.add_argument("--multi-lead", type=int, default=12)
+    ap.add_argument("--multi-lag", type=int, default=30)
     ap.add_argument("--graph", type=int, default=0,
                     help="0 (default): eager launches; K > 0: K consecutive steps captured in ONE hipGraph over the action "
                          "ring, one replay per K steps (steps not a multiple of K are finished eagerly)")
@@ -364,11 +372,46 @@ def main():
     api = args.api
     if api == "auto":
         api = "step" if (args.actions == "pilot" and sub <= 1) else "pipelined"
+    # several steps per launch (auv_step_multi) where the loop is open and long enough to fill the pipeline of a launch: ONE chain of
+    # 64-step launches (measured, tools/multi_sweep.sh: 170 M env-steps/s against 153 M for four chains of one-step launches over
+    # 2000 steps; over the driver's 20-step window the launch's ramp and drain eat the gain: 124-141 M against 138 M)
+    open_loop = api == "pipelined" and args.actions == "uniform" and not fresh and not K
+    multi_T = args.multi
+    calibration = None
+    if multi_T < 0:
+        multi_T = 1
+        if open_loop and args.steps >= 256 and n_local % 64 == 0 and env.effective_step_mode(n_local) == "one_launch" and args.sub_batches == 0:
+            # which open-loop shape is faster for THIS workload?  192 steps of each before anything is timed: one chain of 64-step
+            # launches (170 against 153 M env-steps/s at 4096 x 180) or four chains of one-step launches (141 against 125 M at
+            # 8192 x 256: its sweeps' larger LDS slices leave a launch of several steps too few wave slots to pipeline in)
+            def trial(k, T):
+                env.set_sub_batches(k, probe_streams=bool(args.probe_streams))
+                env.set_multi_order(args.multi_order, args.multi_lead, args.multi_lag)
+                for rep in range(2):
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    for i in range(0, 192, T):
+                        if T > 1:
+                            env.step_multi(pool, i % n_pool, T)
+                        else:
+                            env.step_pipelined(pool[i % n_pool])
+                    torch.cuda.synchronize(dev)
+                    dt = time.perf_counter() - t1
+                return n_local * 192 / dt
+            want4 = n_local >= 2048 and env.effective_step_mode(n_local // 4) == "one_launch"
+            r_multi, r_chains = trial(1, 64), trial(4 if want4 else 1, 1)
+            multi_T = 64 if r_multi > r_chains else 1
+            calibration = dict(one_chain_64_steps_per_launch=round(r_multi, 1), chains_one_step_per_launch=round(r_chains, 1), steps_each=192)
+            env.reset()
+    if multi_T > 1 and not open_loop:
+        raise SystemExit("--multi T: open-loop stretches only (api pipelined, resident actions, no --fresh-worlds, no --graph)")
     if sub <= 0:
         want4 = n_local >= 2048 and env.effective_step_mode(n_local // 4) == "one_launch"
         sub = 4 if (want4 and api in ("pipelined", "async") and args.actions == "uniform") else 1
         if sub == 4 and fresh:
             sub = 3      # (at most four kernels run side by side on this GPU: three chains and the refill passes' stream)
+        if multi_T > 1:
+            sub = 1      # (a launch of several steps pipelines the whole batch by itself)
     if api == "step":
         sub = 1
     t_probe = 0.0
@@ -450,6 +493,20 @@ def main():
             for _ in range(n):
                 pilot_all()
                 env.step(act)
+    elif multi_T > 1:
+        # several steps per launch and chain: the action pool is the ring, step i reads slot i % n_pool
+        if env._slices is None or env.sub_batches != sub:
+            env.set_sub_batches(sub, probe_streams=bool(args.probe_streams))
+        env.set_multi_order(args.multi_order, args.multi_lead, args.multi_lag)
+        api = "multi"
+
+        def run(i0, n):
+            i = 0
+            while n - i >= multi_T:
+                env.step_multi(pool, (i0 + i) % n_pool, multi_T)
+                i += multi_T
+            for j in range(i, n):                                  # (a remainder shorter than T: single-step launches)
+                env.step_pipelined(pool[(i0 + j) % n_pool])
     elif sub > 1:
         def run(i0, n):
             # K independent launch chains: sub-batch s of step i goes to stream s; nothing orders the chains against
@@ -503,7 +560,29 @@ def main():
     alg = algorithmic_bytes(bank, S, world_of_env, nearby)
     step_bytes = sum(alg[ph] for ph in ("k1", "lidar", "nav", "reward"))
     pipelined = sub > 1 and env.effective_step_mode(max(1, n_local // sub)) == "one_launch"
-    if pipelined:
+    if api == "multi":
+        # every chain's launch of multi_T steps bracketed by HIP events on ITS stream (the stream is in order: the pair encloses
+        # exactly that launch) while the other chains' launches run beside it
+        n_launch = max(4, min(n_prof // multi_T, 24))
+        evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in env._sub_streams] for _ in range(n_launch)]
+        for j in range(n_launch):
+            for (a, _), stq in zip(evs[j], env._sub_streams):
+                a.record(stq)
+            env.step_multi(pool, (j * multi_T) % n_pool, multi_T)
+            for (_, b), stq in zip(evs[j], env._sub_streams):
+                b.record(stq)
+        torch.cuda.synchronize(dev)
+        lms = np.array([[a.elapsed_time(b) for a, b in row] for row in evs]).mean(axis=0)      # ms per launch, per chain
+        names = ["k_step_multi"]
+        kms = np.array([lms.mean(), 0.0, 0.0, lms.max()])
+        launch_bytes = step_bytes / env.sub_batches * multi_T
+        per_kernel = {"k_step_multi": dict(avg_ms=round(float(lms.mean()), 5), steps_per_launch=multi_T, launches_per_step=round(env.sub_batches / multi_T, 4),
+                                           algorithmic_bytes=int(launch_bytes),
+                                           achieved_GBs=round(launch_bytes / (lms.mean() * 1e-3) / 1e9, 1),
+                                           frac=round(launch_bytes / (lms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           per_slice_ms=[round(float(x), 5) for x in lms],
+                                           avg_ms_per_step=round(float(lms.mean()) / multi_T, 5))}
+    elif pipelined:
         # every sub-batch launch stamped on its own stream while the other chains run beside it
         lms = np.zeros(env.sub_batches)
         for i in range(n_prof):
@@ -568,15 +647,37 @@ def main():
                 env.step_async(pool[i % n_pool])
                 env.step_wait()
 
-        comparison = dict(steps=n_cmp, one_chain_step=rate(loop_step))
-        if env._slices is None:
-            env.set_sub_batches(1, inline_first=True)
-        comparison["step_async_wait_%s_sub%d" % (env.rendezvous, env.sub_batches)] = rate(loop_async)
+        comparison = dict(steps=n_cmp)
+        if not fresh:
+            # (with a fresh world per reset the refill passes' stream was chosen to share no hardware queue with the CHAINS' streams;
+            # the caller's own stream, which these two loops run on, may well share one with it: not a figure of that mode)
+            comparison["one_chain_step"] = rate(loop_step)
+            if env._slices is None:
+                env.set_sub_batches(1, inline_first=True)
+            comparison["step_async_wait_%s_sub%d" % (env.rendezvous, env.sub_batches)] = rate(loop_async)
         if sub > 1:
             def loop_pipe(n):
                 for i in range(n):
                     env.step_pipelined(pool[i % n_pool])
             comparison["pipelined_sub%d" % sub] = rate(loop_pipe)
+        if not fresh and n_local % 64 == 0 and env.effective_step_mode(n_local) == "one_launch":
+            # the sustained open-loop rate with 64 steps per launch on one chain, whatever the timed loop above was (the driver's
+            # 20-step window cannot show it): 640 steps after 128 of warm-up, outside the timed region
+            try:
+                env.set_sub_batches(1)
+                env.set_multi_order(args.multi_order, args.multi_lead, args.multi_lag)
+                for j in range(2):
+                    env.step_multi(pool, (64 * j) % n_pool, 64)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for j in range(10):
+                    env.step_multi(pool, (64 * j) % n_pool, 64)
+                torch.cuda.synchronize(dev)
+                comparison["open_loop_multi_T64_sub1"] = round(n_local * 640 / (time.perf_counter() - t1), 1)
+                if sub > 1:
+                    env.set_sub_batches(sub, probe_streams=True)
+            except Exception as exc:
+                comparison["open_loop_multi_error"] = repr(exc)[:200]
         # the closed loop a PPO run lives in (scripts/run.py:332-357: MlpPolicy [256, 128, 64] for policy and value): the fused
         # policy launch (csrc/k6_policy.hip, exact f32 on the matrix cores, random-init weights) and the environment's step of
         # every chain back to back, T transitions stored per environment, one C call (auv_policy_rollout) -- so that a
@@ -636,7 +737,8 @@ def main():
             cyc.close()
 
     lib_sha = library_sha256()
-    cfg_key = "%s/sub%d" % (args.workload, sub)
+    cfg_key = "%s/sub%d" % (args.workload, sub)     # (the committed counter passes step ONE step per launch -- k_step_roles, the very
+                                                     # device functions k_step_multi runs: tools/pmc_workload.sh passes --multi 1)
 
     def committed(name):
         """per-STEP counters of the step's launches from the committed rocprofv3 passes (4096 envs per GPU, this
@@ -675,10 +777,11 @@ def main():
         bound = "latency"      # neither leg saturated: the step is bound by dependent chains / occupancy, not by a pipe
     roofline = dict(bound=bound, kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac,
                     traffic=traffic, valu=valu, wait_frac=valu["wait_frac"] if valu else None, legs=legs,
-                    step_bytes=int(step_bytes), concurrent_launches=sub if pipelined else 1, kernels=per_kernel,
+                    step_bytes=int(step_bytes), concurrent_launches=sub if (pipelined or api == "multi") else 1, kernels=per_kernel,
                     lib_sha256=lib_sha)
 
     loops = {"pipelined": "open loop: %d chains, no ordering between them or with a consumer (auv_step_pipelined)" % sub,
+             "multi": "open loop: %d chains, %d consecutive steps per launch and chain (auv_step_multi; bit-identical to single-step launches)" % (sub, multi_T),
              "step": "env.step() on the caller's stream, one launch per step",
              "async": "VecEnv step_async + step_wait every step: a full rendezvous of %d chain(s) with the caller's stream (%s%s)"
                       % (sub, args.rendezvous, ", first chain on the caller's stream" if args.inline_first else ""),
@@ -691,7 +794,7 @@ def main():
         shape = "side_by_side+k31 (captured, %d steps per graph)" % K
     cfg_out = dict(workload=desc, envs_per_gpu=n_local, n_sensors=S, total_envs=total_envs,
                    parallelism="env-shard x%d (no step-path collective)" % world, ranks=world,
-                   hipgraph_steps=K, sub_batches=sub, api=api, loop=loops[api],
+                   hipgraph_steps=K, steps_per_launch=multi_T, shape_calibration=calibration, sub_batches=sub, api=api, loop=loops[api],
                    step_mode=shape, roofline_step_mode=env.effective_step_mode(max(1, n_local // sub)), actions=args.actions,
                    worlds_per_env=wpe, world_gen_s=round(t_gen, 1),
                    # first contact with an 8-GPU node: what every rank spent before the timed region, and on what

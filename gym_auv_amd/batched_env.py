@@ -288,6 +288,24 @@ class BatchedAuvEnv:
                                        C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.reward.data_ptr()),
                                        C.c_void_p(self.done.data_ptr())), "auv_step_pipelined")
 
+    def step_multi(self, ring: torch.Tensor, first_slot: int, n_steps: int):
+        """`n_steps` consecutive steps of every sub-batch in ONE launch per sub-batch (auv_step_multi): step k reads the actions
+        of ring slot (first_slot + k) % slots.  `ring`: [slots, N, 2] float32 / float64, resident on the device.  Open loop, like
+        step_pipelined (nothing orders the chains against the caller's stream); bit-identical to n_steps step_pipelined calls."""
+        if self._slices is None:
+            self.set_sub_batches(1)
+        if ring.dim() != 3 or tuple(ring.shape[1:]) != (self.n_envs, 2) or ring.device != self.device or not ring.is_contiguous() \
+                or ring.dtype not in (torch.float32, torch.float64):
+            raise ValueError("ring must be a contiguous [slots, %d, 2] float32 / float64 tensor on %s" % (self.n_envs, self.device))
+        dt = _capi.AUV_F64 if ring.dtype == torch.float64 else _capi.AUV_F32
+        _check(_LIB.auv_step_multi(self._h, self.sub_batches, self._bounds_c, self._streams_c, C.c_void_p(ring.data_ptr()), dt,
+                                   int(ring.shape[0]), int(first_slot), int(n_steps), C.c_void_p(self.obs.data_ptr()),
+                                   C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr())), "auv_step_multi")
+
+    def set_multi_order(self, order: str = "cohorts", lead: int = 12, lag: int = 30):
+        """Workgroup order of step_multi's launches: "cohorts" (default: cohort-pipelined, see include/auv_hip.h) or "steps"."""
+        _check(_LIB.auv_set_multi_order(self._h, {"steps": 0, "cohorts": 1}[order], int(lead), int(lag)), "auv_set_multi_order")
+
     def step_pipelined_timed(self, actions: torch.Tensor):
         """step_pipelined with every sub-batch's launch stamped by its own HIP events: ms per sub-batch launch
         (its own duration while the other chains run beside it)."""

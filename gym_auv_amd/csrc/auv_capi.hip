@@ -38,6 +38,8 @@ bool auv_roles_ok(const AuvDev& d);
 void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void auv_launch_k31(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, hipStream_t st);
+void auv_launch_step_multi(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, int n_steps, int first_slot,
+                           int n_slots, unsigned long long seq0, int order, int lead, int lag, hipStream_t st);
 void auv_launch_spin(unsigned long long ticks, hipStream_t st);
 void auv_launch_rdv_publish(unsigned long long* word, unsigned long long seq, hipStream_t st);
 void auv_launch_rdv_arrive(unsigned long long* word, hipStream_t st);
@@ -107,6 +109,8 @@ struct auv_handle {
   std::vector<hipStream_t> fork_streams;   // side streams of the one-graph (fork / join) form
   std::vector<int32_t> chain_bounds;       // the slices of the captured chains
   int chain_steps = 1, graph_steps = 1;    // steps per replay of the captured chains / of the one graph
+  unsigned long long multi_seq = 0;        // auv_step_multi: step numbers handed out so far (every mark of a step carries its number)
+  int multi_order = 1, multi_lead = 12, multi_lag = 30;   // auv_set_multi_order: workgroup order of a launch of several steps
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
   GenOut gen;
@@ -289,6 +293,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.broken, n);
   rc |= dev_alloc(ep, &d.k1_pkt, 8 * n);
   rc |= dev_alloc(ep, &d.nav_hand, 8 * n);
+  rc |= dev_alloc(ep, &d.carry, 24 * n);
   rc |= dev_alloc(ep, &d.k1_done, AUV_MAX_CHAINS);      // (one per captured chain)
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
@@ -335,6 +340,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
     HIP_TRY(hipMemset(d.broken, 0, n));
     HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d.carry, 0, 24 * n * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
     if (((uintptr_t)d.k1_pkt & 63) != 0 || ((uintptr_t)d.nav_hand & 63) != 0) return fail(AUV_EHIP, "hand-over records are not 64-byte aligned");
   }
@@ -470,6 +476,7 @@ static int recover_from_timeout(auv_handle* h, float* obs_now) {
   HIP_TRY(hipMemcpy(d.pair_word, empty.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(d.k1_pkt, 0, 8 * n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.nav_hand, 0, 8 * n * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d.carry, 0, 24 * n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d.k1_done, 0, AUV_MAX_CHAINS * sizeof(int32_t)));
   if (n_broken) auv_launch_reset(d, d.broken, nullptr, obs_now, nullptr);
   HIP_TRY(hipGetLastError());
@@ -492,6 +499,7 @@ static int recover_from_timeout(auv_handle* h, float* obs_now) {
                           "others keep their state, but steps enqueued behind the time-out were not executed.  The handle steps in "
                           "the three-launch shape from now on (no in-launch hand-over); this error is reported once",
               code == 2 ? "a sweep or search wave waited in vain for the dynamics role's state"
+                        : code == 6 ? "a wave of a launch of several steps waited in vain for the previous step's finish wave"
                         : (code == 3 ? "a finish wave waited in vain for a state packet or a search record" : "a finish wave waited in vain for a sweep's word"),
               fe0, fe0 + fne, n_broken, obs_now ? " and in this call's observation buffer" : "");
 }
@@ -1243,6 +1251,42 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
                       obs_dev, reward_dev, done_dev, (hipStream_t)streams[i], false);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_step_multi(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, const void* actions_dev, int32_t action_dtype,
+                   int32_t n_slots, int32_t first_slot, int32_t n_steps, float* obs_dev, float* reward_dev, uint8_t* done_dev) {
+  REQUIRE_READY(h);
+  int rc = check_actions(actions_dev, action_dtype, "auv_step_multi");
+  if (rc) return rc;
+  rc = check_slices(h, n_slices, bounds, streams, "auv_step_multi");
+  if (rc) return rc;
+  if (n_slots < 1 || first_slot < 0 || first_slot >= n_slots || n_steps < 1 || n_steps > 1024)
+    return fail(AUV_EINVAL, "auv_step_multi: n_slots >= 1, 0 <= first_slot < n_slots, 1 <= n_steps <= 1024");
+  if (h->fw.on) return fail(AUV_ESTATE, "auv_step_multi: not with a fresh world per reset (a slot's tables may be rebuilt beside the launch)");
+  if (h->d.k_max > AUV_WAVE) return fail(AUV_ESTATE, "auv_step_multi: more than 64 obstacles per world");
+  for (int i = 0; i < n_slices; i++) {
+    const int ne = bounds[i + 1] - bounds[i];
+    if (effective_mode(h, ne) != AUV_STEP_ONE_LAUNCH) return fail(AUV_ESTATE, "auv_step_multi: needs the one-launch shape for every slice");
+    const long long wg = (long long)n_steps * (2 * (8 * ((ne + 63) / 64)) + 2 * (8 * ((ne + 7) / 8)));
+    if (wg > 0x7fffffffll) return fail(AUV_EINVAL, "auv_step_multi: %lld workgroups in one launch", wg);
+  }
+  PAIR_CHECK(h, obs_dev);
+  const unsigned long long seq0 = h->multi_seq;
+  h->multi_seq += (unsigned long long)n_steps;
+  for (int i = 0; i < n_slices; i++) {
+    AuvDev d = h->d;
+    d.e0 = bounds[i], d.ne = bounds[i + 1] - bounds[i];
+    auv_launch_step_multi(d, actions_dev, action_dtype, obs_dev, reward_dev, done_dev, n_steps, first_slot, n_slots, seq0, h->multi_order, h->multi_lead,
+                          h->multi_lag, (hipStream_t)streams[i]);
+  }
+  HIP_TRY(hipGetLastError());
+  return AUV_OK;
+}
+
+int auv_set_multi_order(auv_handle_t* h, int32_t order, int32_t lead, int32_t lag) {
+  if (!h || order < 0 || order > 1 || lead < 0 || lag < 0 || lead > 4096 || lag > 4096) return fail(AUV_EINVAL, "auv_set_multi_order: order 0 / 1, lead and lag in [0, 4096]");
+  h->multi_order = order, h->multi_lead = lead, h->multi_lag = lag;
   return AUV_OK;
 }
 

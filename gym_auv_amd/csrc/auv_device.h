@@ -89,6 +89,7 @@ struct AuvDev {
   uint8_t* broken;     // [N] environments whose step a wave that gave up has left unfinished: what the recovery resets
   unsigned long long* k1_pkt;  // [N][8] one-launch step: the state the dynamics role hands to the other two (k_step_roles)
   unsigned long long* nav_hand; // [N][8] one-launch step: the nearest path segment the navigation role's search hands to the finish role
+  unsigned long long* carry;   // [N][24] launches of several steps (k_step_multi): what a step's finish wave hands the next step's roles
   int32_t* k1_done;            // [1] one-launch step in a captured graph: dynamics waves that have read the ring position
   int32_t cut_lidar, cut_nav;  // diagnostic build only (-DAUV_CUTS, tools/valu_budget.py): phases from this number on are skipped
   int32_t pair_skew;   // one-launch step, test-hook build only: idle workgroups between the roles (an environment's waves on different XCDs)

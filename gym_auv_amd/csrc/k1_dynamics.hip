@@ -97,9 +97,11 @@ __device__ __forceinline__ Vec6 state_dot(const Vec6& y, double tau_u, double ta
 
 // The action (thrust, rudder) of environment e: `actions` is [N][2] of float or double (d.act_f64; one kernel serves
 // both -- the branch is uniform over the launch), inside a captured graph the current slot of the action ring.
-__device__ __forceinline__ void k1_action(const AuvDev& d, const void* __restrict__ actions, const int e, double* a0, double* a1) {
+// `slot`: >= 0 names the ring slot (a launch of several steps reads slot (first + t) % slots for its step t)
+__device__ __forceinline__ void k1_action(const AuvDev& d, const void* __restrict__ actions, const int e, double* a0, double* a1, const int slot = -1) {
   size_t i = 2 * (size_t)e;
-  if (d.ring_slots > 1)   // action ring: slot of this step
+  if (slot >= 0) i += (size_t)slot * 2 * (size_t)d.n;
+  else if (d.ring_slots > 1)   // action ring: slot of this step
     i += (size_t)(d.ring_slot_host >= 0 ? d.ring_slot_host : *d.ring_pos) * 2 * (size_t)d.n;
   if (d.act_f64) {
     const double2 a = *(const double2*)((const double*)actions + i);
@@ -186,17 +188,19 @@ template <int K> __device__ __forceinline__ int k1_group_bcast32(const int x) {
 template <int K> __device__ __forceinline__ double k1_group_bcast(const double t) {
   return __hiloint2double(k1_group_bcast32<K>(__double2hiint(t)), k1_group_bcast32<K>(__double2loint(t)));
 }
-__device__ __forceinline__ double k1_group(const AuvDev& d, const void* __restrict__ actions, const int e, const int lane) {
+// `y_in` (nullable): component c of the state to start from, in the lane that owns it (else the STATE rows); `slot`: see k1_action
+__device__ __forceinline__ double k1_group(const AuvDev& d, const void* __restrict__ actions, const int e, const int lane,
+                                           const double* y_in = nullptr, const int slot = -1) {
   const int c = lane % K1_GROUP, gbase = lane - c;
   const size_t n = (size_t)d.n;
   const bool own = c < 6;
   double a0, a1;
-  k1_action(d, actions, e, &a0, &a1);
+  k1_action(d, actions, e, &a0, &a1, slot);
   if (isnan(a0) || isnan(a1)) a0 = a1 = 0.0;
   const double tu = auv_clip(a0, 0.0, 1.0) * d.cfg.thrust_max;
   const double tr = auv_clip(a1, -1.0, 1.0) * d.cfg.moment_max;
   const double h = d.cfg.dt;
-  const double y = d.state[(size_t)(own ? c : 0) * n + e];
+  const double y = y_in ? *y_in : d.state[(size_t)(own ? c : 0) * n + e];
   (void)gbase;
   const Heading0 h0 = heading0(k1_group_bcast<2>(y));
   // _state_dot of the stage vector whose component c this lane holds in `t`; returns component c

@@ -279,13 +279,15 @@ __device__ __forceinline__ void k2_rays(const AuvDev& d, const int lane, const S
 
 // phase A: movers (obstacles.py:195-233) -- kinematics, then pose and cull-circle centre into LDS.  Needs nothing
 // of the vessel: the one-launch step runs it while the dynamics role is still integrating.
-template <bool WT = false>
+// LD: the mover rows are read with agent-scope loads -- inside a launch of several steps (k_step_multi) the wave that wrote them
+// one step earlier ran on another CU, possibly another XCD, and no kernel boundary lies in between
+template <bool WT = false, bool LD = false>
 __device__ __forceinline__ void k2_movers(const AuvDev& d, const int e, const int lane, const Slice& L, const EnvDesc& ed,
                                           const int advance_movers) {
   const long long m0 = ed.m0;
   const int M = ed.M;
   for (int m = lane; m < M; m += AUV_WAVE) {
-    double4 st = d.mover[(size_t)e * d.m_max + m];
+    double4 st = auv_ld4<LD>(&d.mover[(size_t)e * d.m_max + m]);
     const double4 par_m = d.mv_param[m0 + m];
     if (advance_movers) {
       const double dt = d.cfg.dt;
@@ -326,13 +328,14 @@ struct K2Pre {
   double cx, cy, rho;
   uint8_t near;
 };
+template <bool LD = false>
 __device__ __forceinline__ K2Pre k2_prefetch(const AuvDev& d, const int e, const int lane, const EnvDesc& ed) {
   K2Pre p;
   p.meta = make_int4(0, 0, 0, 0), p.cx = p.cy = p.rho = 0.0, p.near = 0;
   if (lane < ed.K) {
     p.meta = d.obs_meta[ed.k0 + lane];
     p.cx = d.obs_cull[3 * (ed.k0 + lane)], p.cy = d.obs_cull[3 * (ed.k0 + lane) + 1], p.rho = d.obs_cull[3 * (ed.k0 + lane) + 2];
-    p.near = d.nearby[(size_t)e * d.k_max + lane];
+    p.near = auv_ld<LD>(&d.nearby[(size_t)e * d.k_max + lane]);
   }
   return p;
 }
@@ -340,7 +343,7 @@ __device__ __forceinline__ K2Pre k2_prefetch(const AuvDev& d, const int e, const
 // phases A, C, B, S for one environment, by one wave
 // movers_done / kp: phase A has been run / the first 64 obstacle records have been fetched by the caller already
 template <bool WT = false>
-__device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
+__device__ __forceinline__ int k2_front(const AuvDev& d, const int e, const int lane, const Slice& L, const int advance_movers,
                         const EnvPre* pre = nullptr, const int movers_done = 0,
                         const K2Pre* kp = nullptr, const bool beams_staged = false, int2* lim_defer = nullptr) {
   const int S = d.cfg.n_sensors;
@@ -623,7 +626,7 @@ __device__ int k2_front(const AuvDev& d, const int e, const int lane, const Slic
 }
 
 // phases S + D for one environment, by one wave, in batches of <= K2_SEG_CAP boundary segments
-__device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int lane, const int n_act,
+__device__ __forceinline__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int lane, const int n_act,
                                    const double psi, unsigned long long* sub = nullptr) {
   const int S = d.cfg.n_sensors;
   const double px = L.hdr->px, py = L.hdr->py;
@@ -878,7 +881,7 @@ __device__ void k2_stage_and_pairs(const AuvDev& d, const Slice& L, const int la
 #define K2_HIT_S 256                   // beams whose (index, weight) list fits the (by now idle) segment stage: 12 B each
 static_assert(K2_HIT_S * 12 <= K2_SEG_CAP * 32, "the returns' list lives in the segment stage");
 template <bool WT = false>
-__device__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, const int n_act,
+__device__ __forceinline__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, const int n_act,
                        float* __restrict__ obs_out = nullptr, double* rew_lidar_out = nullptr, const int2* lim0 = nullptr) {
   const int S = d.cfg.n_sensors;
   const double R = d.cfg.sensor_range, W = d.cfg.vessel_width;

@@ -230,7 +230,9 @@ __global__ void k_derive(AuvDev d) {
 // with a neighbouring slot's small records).  sc1 loads are served coherently across the XCDs; the pass's stores were complete
 // (its kernels had ended) before its last kernel made the slot READY, and READY was read with an agent-scope load too.  The
 // environment's NEXT step is another launch: its waves start behind a kernel boundary and read the tables the plain way.
-template <bool COH>
+// WTM: the mover and nearby rows go out write-through -- inside a launch of several steps (k_step_multi) the environment's sweep
+// wave of the NEXT step, on another CU, reads them with agent-scope loads without a kernel boundary in between
+template <bool COH, bool WTM = false>
 __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int lane, int episodes,
                                             float* __restrict__ obs_out) {
   const int S = d.cfg.n_sensors;
@@ -269,8 +271,8 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
       d.counters[e] = make_int4(0, 0, episodes, 0);
       d.collision[e] = wcol;
     }
-    if (lane < nd.M) d.mover[(size_t)e * d.m_max + lane] = mv0;
-    for (int m = AUV_WAVE + lane; m < nd.M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = auv_ld4<COH>(d.mv_init + nd.m0 + m);
+    if (lane < nd.M) auv_st<WTM>(&d.mover[(size_t)e * d.m_max + lane], mv0);
+    for (int m = AUV_WAVE + lane; m < nd.M; m += AUV_WAVE) auv_st<WTM>(&d.mover[(size_t)e * d.m_max + m], auv_ld4<COH>(d.mv_init + nd.m0 + m));
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int i = q * AUV_WAVE + lane;
@@ -282,7 +284,7 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
     }
     if (lane < 8) d.info64[8 * (size_t)e + lane] = row;
     else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = row;
-    if (lane < d.k_max) d.nearby[(size_t)e * d.k_max + lane] = nb, d.limits[(size_t)e * d.k_max + lane] = lm;
+    if (lane < d.k_max) auv_st<WTM>(&d.nearby[(size_t)e * d.k_max + lane], nb), d.limits[(size_t)e * d.k_max + lane] = lm;
     return;
   }
   if (lane == 0) {
@@ -303,7 +305,7 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
   }
   const long long m0 = d.mv_off[w2];
   const int M = auv_ld<COH>(d.mv_cnt + w2);
-  for (int m = lane; m < M; m += AUV_WAVE) d.mover[(size_t)e * d.m_max + m] = auv_ld4<COH>(d.mv_init + m0 + m);
+  for (int m = lane; m < M; m += AUV_WAVE) auv_st<WTM>(&d.mover[(size_t)e * d.m_max + m], auv_ld4<COH>(d.mv_init + m0 + m));
   if (!d.w_ready) {
     for (int i = lane; i < S; i += AUV_WAVE) d.lidar_d[(size_t)e * S + i] = d.cfg.sensor_range;
     for (int k = lane; k < d.k_max; k += AUV_WAVE) d.nearby[(size_t)e * d.k_max + k] = 0;
@@ -318,7 +320,7 @@ __device__ __forceinline__ void restore_env(const AuvDev& d, int e, int w2, int 
   if (lane < 8) d.info64[8 * (size_t)e + lane] = auv_ld<COH>(d.w_info + 8 * (size_t)w2 + lane);
   else if (lane < 16) d.nav64[8 * (size_t)e + lane - 8] = auv_ld<COH>(d.w_nav + 8 * (size_t)w2 + lane - 8);
   for (int k = lane; k < d.k_max; k += AUV_WAVE) {
-    d.nearby[(size_t)e * d.k_max + k] = auv_ld<COH>(d.w_nearby + (size_t)w2 * d.k_max + k);
+    auv_st<WTM>(&d.nearby[(size_t)e * d.k_max + k], auv_ld<COH>(d.w_nearby + (size_t)w2 * d.k_max + k));
     d.limits[(size_t)e * d.k_max + k] = auv_ld2i<COH>(d.w_limits + (size_t)w2 * d.k_max + k);
   }
 }
@@ -482,6 +484,7 @@ struct NavOut {
   double rew_path, reached, goal, progress;
   double u, v, r;                   // the velocities it was computed with (STATE rows 3..5)
   double cte100;                    // cross-track error / 100 (NAV64 [5])
+  double maxp;                      // INFO64 [5] after this step (the episode's maximum progress so far)
 };
 
 // the nearest segment of the path: its end points and the cumulative arclength at its first vertex (wave-uniform)
@@ -588,7 +591,7 @@ __device__ __forceinline__ NavOut nav_tail(const Desc& d, const int e, const int
   const double2 A = t.nr.A, B = t.nr.B;
   const double cum = t.nr.cum;
   NavOut out;
-  out.rew_path = out.reached = out.goal = out.progress = out.u = out.v = out.r = out.cte100 = 0.0;
+  out.rew_path = out.reached = out.goal = out.progress = out.u = out.v = out.r = out.cte100 = out.maxp = 0.0;
   // cos / sin of the new heading for the reward's cos(heading error) below
   double sin_psi, cos_psi;
   sincos(psi, &sin_psi, &cos_psi);
@@ -646,6 +649,7 @@ __device__ __forceinline__ NavOut nav_tail(const Desc& d, const int e, const int
     const double rew_path = reward_path_term_cos(d, speed_l, cos_he, cte100, progress, maxp);
     d.rew_path[e] = rew_path;
     out.rew_path = rew_path, out.reached = reached, out.goal = goal, out.progress = progress, out.u = u, out.v = v, out.r = r, out.cte100 = cte100;
+    out.maxp = maxp;
     // environment.py:276-280; lane 0 also emits the float32 copies of its own six values.  OBS64 rows
     // start 16-byte aligned when 6 + S is even, float32 rows 8-byte aligned when their stride is even.
     const double c0 = auv_clip(u, -1.0, 1.0), c1 = auv_clip(v, -1.0, 1.0), c2 = auv_clip(r, -1.0, 1.0),
@@ -723,9 +727,10 @@ struct RewardIn {
 
 // `D`: AuvDev or StepTabs (see there)
 template <class D>
+// `carry_out` (nullable): [0] the cumulative reward, [1] the sum of |cross-track error| after this step (k_step_multi)
 __device__ __forceinline__ int reward_apply(const D& d, const int e, const int collision, int4& cnt, const RewardIn in,
                                             float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
-                                            const bool advance_ring) {
+                                            const bool advance_ring, double* carry_out = nullptr) {
   double* inf = d.info64 + 8 * (size_t)e;
   const bool colav = d.cfg.rewarder == AUV_REWARD_COLAV;
   const double lambda = 0.5, eta = 0.0, penalty_yawrate = 10.0, neutral_speed = 0.05, max_speed = 2.0;
@@ -757,6 +762,7 @@ __device__ __forceinline__ int reward_apply(const D& d, const int e, const int c
   // environment.py:345, :460-464 (_save_latest_step): |cross-track error| in metres of every step, for the episode's mean
   const double cte_sum = in.cte_sum + fabs(in.cte100) * 100;
   inf[7] = cte_sum;
+  if (carry_out) carry_out[0] = cum, carry_out[1] = cte_sum;
   const int t_step = cnt.x;
   const int done = collision || (reached_in != 0.0) || (t_step >= d.cfg.max_timesteps - 1 && !d.cfg.test_mode) ||
                    (cum < d.cfg.min_cumulative_reward && !d.cfg.test_mode);

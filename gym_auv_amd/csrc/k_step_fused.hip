@@ -209,7 +209,10 @@ __device__ __forceinline__ unsigned long long roles_lane_word(const unsigned lon
 
 // the state the dynamics role left for environment e in this launch.  0: here it is; 1: gave up polling (reported, the
 // environment marked broken); 2: an ABORT packet -- a launch behind a time-out: the wave ends without touching anything
-__device__ __forceinline__ int roles_wait_state(const AuvDev& d, const int e, const int lane, EnvPre& pre) {
+// `tagmix`: 0 for a launch of one step; a launch of several steps mixes the step's number into every mark (roles_tagmix), so
+// that a wave of step t + 1 that starts early cannot take step t's packet -- still up -- for its own
+__device__ __forceinline__ unsigned long long roles_tagmix(const unsigned long long tag) { return tag * 0xd6e8feb86659fd93ull; }
+__device__ __forceinline__ int roles_wait_state(const AuvDev& d, const int e, const int lane, EnvPre& pre, const unsigned long long tagmix = 0ull) {
   const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
   // (polling harder does not pay: with two requests in flight per wave the packet is noticed sooner, but the
   // traffic of 3500 polling waves slows the dynamics role down by more -- 102.3 M against 104.7 M env-steps/s;
@@ -222,7 +225,7 @@ __device__ __forceinline__ int roles_wait_state(const AuvDev& d, const int e, co
       unsigned long long x = roles_lane_word(v, 0);
 #pragma unroll
       for (int i = 1; i < 7; i++) x ^= roles_lane_word(v, i);
-      if (roles_mark(x) == got) break;                       // mark and payload belong together
+      if (roles_mark(x ^ tagmix) == got) break;              // mark and payload belong together (and to this step)
     }
     if (polls == (AUV_HOOK_FAULT(d) ? (1 << 12) : PAIR_POLL_LIMIT)) {
       if (lane == 0) auv_st<true>(d.broken + e, (uint8_t)1);
@@ -251,7 +254,7 @@ __device__ __forceinline__ int roles_wait_state(const AuvDev& d, const int e, co
 // pointers with vector loads at the point of use: 38 against 31 us per chain step.  With the tail ahead of the second
 // wait and the tables in scalar registers before the waits: 136 M against 130 M env-steps/s with four chains, 107
 // against 100 M with one -- profiles/r03/shapes_sweep_finish_role.log.)
-__device__ __forceinline__ void roles_publish_search(const AuvDev& d, const int e, const int lane, const NavNear& nr) {
+__device__ __forceinline__ void roles_publish_search(const AuvDev& d, const int e, const int lane, const NavNear& nr, const unsigned long long tagmix = 0ull) {
   unsigned long long* h = d.nav_hand + 8 * (size_t)e;
   // (wave-uniform values: lane 0 stores the five words one by one -- picking "this lane's word" would make the compiler
   // build a table in scratch memory; words 5 and 6 of the record stay zero)
@@ -265,7 +268,7 @@ __device__ __forceinline__ void roles_publish_search(const AuvDev& d, const int 
     __hip_atomic_store(h + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(h + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(h + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(h + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(h + 4, w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(h + 7, roles_mark(w0 ^ w1 ^ w2 ^ w3 ^ w4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h + 7, roles_mark(w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ tagmix), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -278,9 +281,9 @@ __device__ __forceinline__ double roles_group_value(const unsigned long long v, 
   return __longlong_as_double((long long)roles_group_word(v, src));
 }
 // lane c of a group holds word c of a checksummed 64-byte record: does it hold together?
-__device__ __forceinline__ bool roles_record_ok(const unsigned long long v, const int c) {
+__device__ __forceinline__ bool roles_record_ok(const unsigned long long v, const int c, const unsigned long long tagmix = 0ull) {
   const unsigned long long x = roles_group_xor(c < 7 ? v : 0ull), mark = roles_group_word(v, 7);
-  return mark != 0ull && roles_mark(x) == mark;
+  return mark != 0ull && roles_mark(x ^ tagmix) == mark;
 }
 
 __device__ __forceinline__ void roles_finish_wave(const AuvDev& dk, const int f, const int lane, float* __restrict__ obs_out,
@@ -593,6 +596,426 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
   }
 }
 
+// ---- SEVERAL steps in ONE launch (auv_step_multi) ---------------------------------------------------------
+// An open-loop stretch knows its actions ahead (a ring of slots), so nothing but the launch boundary makes step t + 1 of an
+// environment wait for the slowest sweep of the whole slice.  k_step_multi is k_step_roles' grid T times over, step-major:
+// workgroup b plays role b % per of step b / per.  Workgroups are still dispatched in index order, so every wave's producers --
+// its own step's lower roles and the previous step's finish wave -- are resident or done when it gets its slot; as step t's
+// waves retire, step t + 1's take their slots, and an environment's next dynamics starts when ITS finish wave is through.
+// What a kernel boundary used to do between two steps is done explicitly:
+//   * the CARRY record (AuvDev::carry, 24 words per environment): what the next step's roles need of this step's outcome --
+//     the state and the counters (dynamics: words 0..7, the very format of the state packet), episode count, cumulative reward,
+//     maximum progress, cross-track sum and the table descriptor (sweep, search, finish).  The finish wave writes it last, by
+//     agent-scope stores, with two checksum marks that carry the step's number; the next step's waves poll for marks that match
+//     THEIR step.  Step 0 of a launch reads the arrays as ever (a kernel boundary lies in front of it), and the last step's finish
+//     wave leaves the arrays as ever for the launch that follows.
+//   * the rows one wave writes and ANOTHER step's wave reads -- mover states, the cached nearby mask -- are stored write-through
+//     (they already were) and, in steps > 0, loaded with agent-scope loads (k2_movers / k2_prefetch <LD>); restore_env stores
+//     them write-through too (<WTM>).  Everything else a step writes is output only (or a hint: the path search's starting
+//     chunk, where a stale value costs nothing but a wider first bound).
+//   * every mark of a step is mixed with the step's number (roles_tagmix), so a packet of step t still up cannot pass for
+//     step t + 1's.
+// Bitwise the same as T launches of k_step_roles (tests/test_gpu_multi.py).  Not with a fresh world per reset: there a slot's
+// tables may be rebuilt beside the launch, and only the binding launch reads them coherently.
+#define CARRY_WORDS 24
+
+__device__ __forceinline__ unsigned long long carry_ed_word(const EnvDesc& ed, const int i) {
+  switch (i) {
+    case 0: return (unsigned long long)ed.k0;
+    case 1: return (unsigned long long)ed.m0;
+    case 2: return (unsigned long long)ed.p0;
+    case 3: return (unsigned long long)ed.c0;
+    case 4: return (unsigned long long)ed.kn0;
+    case 5: return (unsigned long long)(unsigned)ed.K | ((unsigned long long)(unsigned)ed.M << 32);
+    case 6: return (unsigned long long)(unsigned)ed.P | ((unsigned long long)(unsigned)ed.nch << 32);
+    default: return (unsigned long long)(unsigned)ed.nk | ((unsigned long long)(unsigned)ed.w << 32);
+  }
+}
+__device__ __forceinline__ void carry_ed_from(EnvDesc& ed, const unsigned long long w[8]) {
+  ed.k0 = (long long)w[0], ed.m0 = (long long)w[1], ed.p0 = (long long)w[2], ed.c0 = (long long)w[3], ed.kn0 = (long long)w[4];
+  ed.K = (int)(unsigned)w[5], ed.M = (int)(unsigned)(w[5] >> 32), ed.P = (int)(unsigned)w[6], ed.nch = (int)(unsigned)(w[6] >> 32);
+  ed.nk = (int)(unsigned)w[7], ed.w = (int)(unsigned)(w[7] >> 32);
+}
+
+// one wave, one environment (sweep, search): the carry of the previous step.  0: here it is; 1: gave up (reported, environment
+// marked); 2: the abort flag went up meanwhile -- the wave ends without touching anything
+__device__ __forceinline__ int carry_wait_wave(const AuvDev& d, const int e, const int lane, const unsigned long long tagmix, EnvDesc& ed, int4& cnt) {
+  const unsigned long long* cw = d.carry + CARRY_WORDS * (size_t)e;
+  unsigned long long v = 0ull;
+  for (int polls = 0;; polls++) {
+    if (lane < CARRY_WORDS) v = __hip_atomic_load(cw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long ma = roles_lane_word(v, 7), mb = roles_lane_word(v, 20);
+    if (ma != 0ull && mb != 0ull) {
+      unsigned long long xa = roles_lane_word(v, 0), xb = roles_lane_word(v, 8);
+#pragma unroll
+      for (int i = 1; i < 7; i++) xa ^= roles_lane_word(v, i);
+#pragma unroll
+      for (int i = 9; i < 20; i++) xb ^= roles_lane_word(v, i);
+      if (roles_mark(xa ^ tagmix) == ma && roles_mark(xb ^ tagmix) == mb) break;
+    }
+    if ((polls & 31) == 31 && auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return 2;
+    if (polls == (AUV_HOOK_FAULT(d) ? (1 << 12) : PAIR_POLL_LIMIT)) {
+      if (lane == 0) auv_st<true>(d.broken + e, (uint8_t)1);
+      roles_give_up(d, d.e0, d.ne, 6, lane);
+      return 1;
+    }
+    __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
+  }
+  unsigned long long w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = roles_lane_word(v, 12 + i);
+  carry_ed_from(ed, w);
+  const unsigned long long c6 = roles_lane_word(v, 6), c8 = roles_lane_word(v, 8);
+  cnt = make_int4((int)(unsigned)c6, (int)(unsigned)(c6 >> 32), (int)(unsigned)c8, 0);
+  return 0;
+}
+
+template <bool MULTI>
+__device__ __forceinline__ void roles_finish_wave_multi(const AuvDev& dk, const int f, const int lane, float* __restrict__ obs_out,
+                                                        float* __restrict__ reward_out, uint8_t* __restrict__ done_out, const int step,
+                                                        const bool last_step, const unsigned long long tagmix, const unsigned long long tagmix_prev) {
+  // (roles_finish_wave with the previous step's outcome from the carry record instead of the arrays, and its own outcome into
+  // the record at the end; the arithmetic in between is the very same code)
+  const __attribute__((address_space(4))) AuvDev* dc = (const __attribute__((address_space(4))) AuvDev*)dk.self;
+  const AuvDev& d = *(const AuvDev*)dc;
+  StepTabs st;
+  st.cfg.min_cumulative_reward = dc->cfg.min_cumulative_reward, st.cfg.min_goal_distance = dc->cfg.min_goal_distance;
+  st.cfg.min_path_progress = dc->cfg.min_path_progress, st.cfg.look_ahead_distance = dc->cfg.look_ahead_distance;
+  st.cfg.max_timesteps = dc->cfg.max_timesteps, st.cfg.rewarder = dc->cfg.rewarder, st.cfg.test_mode = dc->cfg.test_mode;
+  st.cfg.auto_reset = dc->cfg.auto_reset, st.cfg.n_sensors = dc->cfg.n_sensors, st.cfg.use_lidar = dc->cfg.use_lidar;
+  st.cfg.obs_channels = dc->cfg.obs_channels;
+  st.knot_s = dc->knot_s, st.knot_coef = dc->knot_coef;
+  st.info64 = dc->info64, st.nav64 = dc->nav64, st.obs64 = dc->obs64, st.rew_path = dc->rew_path, st.reward64 = dc->reward64;
+  st.step_info = dc->step_info, st.episode = dc->episode, st.ep_log = dc->ep_log, st.ep_log_count = dc->ep_log_count;
+  st.ep_log_cap = dc->ep_log_cap, st.world_idx = dc->world_idx, st.counters = dc->counters;
+  st.fw_serial = nullptr, st.n = dc->n;
+  st.ring_slots = 1, st.ring_slot_host = 0, st.ring_pos = nullptr;
+  unsigned long long* const pair_word = dc->pair_word;
+  unsigned long long* const k1_pkt = dc->k1_pkt;
+  unsigned long long* const nav_hand = dc->nav_hand;
+  unsigned long long* const carry = dc->carry;
+  const EnvDesc* const env_desc = dc->env_desc;
+  const double* const world_scalar = dc->world_scalar;
+  double* const state = dc->state;
+  uint8_t* const broken = dc->broken;
+  const int n_envs = dc->n;
+  const int ne = dk.ne, e0 = dk.e0;
+  const int g = lane / K1_GROUP, c = lane % K1_GROUP;
+  const int er = 8 * (8 * (f / 8) + g) + (f % 8);
+  const bool live = er < ne;
+  const int e = e0 + (live ? er : ne - 1);
+  const int limit = AUV_HOOK_FAULT(dk) ? (1 << 12) : PAIR_POLL_LIMIT;
+  int4 cnt;
+  double cum_in, cte_sum_in, maxp_in;
+  EnvDesc ed;
+  unsigned long long* const cw = carry + CARRY_WORDS * (size_t)e;
+  if (step == 0) {
+    cnt = st.counters[e];
+    cum_in = st.info64[8 * (size_t)e + 4], cte_sum_in = st.info64[8 * (size_t)e + 7], maxp_in = st.info64[8 * (size_t)e + 5];
+    ed = env_desc[e];
+  } else {
+    // ---- the previous step's carry: words c, 8 + c, 16 + c of the group's environment ----
+    // (idle groups wait for nobody: the record of the environment they shadow -- the launch's last -- belongs to ITS waves, and
+    // its finish wave of this step may overwrite it before a foreign reader has looked; they take that environment's table
+    // descriptor from the array instead -- possibly a step old, always a valid one: their table reads stay in bounds and their
+    // results are dropped)
+    unsigned long long v0 = 0ull, v1 = 0ull, v2 = 0ull;
+    bool ok = !live;
+    for (int polls = 0;; polls++) {
+      if (!ok) {
+        v0 = __hip_atomic_load(cw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v1 = __hip_atomic_load(cw + 8 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v2 = __hip_atomic_load(cw + 16 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned long long xb = roles_group_xor(v1) ^ roles_group_xor(c < 4 ? v2 : 0ull), mb = roles_group_word(v2, 4);
+      ok = !live || (roles_record_ok(v0, c, tagmix_prev) && mb != 0ull && roles_mark(xb ^ tagmix_prev) == mb);
+      if (!__any(!ok)) break;
+      if ((polls & 31) == 31 && auv_uniform(__hip_atomic_load(dc->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+      if (polls == limit) {
+        if (live && c == 0) auv_st<true>(broken + e, (uint8_t)1);
+        roles_give_up(d, e0, ne, 6, lane);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
+    }
+    const unsigned long long c6 = roles_group_word(v0, 6), c8 = roles_group_word(v1, 0);
+    cnt = make_int4((int)(unsigned)c6, (int)(unsigned)(c6 >> 32), (int)(unsigned)c8, 0);
+    cum_in = roles_group_value(v1, 1), maxp_in = roles_group_value(v1, 2), cte_sum_in = roles_group_value(v1, 3);
+    unsigned long long w[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = roles_group_word(v1, 4 + i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[4 + i] = roles_group_word(v2, i);
+    carry_ed_from(ed, w);
+    if (!live) ed = env_desc[e];
+  }
+  const int w = ed.w;
+  TailIn t;
+  t.kn0 = ed.kn0, t.nk = ed.nk;
+  {
+    const double* ws = world_scalar + 8 * (size_t)ed.w;
+    t.L = ws[0], t.goal_x = ws[1], t.goal_y = ws[2];
+    t.knot_first = st.knot_s[ed.kn0], t.knot_last = st.knot_s[ed.kn0 + ed.nk - 1];
+    t.maxp_in = maxp_in;
+  }
+  const unsigned long long* pk = k1_pkt + 8 * (size_t)e;
+  unsigned long long* hd = nav_hand + 8 * (size_t)e;
+  // ---- the state packet and the search record of every group (this step's) ----
+  unsigned long long vp = 0ull, vh = 0ull;
+  bool okp = !live, okh = !live, aborted = false;
+  for (int polls = 0;; polls++) {
+    if (!okp) vp = __hip_atomic_load(pk + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!okh) vh = __hip_atomic_load(hd + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    okp = !live || roles_record_ok(vp, c, tagmix);
+    aborted = live && okp && (unsigned)roles_group_word(vp, 6) == ROLES_ABORT_COUNTER;
+    okh = !live || aborted || roles_record_ok(vh, c, tagmix);
+    if (!__any(!(okp && okh))) break;
+    if (polls == limit) {
+      if (live && c == 0) auv_st<true>(broken + e, (uint8_t)1);
+      roles_give_up(d, e0, ne, 3, lane);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
+  }
+  if (__any(aborted)) return;
+  t.px = roles_group_value(vp, 0), t.py = roles_group_value(vp, 1), t.psi = roles_group_value(vp, 2);
+  t.u = roles_group_value(vp, 3), t.v = roles_group_value(vp, 4), t.r = roles_group_value(vp, 5);
+  cnt.y = (int)(unsigned)roles_group_word(vp, 6);
+  t.nr.A = make_double2(roles_group_value(vh, 0), roles_group_value(vh, 1));
+  t.nr.B = make_double2(roles_group_value(vh, 2), roles_group_value(vh, 3));
+  t.nr.cum = roles_group_value(vh, 4);
+  NavOut no;
+  no.rew_path = no.reached = no.goal = no.progress = no.u = no.v = no.r = no.cte100 = no.maxp = 0.0;
+  unsigned long long word = live ? __hip_atomic_load(pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  no = nav_tail<K1_GROUP>(st, e, c, live, t, obs_out);
+  if (live && c < 6) state[(size_t)c * (size_t)n_envs + e] = __longlong_as_double((long long)vp);
+  for (int polls = 0;; polls++) {
+    if (!__any(word == PAIR_EMPTY)) break;
+    if (word == PAIR_EMPTY) word = __hip_atomic_load(pair_word + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!__any(word == PAIR_EMPTY)) break;
+    if (polls == limit) {
+      if (live && c == 0) auv_st<true>(broken + e, (uint8_t)1);
+      roles_give_up(d, e0, ne, 1, lane);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
+  }
+  int do_reset = 0;
+  double co[2] = {0.0, 0.0};
+  if (live && c == 0) {
+    __hip_atomic_store(pair_word + e, PAIR_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(k1_pkt + 8 * (size_t)e + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(hd + 7, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    RewardIn in;
+    const int collision = word == PAIR_COLLISION;
+    in.closeness_reward = collision ? 0.0 : __longlong_as_double((long long)word);
+    in.path_reward = no.rew_path, in.reached = no.reached, in.goal = no.goal, in.progress = no.progress;
+    in.u = no.u, in.v = no.v, in.yaw_rate = no.r;
+    in.cum = cum_in;
+    in.cte100 = no.cte100, in.cte_sum = cte_sum_in;
+    st.info64[8 * (size_t)e] = collision;
+    do_reset = reward_apply(st, e, collision, cnt, in, reward_out, done_out, false, co);
+  }
+  unsigned long long m = __ballot(do_reset);
+  const unsigned long long m_reset = m;
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int er2 = auv_uniform(__shfl(e, src, AUV_WAVE));
+    const int wr = auv_uniform(__shfl(w, src, AUV_WAVE)), ep = auv_uniform(__shfl(cnt.z, src, AUV_WAVE));
+    const AuvDev* dp = dk.self;
+    asm volatile("" : "+s"(dp));
+    const AuvDev& dr = *(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)dp;
+    restore_env<false, true>(dr, er2, (int)(((long long)wr + dr.n) % dr.n_worlds), lane, ep, obs_out);
+  }
+  if (last_step) return;                                   // (the launch that follows reads the arrays, behind a kernel boundary)
+  // ---- this step's outcome into the carry record ----
+  // every store the next step's waves depend on -- the marks taken down, a restored environment's mover / nearby rows -- is
+  // complete before the record can be seen
+  auv_stores_done();
+  unsigned long long w0, w1, w2;
+  {
+    // group lane 0 ran the reward phase: its counters, cumulative reward, cross-track sum and the tail's maximum progress
+    const int cx = __shfl(cnt.x, 0, K1_GROUP), cy = __shfl(cnt.y, 0, K1_GROUP), cz = __shfl(cnt.z, 0, K1_GROUP);
+    const double cum = __shfl(co[0], 0, K1_GROUP), cte = __shfl(co[1], 0, K1_GROUP), maxp = __shfl(no.maxp, 0, K1_GROUP);
+    w0 = c < 6 ? vp : (unsigned long long)(unsigned)cx | ((unsigned long long)(unsigned)cy << 32);
+    w1 = c == 0 ? (unsigned long long)(unsigned)cz
+                : (c == 1 ? (unsigned long long)__double_as_longlong(cum)
+                          : (c == 2 ? (unsigned long long)__double_as_longlong(maxp) : (c == 3 ? (unsigned long long)__double_as_longlong(cte) : carry_ed_word(ed, c - 4))));
+    w2 = c < 4 ? carry_ed_word(ed, 4 + c) : 0ull;
+  }
+  if (m_reset & (0xffull << (8 * g))) {
+    // this group's environment was restored: what the restore has just written (this wave's own stores, complete: read past L1)
+    const size_t n = (size_t)n_envs;
+    const int4 rc = make_int4(0, 0, __shfl(cnt.z, 0, K1_GROUP), 0);
+    const EnvDesc ne_ = auv_make_desc<true>(d, (int)(((long long)w + d.n) % d.n_worlds));
+    const double sv = c < 6 ? __hip_atomic_load(state + (size_t)c * n + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    const double iv = (c >= 1 && c <= 3) ? __hip_atomic_load(st.info64 + 8 * (size_t)e + (c == 1 ? 4 : (c == 2 ? 5 : 7)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    w0 = c < 6 ? (unsigned long long)__double_as_longlong(sv) : 0ull;          // counters x = y = 0
+    w1 = c == 0 ? (unsigned long long)(unsigned)rc.z : (c <= 3 ? (unsigned long long)__double_as_longlong(iv) : carry_ed_word(ne_, c - 4));
+    w2 = c < 4 ? carry_ed_word(ne_, 4 + c) : 0ull;
+  }
+  const unsigned long long ma = roles_mark(roles_group_xor(c < 7 ? w0 : 0ull) ^ tagmix);
+  const unsigned long long mb = roles_mark(roles_group_xor(w1) ^ roles_group_xor(c < 4 ? w2 : 0ull) ^ tagmix);
+  if (live) {
+    __hip_atomic_store(cw + c, c < 7 ? w0 : ma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cw + 8 + c, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cw + 16 + c, c < 4 ? w2 : (c == 4 ? mb : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvDev dk, const void* __restrict__ actions, float* __restrict__ obs_out,
+                                                                           float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
+                                                                           const int n_steps, const int first_slot, const int n_slots,
+                                                                           const unsigned long long seq0, const int lead_dyn, const int lag_fin, const unsigned magic_c) {
+  const AuvDev& d = dk;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int S = d.cfg.n_sensors;
+  const int ne = d.ne;
+  const int nk = 8 * ((ne + 63) / 64), nb = 8 * ((ne + 7) / 8);
+  const int per = 2 * nk + 2 * nb;
+  // role: 0 dynamics, 1 sweep, 2 search, 3 finish; bi: the wave's index within its role and step.
+  // Two workgroup orders (both computed, one selected: a run-time branch around this index arithmetic makes this compiler emit a
+  // vector-to-scalar copy it then rejects):
+  //   step-major: all of step t's workgroups, role by role, then step t + 1's;
+  //   COHORT-PIPELINED (lead_dyn >= 0).  A cohort = 64 consecutive environments = 8 dynamics + 64 sweep + 64 search + 8 finish
+  //   workgroups (every run a multiple of 8: an environment's waves still share an XCD).  Cohort-steps are numbered
+  //   q = step * C + cohort; position p of the grid holds the dynamics of q = p, the sweeps and searches of q = p - lead and the
+  //   finish waves of q = p - lead - lag: a sweep is dispatched `lead` positions behind its dynamics -- which have finished by
+  //   then -- and a finish wave `lag` positions behind its sweeps, so waves find what they need instead of holding a slot while
+  //   they poll for it (the step-major order makes step t + 1's sweeps wait, resident, for a finish wave that is dispatched last
+  //   of all of step t).  lead + lag < C keeps every producer ahead of its consumer in index order, also across steps: the
+  //   dynamics of q + C sit at position q + C, behind the finish waves of q at q + lead + lag.
+  const bool cohorts = lead_dyn >= 0;
+  const int bx = (int)blockIdx.x;
+  // step-major
+  const int step_a = bx / per, b_a = bx - step_a * per;
+  const int role_a = b_a < nk ? 0 : (b_a < nk + nb ? 1 : (b_a < nk + 2 * nb ? 2 : 3));
+  const int bi_a = b_a - (role_a == 0 ? 0 : (role_a == 1 ? nk : (role_a == 2 ? nk + nb : nk + 2 * nb)));
+  // cohort-pipelined
+  const int C = nk / 8;
+  const int p = bx / 144, r = bx - 144 * p;
+  const int role_c = r < 8 ? 0 : (r < 72 ? 1 : (r < 136 ? 2 : 3));
+  const int q = p - (role_c == 0 ? 0 : (role_c == 3 ? lead_dyn + lag_fin : lead_dyn));
+  const bool q_ok = q >= 0 && q < n_steps * C;
+  const int step_c = (int)__umulhi((unsigned)(q_ok ? q : 0), magic_c);      // q / C by the host's multiplier ceil(2^32 / C): exact for q < 2^32 / C
+  const int c = (q_ok ? q : 0) - step_c * C;
+  const int bi_c = (role_c == 0 ? r : (role_c == 1 ? r - 8 : (role_c == 2 ? r - 72 : r - 136))) + ((role_c == 0 || role_c == 3) ? 8 * c : 64 * c);
+  int step = auv_uniform(cohorts ? (q_ok ? step_c : n_steps) : step_a);      // (a position outside the launch: ends below)
+  int role = auv_uniform(cohorts ? role_c : role_a), bi = auv_uniform(cohorts ? bi_c : bi_a);
+  if (step >= n_steps) return;
+  const unsigned long long tagmix = roles_tagmix(seq0 + (unsigned long long)step + 1ull), tagmix_prev = roles_tagmix(seq0 + (unsigned long long)step);
+  if (role == 0) {
+    // ---- Vessel.step of eight environments ----
+    if (bi >= nk) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int b = bi;
+    const int g = lane / K1_GROUP, c = lane % K1_GROUP;
+    const int er = 8 * (8 * (b / 8) + g) + (b % 8);
+    const bool live = er < ne;
+    const int eg = d.e0 + (live ? er : ne - 1);
+    int y, gave_up = 0;
+    double y0 = 0.0;
+    if (step == 0) {
+      y = d.counters[eg].y + 1;
+    } else {
+      // this environment's state and counters after the previous step: the first line of its carry record
+      const unsigned long long* cw = d.carry + CARRY_WORDS * (size_t)eg;
+      unsigned long long v = 0ull;
+      bool ok = !live;
+      for (int polls = 0;; polls++) {
+        if (!ok) v = __hip_atomic_load(cw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = !live || roles_record_ok(v, c, tagmix_prev);
+        if (!__any(!ok)) break;
+        if ((polls & 31) == 31 && auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          gave_up = 1;                                                              // (ABORT packets below)
+          break;
+        }
+        if (polls == (AUV_HOOK_FAULT(d) ? (1 << 12) : PAIR_POLL_LIMIT)) {
+          if (live && c == 0) auv_st<true>(d.broken + eg, (uint8_t)1);
+          roles_give_up(d, d.e0, d.ne, 6, lane);
+          gave_up = 1;                                                              // (the flag is up now: ABORT packets below)
+          break;
+        }
+        __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
+      }
+      y0 = __longlong_as_double((long long)v);
+      y = (int)(unsigned)(roles_group_word(v, 6) >> 32) + 1;
+    }
+    const int aborted = gave_up | auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    double t = 0.0;
+    if (!aborted) t = k1_group(d, actions, eg, lane, step == 0 ? nullptr : &y0, (first_slot + step) % n_slots);
+    unsigned long long* pk = d.k1_pkt + 8 * (size_t)eg;
+    const unsigned long long word = aborted ? (c == 6 ? (unsigned long long)ROLES_ABORT_COUNTER : 0ull)
+                                            : (c < 6 ? (unsigned long long)__double_as_longlong(t) : (c == 6 ? (unsigned long long)(unsigned)y : 0ull));
+    const unsigned long long mark = roles_mark(roles_group_xor(word) ^ tagmix);
+    if (live && !(AUV_HOOK_FAULT(d) == 2 && eg == d.e0 && step == 0))
+      __hip_atomic_store(pk + c, c < 7 ? word : mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  EnvPre pre;
+  EnvDesc ed;
+  if (role == 1) {
+    // ---- _update + Vessel.perceive of one environment ----
+    if (bi >= ne) return;
+    const int e = auv_uniform(d.e0 + bi);
+    if (auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+    const Slice L = carve(smem, S, d.k_max, d.m_max);
+    K2Pre kp;
+    if (step == 0) {
+      ed = d.env_desc[e];
+      pre.cnt = d.counters[e];
+      pre.ed = &ed;
+      k2_movers<true>(d, e, lane, L, ed, 1);
+      kp = k2_prefetch(d, e, lane, ed);
+    } else {
+      if (carry_wait_wave(d, e, lane, tagmix_prev, ed, pre.cnt)) return;
+      pre.ed = &ed;
+      k2_movers<true, true>(d, e, lane, L, ed, 1);
+      kp = k2_prefetch<true>(d, e, lane, ed);
+    }
+    k2_stage_beams(d, lane, L);
+    {
+      const int ws = roles_wait_state(d, e, lane, pre, tagmix);
+      if (ws) {
+        if (ws == 2 && ed.M > 0 && lane == 0) auv_st<true>(d.broken + e, (uint8_t)1);
+        return;
+      }
+    }
+    int2 lim0 = make_int2(INT32_MIN, INT32_MIN);
+    const int n_act = k2_front<true>(d, e, lane, L, 1, &pre, 1, &kp, true, &lim0);
+    k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
+    double term = 0.0;
+    const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term, &lim0);
+    pair_publish_lidar(d, e, lane, collision, term);
+  } else if (role == 2) {
+    // ---- Vessel.navigate of one environment: the nearest-point search ----
+    const int el = bi;
+    if (el >= ne) return;
+    const int e = auv_uniform(d.e0 + el);
+    if (step == 0) {
+      ed = d.env_desc[e];
+      pre.cnt = d.counters[e];
+    } else if (carry_wait_wave(d, e, lane, tagmix_prev, ed, pre.cnt)) {
+      return;
+    }
+    pre.ed = &ed;
+    if (roles_wait_state(d, e, lane, pre, tagmix)) return;
+    NavNear nr;
+    int* list = (int*)smem;
+    const NavSpec sp = nav_bounds(d, e, lane, list, pre.s[0], pre.s[1], &ed);
+    nr = nav_nearest(d, e, lane, list, pre.s[0], pre.s[1], sp);
+    roles_publish_search(d, e, lane, nr, tagmix);
+  } else {
+    // ---- navigation tail + reward / done / auto-reset of eight environments ----
+    const int f = bi;
+    if (f >= nk) return;
+    __builtin_amdgcn_s_setprio(2);
+    roles_finish_wave_multi<true>(d, f, lane, obs_out, reward_out, done_out, step, step == n_steps - 1, tagmix, tagmix_prev);
+  }
+}
+
 // ---- inside a captured graph of several steps: reward / done / auto-reset of step t and Vessel.step of step t + 1
 // in ONE launch (the actions of an open-loop stretch are in the ring already, so nothing sits between the two).
 // Lanes <-> environments for both: the scalar form of the dynamics (k1_env: the same operations in the same order
@@ -768,12 +1191,40 @@ void auv_launch_step_roles(const AuvDev& d0, const void* actions, int dtype, flo
   hipExtLaunchKernelGGL(k_step_roles, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
 }
 
+// order: 0 step-major; 1 cohort-pipelined (lead / lag chosen here: as long as the slice has cohorts for them)
+void auv_launch_step_multi(const AuvDev& d0, const void* actions, int dtype, float* obs, float* reward, uint8_t* done, int n_steps,
+                           int first_slot, int n_slots, unsigned long long seq0, int order, int lead, int lag, hipStream_t st) {
+  AuvDev d = d0;
+  d.act_f64 = dtype == AUV_F64;
+  d.ring_slots = 1;
+  const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
+  const int C = nk / 8;
+  if (order == 1 && C >= 3 && d.ne % 64 == 0) {
+    if (lead < 1) lead = 1;
+    if (lag < 1) lag = 1;
+    while (lead + lag > C - 1) {                          // every producer ahead of its consumer, also across steps
+      if (lag > lead && lag > 1) lag--;
+      else if (lead > 1) lead--;
+      else lag--;
+    }
+    const dim3 grid((unsigned)(n_steps * C + lead + lag) * 144u), block(AUV_WAVE);
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);
+    hipLaunchKernelGGL(k_step_multi, grid, block, lds, st, d, actions, obs, reward, done, n_steps, first_slot, n_slots, seq0, lead, lag, magic);
+    return;
+  }
+  const dim3 grid((unsigned)n_steps * (unsigned)(2 * nk + 2 * nb)), block(AUV_WAVE);
+  hipLaunchKernelGGL(k_step_multi, grid, block, lds, st, d, actions, obs, reward, done, n_steps, first_slot, n_slots, seq0, -1, 0, 0u);
+}
+
 uint32_t auv_step_lds_bytes(const AuvDev& d) { return (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
 
 hipError_t auv_step_fused_prepare(const AuvDev& d) {
   const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
   if (b <= 64 * 1024) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_step_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_step_roles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
 }

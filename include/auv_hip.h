@@ -182,6 +182,26 @@ int auv_step_pipelined(auv_handle_t* h, int32_t n_slices, const int32_t* bounds,
                        const void* actions_dev, int32_t action_dtype, float* obs_dev, float* reward_dev,
                        uint8_t* done_dev);
 
+/* SEVERAL steps of every slice in ONE launch per slice (open-loop stretches: the actions are resident).  actions_dev is a ring of
+ * n_slots consecutive [N][2] buffers; step k of the call reads slot (first_slot + k) % n_slots.  The launch is the one-launch step's
+ * grid n_steps times over, step-major: an environment's step k + 1 starts when ITS finish wave of step k is through -- no barrier
+ * over the slice between two steps, no launch turn-around.  What the kernel boundary between two launches did is done by a
+ * per-environment carry record (agent-scope stores / loads, checksummed, every mark carrying the step's number): csrc/
+ * k_step_fused.hip, k_step_multi.  obs / reward / done hold the LAST step's values afterwards; everything else -- state, counters,
+ * episode log, auto-reset -- is bit for bit what n_steps calls of auv_step_pipelined leave (tests/test_gpu_multi.py).  Needs the
+ * one-launch shape for every slice and at most 64 obstacles per world; refused with a fresh world per reset.  Polls are bounded and
+ * report like the one-launch step's (auv_health).                                                                     */
+int auv_step_multi(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, void* const* streams, const void* actions_dev,
+                   int32_t action_dtype, int32_t n_slots, int32_t first_slot, int32_t n_steps, float* obs_dev, float* reward_dev,
+                   uint8_t* done_dev);
+
+/* Workgroup order of auv_step_multi's launches (same results either way).  order 0: step-major (all of step t, role by role, then
+ * step t + 1).  order 1 (default): cohort-pipelined -- cohorts of 64 environments; the sweeps of a cohort-step are dispatched `lead`
+ * cohort positions behind its dynamics and its finish waves `lag` positions behind the sweeps, so a wave finds its inputs instead of
+ * holding a wave slot while it polls; lead + lag are cut down to (cohorts of the slice) - 1, which keeps every producer ahead of its
+ * consumer in dispatch order; slices that are not a multiple of 64 environments, or of fewer than 3 cohorts, use order 0.      */
+int auv_set_multi_order(auv_handle_t* h, int32_t order, int32_t lead, int32_t lag);
+
 /* VecEnv.step_async / step_wait (scripts/run.py:293-296: SubprocVecEnv sends the actions to its workers and collects their
  * results) with the ordering between the caller's stream and the chains done INSIDE the library, one call each:
  *   auv_step_async  the actions were produced on `caller_stream`; slice i is stepped on streams[i] behind them.  A slice whose

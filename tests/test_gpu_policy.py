@@ -87,6 +87,7 @@ def test_policy_noise_is_standard_normal_and_uncorrelated():
     for s in range(200):
         fused.begin_rollout()
         fused.act(0)
+        torch.cuda.synchronize()                                # (the launch runs on the sub-batch's stream, the clone on the caller's)
         eps.append(fused.eps.clone())
     e = torch.stack(eps).double()                              # [steps, rows, 2]
     assert abs(float(e.mean())) < 0.01 and abs(float(e.var()) - 1.0) < 0.02

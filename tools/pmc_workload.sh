@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 sha256sum gym_auv_amd/csrc/libauv_hip.so > $OUT/lib_sha256.txt
-B="$ROOT/bench.py --bank-cache /tmp/bank --workload $WL --sub-batches $SUB --probe-streams 0 --cpu-baseline 0"
+B="$ROOT/bench.py --bank-cache /tmp/bank --workload $WL --sub-batches $SUB --probe-streams 0 --cpu-baseline 0 --multi 1"
 # Every pass says when it starts AND when it ends, and its stderr is APPENDED to $OUT/pmc_stderr.log (round 4: both went to
 # /dev/null, and a pass that sat behind a polling kernel for 300 s was killed for silence with nothing to read afterwards)
 ERR=$OUT/pmc_stderr.log

@@ -47,7 +47,7 @@ run bench_circles20 $OUT/bench_circles20.json $B --workload circles20 --cpu-base
 run bench_moving28 $OUT/bench_moving28.json $B --workload moving28 --cpu-baseline 0
 # a fresh world on every reset (round 5): the generator inside the timed region, the bank-cycling rate of the same loop beside it
 run bench_moving28_fresh_worlds $OUT/bench_moving28_fresh_worlds.json $B --workload moving28 --fresh-worlds 1 --steps 2000 --warmup 3000 --cpu-baseline 0
-run bench_moving28_fresh_worlds_depth2 $OUT/bench_moving28_fresh_worlds_depth2.json $B --workload moving28 --fresh-worlds 1 --worlds-per-env 4 --fresh-period 8 --steps 2000 --warmup 3000 --cpu-baseline 0
+run bench_moving28_fresh_worlds_depth4_period8 $OUT/bench_moving28_fresh_worlds_depth4_period8.json $B --workload moving28 --fresh-worlds 1 --worlds-per-env 4 --fresh-period 8 --steps 2000 --warmup 3000 --cpu-baseline 0
 run host_bound_probe $OUT/host_bound_probe.jsonl python tools/host_bound_probe.py
 run side_queue_probe $OUT/side_queue_probe_default.json python tools/side_queue_probe.py
 run side_queue_probe2 $OUT/side_queue_probe2.json python tools/side_queue_probe2.py
