@@ -119,6 +119,41 @@ def main():
                               effective=env.effective_step_mode())), flush=True)
         ref.close(), env.close()
 
+    # ---- the same inside a launch of SEVERAL steps (auv_step_multi): the sweep of the first environment withholds its word in
+    # step 0; its finish wave gives up, the abort flag goes up, every later step of the launch does nothing (ABORT packets; waves
+    # that wait for a carry record look at the flag) -- the launch of 16 steps ENDS in milliseconds, the next call reports once
+    # and resets the marked environments, stepping goes on
+    import time as _time
+    for fault in (1, 2):
+        n = 256
+        cfg = effective_reference_config(use_lidar=True)
+        env = env_(cfg, n, "one_launch", fault=fault)
+        env.set_sub_batches(1)
+        ring = torch.zeros((4, n, 2), dtype=torch.float32, device="cuda:0")
+        ring[:, :, 0] = 0.7
+        torch.cuda.synchronize()
+        t0 = _time.perf_counter()
+        env.step_multi(ring, 0, 16)
+        torch.cuda.synchronize()
+        dt = _time.perf_counter() - t0
+        h1 = env.health()
+        t_step = env.read("COUNTERS")[:, 0]
+        marked = int((env.read("BROKEN") != 0).sum())
+        msg = ""
+        try:
+            env.step(ring[0])
+        except RuntimeError as exc:
+            msg = str(exc)
+        h2 = env.health()
+        ok = True
+        for _ in range(5):
+            o, r, dn, _ = env.step(ring[0])
+            ok = ok and bool(torch.isfinite(o).all()) and bool(torch.isfinite(r).all())
+        torch.cuda.synchronize()
+        print(json.dumps(dict(case="multi_fault", fault=fault, seconds=round(dt, 4), after_launch=h1, after_recovery=h2, message=msg, marked=marked,
+                              t_step_min=int(t_step.min()), t_step_max=int(t_step.max()), continues=bool(ok), effective=env.effective_step_mode())), flush=True)
+        env.close()
+
     # ---- the dispatch-order probe in the shape production runs: four launches in flight on four streams, a foreign kernel
     # behind each (set_sub_batches runs it); and a rendezvous kernel of step_async that gives up (nobody publishes)
     cfg = effective_reference_config(use_lidar=True)

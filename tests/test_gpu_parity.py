@@ -352,6 +352,13 @@ def test_hook_build_cases(hook_cases):
         # ... everybody else completed exactly the one step of the launches that ran: the launches queued behind did nothing
         assert c["steps_as_expected"] and c["state_equal"] and c["obs_rows_reset"], c
         assert c["continues_bitwise"] and c["effective"] == "side_by_side", c
+    # (d) the same inside a launch of sixteen steps: it ends at once, is reported once, and the handle carries on
+    multi = [c for c in hook_cases if c["case"] == "multi_fault"]
+    assert sorted(c["fault"] for c in multi) == [1, 2]
+    for c in multi:
+        assert c["seconds"] < 2.0 and c["after_launch"]["pending"] == 1 and c["marked"] >= 1, c
+        assert "timed out" in c["message"] and c["after_recovery"] == dict(handover_ok=0, probe_failures=0, timeouts=1, pending=0), c
+        assert c["t_step_max"] <= 16 and c["continues"] and c["effective"] == "side_by_side", c
     probe = [c for c in hook_cases if c["case"] == "probe"]
     assert len(probe) == 1 and probe[0]["sub_batches"] == 4 and probe[0]["effective"] == "one_launch", probe
     assert probe[0]["health"] == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0), probe

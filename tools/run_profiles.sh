@@ -13,9 +13,11 @@ sha256sum gym_auv_amd/csrc/libauv_hip.so > $OUT/lib_sha256.txt
 # Every pass says when it starts AND when it ends (a long pass otherwise looks hung to the GPU runner: round 4 lost two calls
 # to 420 s of silence), and the benches' stderr is APPENDED to $OUT/stderr.log under the pass's name -- never /dev/null.
 ERR=$OUT/stderr.log
-: > $ERR
+[ -n "$ONLY$NOT" ] || : > $ERR
 run() {   # run <name> <stdout file> <command ...>
   local name=$1 out=$2; shift 2
+  if [ -n "$ONLY" ] && ! [[ $name =~ $ONLY ]]; then return 0; fi     # ONLY=<regex> / NOT=<regex>: a round's passes split over GPU calls
+  if [ -n "$NOT" ] && [[ $name =~ $NOT ]]; then return 0; fi
   echo "  start $name $(date +%T)"
   echo "==== $name: $*" >> $ERR
   "$@" > $out 2>> $ERR
@@ -28,6 +30,12 @@ B="python bench.py --bank-cache /tmp/bank"
 run bench_polygons50 $OUT/bench_polygons50.json $B
 echo "headline: $(cut -c1-140 $OUT/bench_polygons50.json)"
 run bench_driver_command $OUT/bench_driver_command.json python bench.py --gpus 1 --steps 20 --warmup 5 --bank-cache /tmp/bank --cpu-baseline 0
+# several steps per launch (round 5): one chain x 64 / 16 steps, two chains x 64, one step per launch on four chains; the rate table by order
+run bench_polygons50_multi64_sub1 $OUT/bench_polygons50_multi64_sub1.json $B --multi 64 --sub-batches 1 --cpu-baseline 0
+run bench_polygons50_multi16_sub1 $OUT/bench_polygons50_multi16_sub1.json $B --multi 16 --sub-batches 1 --cpu-baseline 0
+run bench_polygons50_multi64_sub2 $OUT/bench_polygons50_multi64_sub2.json $B --multi 64 --sub-batches 2 --cpu-baseline 0
+run bench_polygons50_multi1_sub4 $OUT/bench_polygons50_multi1_sub4.json $B --multi 1 --sub-batches 4 --cpu-baseline 0
+run multi_bench_polygons50 $OUT/multi_bench_polygons50.jsonl python tools/multi_bench.py polygons50 4096
 for k in 1 2; do run bench_polygons50_sub$k $OUT/bench_polygons50_sub$k.json $B --sub-batches $k --cpu-baseline 0; done
 # the VecEnv protocol: a full rendezvous per step (round 4), by mechanism and chain count; one chain on the caller's stream
 run bench_polygons50_async_inline_sub1 $OUT/bench_polygons50_async_inline_sub1.json $B --api async --sub-batches 1 --inline-first 1 --cpu-baseline 0
@@ -64,11 +72,13 @@ run policy_bench $OUT/policy_bench.log python tools/policy_bench.py 4096
 run ppo_colav_fused_4096x128 $OUT/ppo_colav_fused_4096x128.log python examples/ppo.py --envs 4096 --updates 6 --rollout 128
 run ppo_colav_fused_4096x128_generated_bank $OUT/ppo_colav_fused_4096x128_generated_bank.log python examples/ppo.py --envs 4096 --updates 6 --rollout 128 --worlds generated
 echo "benches done"
+[ "${SKIP_TRACE:-0}" = 1 ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 run bench_under_rocprof $OUT/bench_under_rocprof.json rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --bank-cache /tmp/bank --cpu-baseline 0
 cd $ROOT
 python tools/trace_summary.py $OUT/trace/*/*_kernel_trace.csv > $OUT/kernel_trace_summary.txt
 python tools/trace_overlap.py $OUT/trace/*/*_kernel_trace.csv k_step_roles 4000 > $OUT/kernel_trace_overlap.txt
+python tools/trace_overlap.py $OUT/trace/*/*_kernel_trace.csv k_step_multi 64 >> $OUT/kernel_trace_overlap.txt   # the timed loop when it runs 64 steps per launch
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace
 head -6 $OUT/kernel_trace_summary.txt; head -12 $OUT/kernel_trace_overlap.txt

@@ -42,6 +42,33 @@ np_ = lambda t: t.detach().cpu().numpy()
 n_lim = n_beams = n_done = 0
 worst = 0.0
 t0 = time.time()
+MULTI = int(os.environ.get("MULTI", "0"))      # MULTI=k: the batch is stepped k steps per launch (auv_step_multi), compared with the oracle every k steps
+if MULTI:
+    n_cmp = 0
+    for t0_ in range(0, T, MULTI):
+        acts = rs.uniform([-1, -0.15], [1, 0.15], (MULTI, E, 2))
+        acts[..., 0] = np.abs(acts[..., 0]) ** 0.3
+        env.step_multi(torch.as_tensor(acts, dtype=torch.float64, device="cuda:0").contiguous(), 0, MULTI)
+        for k in range(MULTI):
+            o_obs, o_rew, o_done = ora.step(acts[k])
+            n_done += int(o_done.sum())
+        for f in ("CULL_LIMITS", "NEARBY", "COLLISION", "WORLD_IDX", "COUNTERS"):
+            g, o = np_(env.read(f)), ora.read(f)
+            if not np.array_equal(g, o):
+                bad = np.argwhere(g != o)[0]
+                raise SystemExit("MISMATCH %s after step %d at %s: gpu %s oracle %s" % (f, t0_ + MULTI, bad, g[tuple(bad)], o[tuple(bad)]))
+        for f in ("STATE", "LIDAR_D", "OBS64", "REWARD64", "INFO64", "NAV64", "MOVER_STATE", "EPISODE"):
+            dlt = float(np.abs(np_(env.read(f)) - ora.read(f)).max())
+            worst = max(worst, dlt)
+            if dlt > 1e-8:
+                raise SystemExit("MISMATCH %s after step %d: %.3e" % (f, t0_ + MULTI, dlt))
+        n_cmp += 1
+        if (t0_ // MULTI) % 50 == 49:
+            print("step %d: %d comparisons, %d episodes, worst fp64 delta %.2e (%.0f s)" % (t0_ + MULTI, n_cmp, n_done, worst, time.time() - t0), flush=True)
+    assert env.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0), env.health()
+    print("SOAK OK multi=%d sub-batches=%d: %d envs x %d steps in launches of %d, every field against the oracle after every launch (%d comparisons), "
+          "integer fields bit-exact, %d episodes ended, worst fp64 field delta %.2e" % (MULTI, env.sub_batches, E, T, MULTI, n_cmp, n_done, worst))
+    sys.exit(0)
 for t in range(T):
     a = rs.uniform([-1, -0.15], [1, 0.15], (E, 2))
     a[:, 0] = np.abs(a[:, 0]) ** 0.3                     # mostly forward: obstacles are met
