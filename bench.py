@@ -374,34 +374,47 @@ def main():
         api = "step" if (args.actions == "pilot" and sub <= 1) else "pipelined"
     # several steps per launch (auv_step_multi) where the loop is open and long enough to fill the pipeline of a launch: ONE chain of
     # 64-step launches (measured, tools/multi_sweep.sh: 170 M env-steps/s against 153 M for four chains of one-step launches over
-    # 2000 steps; over the driver's 20-step window the launch's ramp and drain eat the gain: 124-141 M against 138 M)
+    # 2000 steps; the driver's 20-step window as ONE launch: 157-164 M against 132-138 M for four one-step chains -- once the
+    # multi-step kernel is warm: its first launch inside the timed region had cost 0.15 ms and hidden this)
     open_loop = api == "pipelined" and args.actions == "uniform" and not fresh and not K
     multi_T = args.multi
     calibration = None
     if multi_T < 0:
         multi_T = 1
-        if open_loop and args.steps >= 256 and n_local % 64 == 0 and env.effective_step_mode(n_local) == "one_launch" and args.sub_batches == 0:
-            # which open-loop shape is faster for THIS workload?  192 steps of each before anything is timed: one chain of 64-step
-            # launches (170 against 153 M env-steps/s at 4096 x 180) or four chains of one-step launches (141 against 125 M at
-            # 8192 x 256: its sweeps' larger LDS slices leave a launch of several steps too few wave slots to pipeline in)
-            def trial(k, T):
+        if open_loop and args.steps >= 4 and n_local % 64 == 0 and env.effective_step_mode(n_local) == "one_launch" and args.sub_batches == 0:
+            # which open-loop shape is faster for THIS workload and THIS window?  Measured before anything is timed, in windows shaped
+            # like the timed region (synchronize on both sides).  Long runs (>= 256 steps): 192 steps of one chain x 64-step launches
+            # (170 against 153 M env-steps/s at 4096 x 180) and of four chains x one-step launches (141 against 125 M at 8192 x 256:
+            # its sweeps' larger LDS slices leave a launch of several steps too few wave slots to pipeline in).  Short runs (the
+            # driver's 20 steps): the whole window as ONE launch, as two, in launches of five, or as four one-step chains -- a
+            # launch's ramp and drain weigh as much as its steady state there.
+            def trial(k, T, n, reps):
                 env.set_sub_batches(k, probe_streams=bool(args.probe_streams))
                 env.set_multi_order(args.multi_order, args.multi_lead, args.multi_lag)
-                for rep in range(2):
+                dts = []
+                for rep in range(reps + 1):                          # (the first window warms the shape's kernel up)
                     torch.cuda.synchronize(dev)
                     t1 = time.perf_counter()
-                    for i in range(0, 192, T):
+                    for i in range(0, n, T):
                         if T > 1:
                             env.step_multi(pool, i % n_pool, T)
                         else:
                             env.step_pipelined(pool[i % n_pool])
                     torch.cuda.synchronize(dev)
-                    dt = time.perf_counter() - t1
-                return n_local * 192 / dt
+                    dts.append(time.perf_counter() - t1)
+                return n_local * n / float(np.median(dts[1:]))
             want4 = n_local >= 2048 and env.effective_step_mode(n_local // 4) == "one_launch"
-            r_multi, r_chains = trial(1, 64), trial(4 if want4 else 1, 1)
-            multi_T = 64 if r_multi > r_chains else 1
-            calibration = dict(one_chain_64_steps_per_launch=round(r_multi, 1), chains_one_step_per_launch=round(r_chains, 1), steps_each=192)
+            if args.steps >= 256:
+                r_multi, r_chains = trial(1, 64, 192, 1), trial(4 if want4 else 1, 1, 192, 1)
+                multi_T = 64 if r_multi > r_chains else 1
+                calibration = dict(one_chain_64_steps_per_launch=round(r_multi, 1), chains_one_step_per_launch=round(r_chains, 1), steps_each=192)
+            else:
+                cands = sorted({T for T in (args.steps, args.steps // 2, 5) if 2 <= T <= min(64, n_pool) and args.steps % T == 0}, reverse=True)
+                rates = {T: trial(1, T, args.steps, 5) for T in cands}
+                rates[1] = trial(4 if want4 else 1, 1, args.steps, 5)
+                multi_T = max(rates, key=rates.get)
+                calibration = dict({("one_chain_%d_steps_per_launch" % T if T > 1 else "chains_one_step_per_launch"): round(r, 1) for T, r in rates.items()},
+                                   steps_each=args.steps, windows_each=5)
             env.reset()
     if multi_T > 1 and not open_loop:
         raise SystemExit("--multi T: open-loop stretches only (api pipelined, resident actions, no --fresh-worlds, no --graph)")
@@ -561,18 +574,27 @@ def main():
     step_bytes = sum(alg[ph] for ph in ("k1", "lidar", "nav", "reward"))
     pipelined = sub > 1 and env.effective_step_mode(max(1, n_local // sub)) == "one_launch"
     if api == "multi":
-        # every chain's launch of multi_T steps bracketed by HIP events on ITS stream (the stream is in order: the pair encloses
-        # exactly that launch) while the other chains' launches run beside it
+        # a run of back-to-back launches of multi_T steps bracketed by ONE pair of HIP events per chain, on that chain's stream (the
+        # stream is in order: the pair encloses exactly those launches, as the timed region issues them) => average launch duration;
+        # `alone_ms`: one launch between its own pair of events (its ramp and drain not hidden under its neighbours)
         n_launch = max(4, min(n_prof // multi_T, 24))
-        evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in env._sub_streams] for _ in range(n_launch)]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in env._sub_streams]
+        ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in env._sub_streams]
+        for (a, _), stq in zip(evs, env._sub_streams):
+            a.record(stq)
         for j in range(n_launch):
-            for (a, _), stq in zip(evs[j], env._sub_streams):
-                a.record(stq)
             env.step_multi(pool, (j * multi_T) % n_pool, multi_T)
-            for (_, b), stq in zip(evs[j], env._sub_streams):
-                b.record(stq)
+        for (_, b), stq in zip(evs, env._sub_streams):
+            b.record(stq)
         torch.cuda.synchronize(dev)
-        lms = np.array([[a.elapsed_time(b) for a, b in row] for row in evs]).mean(axis=0)      # ms per launch, per chain
+        for (a, _), stq in zip(ev1, env._sub_streams):
+            a.record(stq)
+        env.step_multi(pool, 0, multi_T)
+        for (_, b), stq in zip(ev1, env._sub_streams):
+            b.record(stq)
+        torch.cuda.synchronize(dev)
+        lms = np.array([a.elapsed_time(b) / n_launch for a, b in evs])      # ms per launch, per chain
+        alone = np.array([a.elapsed_time(b) for a, b in ev1])
         names = ["k_step_multi"]
         kms = np.array([lms.mean(), 0.0, 0.0, lms.max()])
         launch_bytes = step_bytes / env.sub_batches * multi_T
@@ -580,7 +602,8 @@ def main():
                                            algorithmic_bytes=int(launch_bytes),
                                            achieved_GBs=round(launch_bytes / (lms.mean() * 1e-3) / 1e9, 1),
                                            frac=round(launch_bytes / (lms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                           per_slice_ms=[round(float(x), 5) for x in lms],
+                                           per_slice_ms=[round(float(x), 5) for x in lms], launches_timed=n_launch,
+                                           alone_ms=round(float(alone.mean()), 5),
                                            avg_ms_per_step=round(float(lms.mean()) / multi_T, 5))}
     elif pipelined:
         # every sub-batch launch stamped on its own stream while the other chains run beside it
@@ -737,8 +760,10 @@ def main():
             cyc.close()
 
     lib_sha = library_sha256()
-    cfg_key = "%s/sub%d" % (args.workload, sub)     # (the committed counter passes step ONE step per launch -- k_step_roles, the very
-                                                     # device functions k_step_multi runs: tools/pmc_workload.sh passes --multi 1)
+    # the committed counter passes: of this very shape ("polygons50/sub1_T64": MULTI=64 tools/pmc_workload.sh) when there is one,
+    # otherwise of one step per launch over as many chains (k_step_roles: the device functions k_step_multi runs)
+    cfg_key = "%s/sub%d" % (args.workload, sub)
+    cfg_key_T = cfg_key + ("_T%d" % multi_T if multi_T > 1 else "")
 
     def committed(name):
         """per-STEP counters of the step's launches from the committed rocprofv3 passes (4096 envs per GPU, this
@@ -747,7 +772,14 @@ def main():
         if n_local != 4096 or not os.path.exists(path):
             return None
         try:
-            return json.load(open(path)).get(cfg_key)
+            tab = json.load(open(path))
+            k = cfg_key_T if cfg_key_T in tab else cfg_key
+            if multi_T > 1 and cfg_key_T not in tab:
+                # (no pass of this very launch length: the counters per STEP of another length of the same kernel, nearest first)
+                others = sorted((abs(int(x.rsplit("_T", 1)[1]) - multi_T), x) for x in tab if x.startswith(cfg_key + "_T"))
+                if others:
+                    k = others[0][1]
+            return dict(tab[k], key=k) if k in tab else None
         except Exception:
             return None
 
@@ -769,7 +801,7 @@ def main():
                     frac=round(issue / (N_SIMD * cyc_step), 4),
                     frac_at_measured_clock=round(issue / (N_SIMD * sq["clock_ghz"] * 1e9 * ms_step * 1e-3), 4), measured_clock_ghz=sq["clock_ghz"],
                     wait_frac=round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 4) if sq.get("SQ_WAVE_CYCLES") else None,
-                    source="profiles/pmc_sq.json [%s]" % cfg_key, lib_sha256=sq.get("lib_sha256"),
+                    source="profiles/pmc_sq.json [%s]" % sq["key"], lib_sha256=sq.get("lib_sha256"),
                     stale=sq.get("lib_sha256") != lib_sha)
     legs = dict(hbm=hbm_frac, valu=valu["frac"] if valu else 0.0)
     bound = max(legs, key=legs.get)

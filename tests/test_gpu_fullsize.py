@@ -321,3 +321,50 @@ def test_captured_chains_in_the_side_by_side_shape_walk_their_own_ring_positions
         assert torch.equal(eager.read(f), chains.read(f)), f
     assert int(eager.read("COUNTERS")[:, 2].sum()) >= n
     eager.close(), chains.close()
+
+
+@pytest.mark.parametrize("kind,n,ns,nps,T", [("polygons50", 4096, 9, 20, 64), ("mixed47", 8192, 16, 16, 48)])
+def test_fullsize_several_steps_per_launch_bitwise_and_against_the_oracle(kind, n, ns, nps, T):
+    """BASELINE's full shapes through `auv_step_multi`: two launches of T steps are bit for bit 2 T one-step
+    launches (every output of every step, every field at the end), and a 64-env subset agrees with the oracle."""
+    from gym_auv_amd.batched_env import BatchedAuvEnv
+    from oracle.pyoracle import Oracle
+    cfg = effective_reference_config(use_lidar=True)
+    cfg.vessel.n_sectors, cfg.vessel.n_sensors_per_sector = ns, nps
+    cfg.episode.max_timesteps = 37                     # every env turns over inside each launch
+    bank = _bank(kind)
+    W = int(bank["n_worlds"])
+    one = BatchedAuvEnv(cfg, bank, n, device="cuda:0", auto_reset=True)
+    mul = BatchedAuvEnv(cfg, bank, n, device="cuda:0", auto_reset=True)
+    rs = np.random.RandomState(11)
+    sub = np.sort(rs.choice(n, 64, replace=False))
+    ora = Oracle(make_config(cfg, auto_reset=False), len(sub), bank)
+    w_now = (sub % W).astype(np.int32)
+    one.reset(), mul.reset(), ora.reset(world_idx=w_now)
+    a_np = rs.uniform([-1, -0.15], [1, 0.15], (T, n, 2))
+    a_np[..., 0] = np.abs(a_np[..., 0]) ** 0.3
+    ring = torch.as_tensor(a_np, device="cuda:0").contiguous()
+    n_done = 0
+    for rep in range(2):
+        for t in range(T):
+            o, r, dn, _ = one.step(ring[t])
+            o_obs, o_rew, o_done = ora.step(a_np[t][sub])
+            g_done = _np(dn)[sub]
+            np.testing.assert_array_equal(g_done, o_done)
+            np.testing.assert_allclose(_np(r)[sub], o_rew, rtol=1e-6, atol=1e-4)
+            n_done += int(o_done.sum())
+            if o_done.any():                           # the oracle's subset follows the batch's world rotation
+                w_now = np.where(o_done > 0, (w_now + n) % W, w_now).astype(np.int32)
+                ora.reset(mask=o_done, world_idx=w_now)
+        mul.step_multi(ring, 0, T)
+        torch.cuda.synchronize()
+        # (a multi-step launch leaves the LAST step's outputs in the env's buffers)
+        assert torch.equal(one.obs, mul.obs) and torch.equal(one.reward, mul.reward) and torch.equal(one.done, mul.done), rep
+        for f in ("STATE", "LIDAR_D", "OBS64", "REWARD64", "INFO64", "NAV64", "MOVER_STATE", "NEARBY", "COLLISION", "COUNTERS", "EPISODE",
+                  "CULL_LIMITS", "STEP_INFO", "WORLD_IDX"):
+            assert torch.equal(one.read(f), mul.read(f)), (rep, f)
+    assert n_done >= 64 and int(one.read("COUNTERS")[:, 2].sum()) >= 2 * n
+    la, lb = one.episode_log().cpu().numpy(), mul.episode_log().cpu().numpy()
+    np.testing.assert_array_equal(la[np.lexsort(la.T[::-1])], lb[np.lexsort(lb.T[::-1])])
+    assert mul.health() == dict(handover_ok=1, probe_failures=0, timeouts=0, pending=0)
+    one.close(), mul.close()

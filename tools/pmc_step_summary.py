@@ -5,7 +5,8 @@ of k_step_roles), plus the per-dispatch medians and the shader clock of the SQ p
 engines / the dispatch's duration in the same pass's kernel trace).
 Units: FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read
 (MI355X_MICROARCH.md), so both the raw and the reads-doubled byte counts are given.
-usage: pmc_step_summary.py <out dir> <launches per step>"""
+With a third argument T > 1 the passes ran T steps per launch (k_step_multi): a step is then 1 / T of K dispatches.
+usage: pmc_step_summary.py <out dir> <chains> [steps per launch]"""
 import collections
 import csv
 import glob
@@ -15,13 +16,16 @@ import sys
 import numpy as np
 
 out, per_step = sys.argv[1], int(sys.argv[2])
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 import os
 for nm in ("pmc_fetch", "pmc_write", "pmc_sq"):      # the passes must have stepped with that many launches per step
     f = os.path.join(out, nm + "_bench.json")
     if os.path.exists(f) and os.path.getsize(f):
         got = json.load(open(f))["config"]["sub_batches"]
         assert got == per_step, "%s ran with %d sub-batches, summary asked for %d" % (nm, got, per_step)
-STEP_KERNELS = ("k_step_roles", "k1_dynamics", "k23_lidar_nav", "k3_reward")
+        gotT = json.load(open(f))["config"].get("steps_per_launch", 1)
+        assert gotT == T, "%s ran %d steps per launch, summary asked for %d" % (nm, gotT, T)
+STEP_KERNELS = ("k_step_multi", "k_step_roles", "k1_dynamics", "k23_lidar_nav", "k3_reward")
 
 
 def kname(r):
@@ -45,17 +49,18 @@ def load(sub):
     return rows, names, dur
 
 
-res = dict(launches_per_step=per_step, kernels={}, per_step={})
+MAIN = "k_step_multi" if T > 1 else "k_step_roles"
+res = dict(launches_per_step=per_step / float(T), chains=per_step, steps_per_launch=T, kernels={}, per_step={})
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     rows, names, dur = load(sub)
     if not rows:
         continue
     ids = sorted(rows)
-    main = [i for i in ids if names[i] == "k_step_roles"] or ids
+    main = [i for i in ids if names[i] == MAIN] or ids
     main = main[len(main) // 2:]                     # steady state: the second half of the run
     lo = main[0]
     ids = [i for i in ids if i >= lo]
-    n_steps = len(main) / float(per_step)
+    n_steps = len(main) * T / float(per_step)
     for c in sorted(next(iter(rows.values()))):
         res["per_step"][c] = sum(rows[i].get(c, 0.0) for i in ids) / n_steps
     by_k = collections.defaultdict(list)
@@ -77,6 +82,6 @@ ps = res["per_step"]
 f, w = ps.get("FETCH_SIZE", 0.0), ps.get("WRITE_SIZE", 0.0)
 ps["bytes_raw"] = int((f + w) * 1024)
 ps["bytes_reads_doubled"] = int((2 * f + w) * 1024)
-main_k = res["kernels"].get("k_step_roles") or next(iter(res["kernels"].values()), {})
+main_k = res["kernels"].get(MAIN) or next(iter(res["kernels"].values()), {})
 ps["clock_ghz"] = round(main_k.get("clock_ghz", 0.0), 4)
 print(json.dumps(res, indent=1))
