@@ -577,7 +577,7 @@ def main():
         # a run of back-to-back launches of multi_T steps bracketed by ONE pair of HIP events per chain, on that chain's stream (the
         # stream is in order: the pair encloses exactly those launches, as the timed region issues them) => average launch duration;
         # `alone_ms`: one launch between its own pair of events (its ramp and drain not hidden under its neighbours)
-        n_launch = max(4, min(n_prof // multi_T, 24))
+        n_launch = max(4, min(max(args.steps, 1024) // multi_T, 24))      # (16 launches of 64 steps; the driver's 20 steps: 24 launches of 20)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in env._sub_streams]
         ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in env._sub_streams]
         for (a, _), stq in zip(evs, env._sub_streams):

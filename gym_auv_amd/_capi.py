@@ -151,6 +151,7 @@ def load_library(path: str = None) -> C.CDLL:
         "auv_step_pipelined": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp]),
         "auv_step_multi": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, i32, i32, i32, vp, vp, vp]),
         "auv_set_multi_order": (C.c_int, [vp, i32, i32, i32]),
+        "auv_lidar_stage": (C.c_int, [vp, i32, C.POINTER(i32)]),
         "auv_step_async": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(vp), vp, i32, vp, vp, vp, vp, i32]),
         "auv_step_wait": (C.c_int, [vp, vp]),
         "auv_set_rendezvous_limit": (C.c_int, [vp, C.c_double]),
@@ -206,7 +207,7 @@ def load_library(path: str = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ["auv_create", "auv_destroy", "auv_load_worlds", "auv_reset", "auv_step", "auv_step_slice",
-                    "auv_step_pipelined", "auv_step_multi", "auv_set_multi_order", "auv_step_async", "auv_step_wait", "auv_set_rendezvous_limit", "auv_graph_capture_chains",
+                    "auv_step_pipelined", "auv_step_multi", "auv_set_multi_order", "auv_lidar_stage", "auv_step_async", "auv_step_wait", "auv_set_rendezvous_limit", "auv_graph_capture_chains",
                     "auv_graph_launch_chains", "auv_policy_param_floats", "auv_policy_act", "auv_gae", "auv_policy_rollout", "auv_step_pipelined_timed", "auv_streams_overlap", "auv_episode_log", "auv_health", "auv_probe_streams", "auv_effective_step_mode",
                     "auv_step_dynamics", "auv_lidar", "auv_nav_reward", "auv_read", "auv_write",
                     "auv_field_bytes", "auv_graph_capture", "auv_graph_launch", "auv_graph_capture_steps", "auv_step_timed",

@@ -306,6 +306,13 @@ class BatchedAuvEnv:
         """Workgroup order of step_multi's launches: "cohorts" (default: cohort-pipelined, see include/auv_hip.h) or "steps"."""
         _check(_LIB.auv_set_multi_order(self._h, {"steps": 0, "cohorts": 1}[order], int(lead), int(lag)), "auv_set_multi_order")
 
+    def lidar_stage(self, segments: int = 0) -> int:
+        """Boundary segments the LiDAR wave stages in LDS per batch of its pair sweep (auv_lidar_stage): picked per bank for the
+        one-launch step's occupancy; `segments` 32 .. 96 (even) overrides it.  Results do not depend on it.  Returns the value in force."""
+        out = C.c_int32(0)
+        _check(_LIB.auv_lidar_stage(self._h, int(segments), C.byref(out)), "auv_lidar_stage")
+        return int(out.value)
+
     def step_pipelined_timed(self, actions: torch.Tensor):
         """step_pipelined with every sub-batch's launch stamped by its own HIP events: ms per sub-batch launch
         (its own duration while the other chains run beside it)."""

@@ -34,6 +34,7 @@ bool auv_k23_ok(const AuvDev& d);
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t auv_step_fused_prepare(const AuvDev& d);
 uint32_t auv_step_lds_bytes(const AuvDev& d);
+int auv_pick_seg_cap(const AuvDev& d);
 bool auv_roles_ok(const AuvDev& d);
 void auv_launch_step_roles(const AuvDev& d, const void* actions, int dtype, float* obs, float* reward, uint8_t* done,
                            hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
@@ -359,6 +360,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   d.w_ready = 0;
   auv_launch_derive(d, nullptr);
   std::vector<int32_t> wi(n);
+  d.seg_cap = auv_pick_seg_cap(d);
   if (auv_k2_lds_bytes(d) > 160 * 1024) return fail(AUV_EINVAL, "K2 LDS footprint %zu B exceeds the 160 KiB of a CU", auv_k2_lds_bytes(d));
   HIP_TRY(auv_k2_prepare(d));
   HIP_TRY(auv_step_fused_prepare(d));
@@ -1287,6 +1289,24 @@ int auv_step_multi(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, voi
 int auv_set_multi_order(auv_handle_t* h, int32_t order, int32_t lead, int32_t lag) {
   if (!h || order < 0 || order > 1 || lead < 0 || lag < 0 || lead > 4096 || lag > 4096) return fail(AUV_EINVAL, "auv_set_multi_order: order 0 / 1, lead and lag in [0, 4096]");
   h->multi_order = order, h->multi_lead = lead, h->multi_lag = lag;
+  return AUV_OK;
+}
+
+int auv_lidar_stage(auv_handle_t* h, int32_t segments, int32_t* out_segments) {
+  REQUIRE_READY(h);
+  if (segments != 0) {
+    if (segments < 32 || segments > 96 || (segments & 1)) return fail(AUV_EINVAL, "auv_lidar_stage: segments must be 0 (report) or even, 32 .. 96");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());                      // (launches in flight carry the old stage by value: let them end first)
+    AuvDev d = h->d;
+    d.seg_cap = segments;
+    if (!auv_k23_ok(d)) return fail(AUV_EINVAL, "auv_lidar_stage: a %d-segment slice cannot hold the navigation's chunk list", segments);
+    HIP_TRY(auv_k2_prepare(d));
+    HIP_TRY(auv_step_fused_prepare(d));
+    h->d.seg_cap = segments;
+    if (h->fw.on) h->fw.shadow.seg_cap = segments;         // (the refill pass's captured graph keeps the stage it was captured with)
+  }
+  if (out_segments) *out_segments = h->d.seg_cap;
   return AUV_OK;
 }
 

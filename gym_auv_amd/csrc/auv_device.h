@@ -49,6 +49,7 @@ struct AuvDev {
   const int64_t* chunk_off;    // [W+1] offsets into chunk_bound (derived at load time)
   const double4* chunk_bound;  // cx, cy, inflated radius, - : circle around AUV_CHUNK segments
   int32_t nch_max;             // max chunks of any world
+  int32_t seg_cap;             // boundary segments the LiDAR wave stages per batch (<= AUV_SEG_CAP_MAX; picked per bank: k2_lidar.hip)
   const int64_t* knot_off;
   const double* knot_s;
   const double* knot_coef;     // [.][8]

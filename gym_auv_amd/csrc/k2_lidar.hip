@@ -94,8 +94,17 @@ struct MoverSegs {
 };
 
 #ifndef K2_SEG_CAP
-#define K2_SEG_CAP 96    // staged segments per wave and batch (slice <= 10 KiB -> 16 waves per CU)
+#define K2_SEG_CAP 96    // the LARGEST stage: segments per wave and batch (180 beams, 50 obstacles: slice <= 10 KiB -> 16 waves per CU)
 #endif
+#define K2_SEG_CAP_MIN 32
+#ifndef K2_HIT_S
+#define K2_HIT_S 256     // k2_back: most beams whose (index, weight) lists are kept in LDS (Slice::hit_list; else every pass does everything)
+#endif
+// A handle's stage holds d.seg_cap segments, K2_SEG_CAP_MIN <= seg_cap <= K2_SEG_CAP, picked per bank (auv_pick_seg_cap): the
+// largest that leaves the one-launch step its best occupancy.  EVERY role of that launch is charged the sweep's slice, so at 256
+// beams + 47 obstacles + 17 movers a 96-segment stage (12.7 KB) means 12 waves per CU for all of them; a 34-segment one 16:
+// 140.5 -> 162-165 M env-steps/s at 8192 x 256 (profiles/r05/ab_seg_cap_8192x256.jsonl: compile-time 96 / 64 / 32).  Results do not depend on it (a crowded
+// environment's sweep takes more batches; every beam keeps the minimum over all of them).
 #ifndef K2_RAW_CAP
 #define K2_RAW_CAP 192   // boundary segments looked at per batch; only the front-facing ones are staged
 #endif
@@ -108,13 +117,14 @@ struct MoverSegs {
 //   [S] double2 ray vectors | [Mmax] double2 mover cull centre | [S] u64 min-t bits | [Mmax] double
 //   mover width | [Kmax] ObsLds | [CAP] short2 ray span | [Kmax] int active list | [Kmax+1] int
 //   segment prefix | [Kmax] int inside flags | [CAP] u16 owner | [CAP+1] u16 work-item prefix
-__host__ __device__ __forceinline__ size_t k2_slice_bytes(int S, int k_max, int m_max) {
-  size_t b = sizeof(EnvHdr) + (size_t)m_max * 32 + (size_t)K2_SEG_CAP * 32 + (size_t)S * 16 + (size_t)m_max * 16 +
-             (size_t)S * 8 + (size_t)m_max * 8 + (size_t)k_max * sizeof(ObsLds) + (size_t)K2_SEG_CAP * 4 +
-             (size_t)k_max * 4 + (size_t)(k_max + 1) * 4 + (size_t)k_max * 4 + (size_t)K2_SEG_CAP * 2 +
-             (size_t)(K2_SEG_CAP + 2) * 2;
+__host__ __device__ __forceinline__ size_t k2_slice_bytes(int S, int k_max, int m_max, int cap) {
+  size_t b = sizeof(EnvHdr) + (size_t)m_max * 32 + (size_t)cap * 32 + (size_t)S * 16 + (size_t)m_max * 16 +
+             (size_t)S * 8 + (size_t)m_max * 8 + (size_t)k_max * sizeof(ObsLds) + (size_t)cap * 4 +
+             (size_t)k_max * 4 + (size_t)(k_max + 1) * 4 + (size_t)k_max * 4 + (size_t)cap * 2 +
+             (size_t)(cap + 2) * 2;
   return (b + 15) & ~(size_t)15;
 }
+__host__ __device__ __forceinline__ size_t k2_slice_bytes(const AuvDev& d) { return k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max, d.seg_cap); }
 
 struct Slice {
   EnvHdr* hdr;
@@ -131,6 +141,8 @@ struct Slice {
   int* par;
   unsigned short* owner;
   unsigned short* ioff;
+  int cap;        // segments the stage holds (d.seg_cap)
+  int hit_list;   // k2_back: the returns' (index, weight) lists fit the regions that are idle by then
 };
 
 __device__ __forceinline__ MoverSegs mover_segs(const double4 rot, const double wd) {
@@ -139,24 +151,30 @@ __device__ __forceinline__ MoverSegs mover_segs(const double4 rot, const double 
   return ms;
 }
 
-__device__ __forceinline__ Slice carve(unsigned char* p, int S, int k_max, int m_max) {
+__device__ __forceinline__ Slice carve(unsigned char* p, int S, int k_max, int m_max, int cap) {
   Slice s;
   s.hdr = (EnvHdr*)p;
   s.mvrot = (double4*)(s.hdr + 1);
   s.stage = s.mvrot + m_max;
-  s.rayv = (double2*)(s.stage + K2_SEG_CAP);
+  s.rayv = (double2*)(s.stage + cap);
   s.mvcull = s.rayv + S;
   s.dbits = (unsigned long long*)(s.mvcull + m_max);
   s.mvw = (double*)(s.dbits + S);
   s.obs = (ObsLds*)(s.mvw + m_max);
   s.span = (short2*)(s.obs + k_max);
-  s.act = (int*)(s.span + K2_SEG_CAP);
+  s.act = (int*)(s.span + cap);
   s.sbase = s.act + k_max;
   s.par = s.sbase + k_max + 1;
   s.owner = (unsigned short*)(s.par + k_max);
-  s.ioff = s.owner + K2_SEG_CAP;
+  s.ioff = s.owner + cap;
+  s.cap = cap;
+  // k2_back's lists: beam indices (4 B each) over [mvrot, rayv) = the movers' rotations + the stage, weights (8 B each) over
+  // [mvw, end of the slice) = everything behind the beams' distance words -- both idle once the pair sweep is through
+  s.hit_list = S <= K2_HIT_S && 4 * S <= 32 * (m_max + cap) &&
+               8 * (size_t)S <= (size_t)((unsigned char*)(s.ioff + cap + 2) - (unsigned char*)s.mvw);
   return s;
 }
+__device__ __forceinline__ Slice carve(unsigned char* p, const AuvDev& d) { return carve(p, d.cfg.n_sensors, d.k_max, d.m_max, d.seg_cap); }
 
 // exact test of one (ray, boundary segment) pair, sensor.py:140-159; w = (wx, wy, sx, sy) with
 // w = a - p0, s = b - a.  A hit keeps min t on the ray: the reference's distance
@@ -735,7 +753,7 @@ __device__ __forceinline__ void k2_stage_and_pairs(const AuvDev& d, const Slice&
       const unsigned long long kmask = __ballot(keep);
       const int pos = T + __popcll(kmask & ((1ull << lane) - 1ull));
       if (keep) {
-        if (pos < K2_SEG_CAP) {
+        if (pos < L.cap) {
           L.stage[pos] = wv;
           L.owner[pos] = (unsigned short)a;
           L.span[pos] = sp;
@@ -754,7 +772,7 @@ __device__ __forceinline__ void k2_stage_and_pairs(const AuvDev& d, const Slice&
       }
       T += __popcll(kmask);
     }
-    if (T > K2_SEG_CAP) T = K2_SEG_CAP;
+    if (T > L.cap) T = L.cap;
     auv_wave_lds_sync();
     SUB_ADD(c_stage)
     if (!AUV_RUN_L(d, 4)) {
@@ -878,8 +896,6 @@ __device__ __forceinline__ void k2_stage_and_pairs(const AuvDev& d, const Slice&
 // every store issued before it (~0.7 us for a write-through one).  So everything this phase reads from memory -- the beam
 // weights, the per-config constants -- is requested before its first store, the returns take their weights along through
 // LDS, and the cull-limit rows of phase B (`lim0`: this lane's row of the first 64 obstacles) are stored here, not there.
-#define K2_HIT_S 256                   // beams whose (index, weight) list fits the (by now idle) segment stage: 12 B each
-static_assert(K2_HIT_S * 12 <= K2_SEG_CAP * 32, "the returns' list lives in the segment stage");
 template <bool WT = false>
 __device__ __forceinline__ int k2_back(const AuvDev& d, const int e, const int lane, const Slice& L, const int n_act,
                        float* __restrict__ obs_out = nullptr, double* rew_lidar_out = nullptr, const int2* lim0 = nullptr) {
@@ -910,9 +926,9 @@ __device__ __forceinline__ int k2_back(const AuvDev& d, const int e, const int l
   const double px = L.hdr->px, py = L.hdr->py;
   int col = 0;
   double num = 0.0;
-  if (S <= K2_HIT_S) {
-    int* hits = (int*)L.stage;
-    double* hitw = (double*)(hits + K2_HIT_S);
+  if (L.hit_list) {
+    int* hits = (int*)L.mvrot;
+    double* hitw = L.mvw;
     constexpr int NQ = K2_HIT_S / AUV_WAVE;
     double bw[NQ];                                         // gamma_theta from the per-config table
 #pragma unroll
@@ -1015,10 +1031,9 @@ __device__ __forceinline__ int k2_back(const AuvDev& d, const int e, const int l
 __global__ void __launch_bounds__(AUV_BLOCK, 4) k2_lidar(AuvDev d, int advance_movers) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int S = d.cfg.n_sensors;
   const int e = auv_uniform(blockIdx.x * AUV_ENVS_PER_BLOCK + wave);
   if (e >= d.n) return;
-  const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
+  const Slice L = carve(smem + wave * k2_slice_bytes(d), d);
   AUV_STAMP_DECL
 #ifdef AUV_STAMPS
   const unsigned long long t_real0 = wall_clock64();
@@ -1041,9 +1056,8 @@ __global__ void __launch_bounds__(AUV_BLOCK, 4) k2_lidar(AuvDev d, int advance_m
 __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = threadIdx.x / AUV_WAVE, lane = threadIdx.x % AUV_WAVE;
-  const int S = d.cfg.n_sensors;
   const int nf = *d.fresh_count;
-  const Slice L = carve(smem + wave * k2_slice_bytes(S, d.k_max, d.m_max), S, d.k_max, d.m_max);
+  const Slice L = carve(smem + wave * k2_slice_bytes(d), d);
   for (int i = blockIdx.x * AUV_ENVS_PER_BLOCK + wave; i < nf; i += gridDim.x * AUV_ENVS_PER_BLOCK) {
     const int e = auv_uniform(d.fresh_list[i]);
     const int n_act = k2_front(d, e, lane, L, 0);
@@ -1061,7 +1075,7 @@ __global__ void __launch_bounds__(AUV_BLOCK) k2_lidar_fresh(AuvDev d) {
 
 #ifndef AUV_DEVICE_FUNCS_ONLY
 size_t auv_k2_lds_bytes(const AuvDev& d) {
-  return k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max) * AUV_ENVS_PER_BLOCK;
+  return k2_slice_bytes(d) * AUV_ENVS_PER_BLOCK;
 }
 
 // gfx950 has 160 KiB of LDS per CU; footprints above the 64 KiB default need the opt-in.

@@ -105,7 +105,6 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
   const AuvDev& d = dk;
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
-  const int S = d.cfg.n_sensors;
   const int ne = d.ne;
   if ((int)blockIdx.x >= ne) {
     const int el = (int)blockIdx.x - ne;
@@ -125,7 +124,7 @@ __global__ void __launch_bounds__(AUV_BLOCK, AUV_K23_MIN_WAVES) k23_lidar_nav(Au
     // covers a slice [e0, e0 + ne) and keeps a ring position of its own (`e == 0` left the chains with e0 > 0
     // on slot 0 for good when a captured chain stepped in this shape)
     if (e == d.e0 && lane == 0 && dk.ring_slots > 1 && dk.ring_slot_host == -1) *dk.ring_pos = (*dk.ring_pos + 1) % dk.ring_slots;
-    const Slice L = carve(smem, S, d.k_max, d.m_max);
+    const Slice L = carve(smem, d);
     AUV_STAMP_DECL
 #ifdef AUV_STAMPS
     const unsigned long long t_real0 = wall_clock64();
@@ -441,7 +440,6 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
   const AuvDev& d = dk;
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
-  const int S = d.cfg.n_sensors;
   const int ne = d.ne;                                              // environments of this launch: [e0, e0 + ne)
   const int nk = 8 * ((ne + 63) / 64);                              // dynamics workgroups
   const int nb = 8 * ((ne + 7) / 8);                                // LiDAR workgroups
@@ -520,7 +518,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
     ed = d.env_desc[e];
     pre.cnt = d.counters[e];                               // t_step, episodes; the step counter comes with the state
     pre.ed = &ed;
-    const Slice L = carve(smem, S, d.k_max, d.m_max);
+    const Slice L = carve(smem, d);
     k2_movers<true>(d, e, lane, L, ed, 1);
     const K2Pre kp = k2_prefetch(d, e, lane, ed);
     k2_stage_beams(d, lane, L);
@@ -871,7 +869,6 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
   const AuvDev& d = dk;
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
-  const int S = d.cfg.n_sensors;
   const int ne = d.ne;
   const int nk = 8 * ((ne + 63) / 64), nb = 8 * ((ne + 7) / 8);
   const int per = 2 * nk + 2 * nb;
@@ -961,7 +958,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     if (bi >= ne) return;
     const int e = auv_uniform(d.e0 + bi);
     if (auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
-    const Slice L = carve(smem, S, d.k_max, d.m_max);
+    const Slice L = carve(smem, d);
     K2Pre kp;
     if (step == 0) {
       ed = d.env_desc[e];
@@ -1169,12 +1166,12 @@ void auv_launch_k31(const AuvDev& d0, const void* actions, int dtype, float* obs
 }
 
 // the navigation role keeps its chunk list at the start of the wave's slice
-bool auv_k23_ok(const AuvDev& d) { return NAV_SCRATCH_BYTES(d.nch_max) <= k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
+bool auv_k23_ok(const AuvDev& d) { return NAV_SCRATCH_BYTES(d.nch_max) <= k2_slice_bytes(d); }
 
 // K2 + K3-nav side by side: ONE wave per workgroup, so a wave slot is handed on the moment an environment's sweep
 // ends -- the navigation workgroups queued behind the LiDAR ones start (and end) earlier.
 void auv_launch_k23(const AuvDev& d, float* obs, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-  const size_t lds = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const size_t lds = k2_slice_bytes(d);
   hipExtLaunchKernelGGL(k23_lidar_nav, dim3(2 * d.ne), dim3(AUV_WAVE), (uint32_t)lds, st, ev0, ev1, 0, d, obs);
 }
 
@@ -1185,7 +1182,7 @@ void auv_launch_step_roles(const AuvDev& d0, const void* actions, int dtype, flo
                            hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   AuvDev d = d0;
   d.act_f64 = dtype == AUV_F64;
-  const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const uint32_t lds = (uint32_t)k2_slice_bytes(d);
   const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
   const dim3 grid(nk + 2 * nb + AUV_HOOK_SKEW(d) + nk), block(AUV_WAVE);
   hipExtLaunchKernelGGL(k_step_roles, grid, block, lds, st, ev0, ev1, 0, d, actions, obs, reward, done);
@@ -1197,7 +1194,7 @@ void auv_launch_step_multi(const AuvDev& d0, const void* actions, int dtype, flo
   AuvDev d = d0;
   d.act_f64 = dtype == AUV_F64;
   d.ring_slots = 1;
-  const uint32_t lds = (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const uint32_t lds = (uint32_t)k2_slice_bytes(d);
   const int nk = 8 * ((d.ne + 63) / 64), nb = 8 * ((d.ne + 7) / 8);
   const int C = nk / 8;
   if (order == 1 && C >= 3 && d.ne % 64 == 0) {
@@ -1217,10 +1214,26 @@ void auv_launch_step_multi(const AuvDev& d0, const void* actions, int dtype, flo
   hipLaunchKernelGGL(k_step_multi, grid, block, lds, st, d, actions, obs, reward, done, n_steps, first_slot, n_slots, seq0, -1, 0, 0u);
 }
 
-uint32_t auv_step_lds_bytes(const AuvDev& d) { return (uint32_t)k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max); }
+// The stage's capacity for a bank (S, k_max, m_max known): the largest that gives the one-launch step its best occupancy (see
+// k2_lidar.hip) and still leaves room for the search role's chunk list; asked of the runtime, not computed (allocation granule).
+int auv_pick_seg_cap(const AuvDev& d0) {
+  AuvDev d = d0;
+  int best = K2_SEG_CAP, best_occ = -1;
+  for (int cap = K2_SEG_CAP; cap >= K2_SEG_CAP_MIN; cap -= 2) {
+    d.seg_cap = cap;
+    const size_t b = k2_slice_bytes(d);
+    if (b < NAV_SCRATCH_BYTES(d.nch_max)) break;
+    int occ = 0;
+    if (b > 64 * 1024 || hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_step_roles, AUV_WAVE, b) != hipSuccess) occ = 0;
+    if (occ > best_occ) best_occ = occ, best = cap;
+  }
+  return best;
+}
+
+uint32_t auv_step_lds_bytes(const AuvDev& d) { return (uint32_t)k2_slice_bytes(d); }
 
 hipError_t auv_step_fused_prepare(const AuvDev& d) {
-  const size_t b = k2_slice_bytes(d.cfg.n_sensors, d.k_max, d.m_max);
+  const size_t b = k2_slice_bytes(d);
   if (b <= 64 * 1024) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)k23_lidar_nav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
   if (e != hipSuccess) return e;

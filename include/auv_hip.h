@@ -201,6 +201,13 @@ int auv_step_multi(auv_handle_t* h, int32_t n_slices, const int32_t* bounds, voi
  * holding a wave slot while it polls; lead + lag are cut down to (cohorts of the slice) - 1, which keeps every producer ahead of its
  * consumer in dispatch order; slices that are not a multiple of 64 environments, or of fewer than 3 cohorts, use order 0.      */
 int auv_set_multi_order(auv_handle_t* h, int32_t order, int32_t lead, int32_t lag);
+/* How many obstacle boundary segments the LiDAR wave stages in LDS per batch of its pair sweep (sensor.py:140-159 is evaluated per
+ * (segment, ray) pair; a crowded environment takes several batches).  Picked when a bank is loaded or generated: the largest of
+ * 32 .. 96 that leaves the one-launch step its best occupancy -- every role of that launch is charged the sweep's LDS slice, so at
+ * 256 beams + 47 obstacles + 17 movers a 96-segment stage (12.7 KB) means 12 waves per CU, a 34-segment one 16.  Results do not
+ * depend on it (tested bit for bit).  segments = 0: only report; 32 .. 96 (even): override (a new bank picks again; graphs captured
+ * before keep the stage they were captured with).  *out_segments (may be NULL) <- the value in force.              */
+int auv_lidar_stage(auv_handle_t* h, int32_t segments, int32_t* out_segments);
 
 /* VecEnv.step_async / step_wait (scripts/run.py:293-296: SubprocVecEnv sends the actions to its workers and collects their
  * results) with the ordering between the caller's stream and the chains done INSIDE the library, one call each:
