@@ -142,7 +142,8 @@ struct Slice {
   unsigned short* owner;
   unsigned short* ioff;
   int cap;        // segments the stage holds (d.seg_cap)
-  int hit_list;   // k2_back: the returns' (index, weight) lists fit the regions that are idle by then
+  int* hits;      // k2_back: the returns' beam indices and weights, in regions that are idle by then (nullptr: they do not fit --
+  double* hitw;   // every pass of k2_back then does everything)
 };
 
 __device__ __forceinline__ MoverSegs mover_segs(const double4 rot, const double wd) {
@@ -168,10 +169,14 @@ __device__ __forceinline__ Slice carve(unsigned char* p, int S, int k_max, int m
   s.owner = (unsigned short*)(s.par + k_max);
   s.ioff = s.owner + cap;
   s.cap = cap;
-  // k2_back's lists: beam indices (4 B each) over [mvrot, rayv) = the movers' rotations + the stage, weights (8 B each) over
-  // [mvw, end of the slice) = everything behind the beams' distance words -- both idle once the pair sweep is through
-  s.hit_list = S <= K2_HIT_S && 4 * S <= 32 * (m_max + cap) &&
-               8 * (size_t)S <= (size_t)((unsigned char*)(s.ioff + cap + 2) - (unsigned char*)s.mvw);
+  // k2_back's lists, 4 B of beam index + 8 B of weight per beam, in what is idle once the pair sweep is through: both in
+  // R1 = [mvrot, rayv) = the movers' rotations + the stage if they fit there, else the indices in R1 and the weights in
+  // R2 = [mvw, end of the slice) = everything behind the beams' distance words
+  const size_t r1 = 32 * (size_t)(m_max + cap), r2 = (size_t)((unsigned char*)(s.ioff + cap + 2) - (unsigned char*)s.mvw);
+  const size_t hb = ((size_t)4 * S + 7) & ~(size_t)7;
+  s.hits = nullptr, s.hitw = nullptr;
+  if (S <= K2_HIT_S && hb + (size_t)8 * S <= r1) s.hits = (int*)s.mvrot, s.hitw = (double*)((unsigned char*)s.mvrot + hb);
+  else if (S <= K2_HIT_S && hb <= r1 && (size_t)8 * S <= r2) s.hits = (int*)s.mvrot, s.hitw = s.mvw;
   return s;
 }
 __device__ __forceinline__ Slice carve(unsigned char* p, const AuvDev& d) { return carve(p, d.cfg.n_sensors, d.k_max, d.m_max, d.seg_cap); }
@@ -926,9 +931,9 @@ __device__ __forceinline__ int k2_back(const AuvDev& d, const int e, const int l
   const double px = L.hdr->px, py = L.hdr->py;
   int col = 0;
   double num = 0.0;
-  if (L.hit_list) {
-    int* hits = (int*)L.mvrot;
-    double* hitw = L.mvw;
+  if (L.hits) {
+    int* hits = L.hits;
+    double* hitw = L.hitw;
     constexpr int NQ = K2_HIT_S / AUV_WAVE;
     double bw[NQ];                                         // gamma_theta from the per-config table
 #pragma unroll

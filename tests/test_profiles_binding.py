@@ -1,5 +1,5 @@
 """CPU: the committed counter passes are tied to a binary.  profiles/pmc_sq.json and
-profiles/pmc_traffic.json carry, per "<workload>/sub<K>" entry, the sha256 of the libauv_hip.so they were measured on;
+profiles/pmc_traffic.json carry, per "<workload>/sub<K>[_T<steps per launch>]" entry, the sha256 of the libauv_hip.so they were measured on;
 bench.py hashes the library it runs and marks a leg `stale` when the two differ.  Here: the files have that shape, the
 hash function hashes the in-tree library, and -- informational, printed, not asserted, so that a kernel change does not
 turn the suite red before the next profile run -- whether the committed passes belong to the library as built now."""
@@ -34,7 +34,9 @@ def test_counter_files_carry_the_library_hash_and_bench_hashes_the_library():
         entries = {k: v for k, v in doc.items() if k != "_note"}
         assert "polygons50/sub4" in entries and "polygons50/sub1" in entries, name
         for key, e in entries.items():
-            assert "/sub" in key and len(e["lib_sha256"]) == 64 and e["launches_per_step"] == int(key.split("/sub")[1]), (name, key)
+            # "<workload>/sub<K>": K one-step launches per step; "<workload>/sub<K>_T<T>": K chains of T steps per launch
+            k, _, t = key.split("/sub")[1].partition("_T")
+            assert "/sub" in key and len(e["lib_sha256"]) == 64 and abs(e["launches_per_step"] - int(k) / float(t or 1)) < 1e-9, (name, key)
             assert all(k in e for k in need), (name, key)
             assert os.path.exists(os.path.join(ROOT, e["profile"])), e["profile"]
             print("%s [%s]: measured on %s... -> %s" % (name, key, e["lib_sha256"][:12], "current build" if e["lib_sha256"] == sha else "STALE for the current build"))
