@@ -678,11 +678,21 @@ def main():
             if env._slices is None:
                 env.set_sub_batches(1, inline_first=True)
             comparison["step_async_wait_%s_sub%d" % (env.rendezvous, env.sub_batches)] = rate(loop_async)
-        if sub > 1:
+        # the chains of one-step launches and the policy-in-the-loop figure below on FOUR chains also when the timed loop ran one
+        # chain of several steps per launch (the driver's record then carries both)
+        k_cmp = sub
+        if sub == 1 and not fresh and n_local >= 2048 and env.effective_step_mode(n_local // 4) == "one_launch":
+            k_cmp = 4
+        if k_cmp > 1:
             def loop_pipe(n):
                 for i in range(n):
                     env.step_pipelined(pool[i % n_pool])
-            comparison["pipelined_sub%d" % sub] = rate(loop_pipe)
+            try:
+                if env._slices is None or env.sub_batches != k_cmp:
+                    env.set_sub_batches(k_cmp, probe_streams=True)
+                comparison["pipelined_sub%d" % env.sub_batches] = rate(loop_pipe)
+            except Exception as exc:
+                comparison["pipelined_error"] = repr(exc)[:200]
         if not fresh and n_local % 64 == 0 and env.effective_step_mode(n_local) == "one_launch":
             # the sustained open-loop rate with 64 steps per launch on one chain, whatever the timed loop above was (the driver's
             # 20-step window cannot show it): 640 steps after 128 of warm-up, outside the timed region
@@ -697,8 +707,8 @@ def main():
                     env.step_multi(pool, (64 * j) % n_pool, 64)
                 torch.cuda.synchronize(dev)
                 comparison["open_loop_multi_T64_sub1"] = round(n_local * 640 / (time.perf_counter() - t1), 1)
-                if sub > 1:
-                    env.set_sub_batches(sub, probe_streams=True)
+                if k_cmp > 1:
+                    env.set_sub_batches(k_cmp, probe_streams=True)
             except Exception as exc:
                 comparison["open_loop_multi_error"] = repr(exc)[:200]
         # the closed loop a PPO run lives in (scripts/run.py:332-357: MlpPolicy [256, 128, 64] for policy and value): the fused

@@ -298,7 +298,7 @@ static int finish_bank(auv_handle* h, bool alloc_env) {
   rc |= dev_alloc(ep, &d.k1_done, AUV_MAX_CHAINS);      // (one per captured chain)
   rc |= dev_alloc(ep, &d.fresh_count, 4);
   rc |= dev_alloc(ep, &d.fresh_list, n);
-  rc |= dev_alloc(ep, &d.stamps, n * 16);
+  rc |= dev_alloc(ep, &d.stamps, n * AUV_STAMP_WORDS);
   rc |= dev_alloc(ep, &d.ring_pos, AUV_MAX_CHAINS);     // (one per captured chain)
   rc |= dev_alloc(ep, &d.rew_path, n);
   rc |= dev_alloc(ep, &d.rew_lidar, n);

@@ -184,6 +184,12 @@ struct EnvPre {
 #define AUV_RUN_N(d, n) true
 #endif
 
+// words of `stamps` per environment (-DAUV_STAMPS_MULTI: a second half, where the steps of a multi-step launch that are not looked at put theirs)
+#ifdef AUV_STAMPS_MULTI
+#define AUV_STAMP_WORDS 32
+#else
+#define AUV_STAMP_WORDS 16
+#endif
 // In-kernel phase stamps (diagnostic build only: make STAMPS=1).  The stamp values leave the
 // kernel through `stamps` alone; no output is computed from them.
 #ifdef AUV_STAMPS

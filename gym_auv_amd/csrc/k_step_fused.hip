@@ -617,6 +617,23 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 // tables may be rebuilt beside the launch, and only the binding launch reads them coherently.
 #define CARRY_WORDS 24
 
+// Diagnostic build only (-DAUV_STAMPS_MULTI, tools/multi_stamps.py): wall-clock stamps of the waves of ONE step in the middle of a
+// multi-step launch (the other steps stamp into a dummy half of the array), 16 words per environment:
+//   sweep wave   0 has its slot  1 carry record here  2 state packet here  3 front done  4 pair sweep done  5 word published
+//   search wave  6 has its slot  7 carry record here  8 state packet here  9 record published
+//   dynamics    10 has its slot 11 carry record here 12 packet stored      finish 13 has its slot 14 sweeps' words here 15 done
+#ifdef AUV_STAMPS_MULTI
+#define MSTAMP(e, k) do { if (lane == 0) stamp[(size_t)(e) * 16 + (k)] = wall_clock64(); } while (0)
+#define MSTAMP_IF(cond, e, k) do { if (cond) stamp[(size_t)(e) * 16 + (k)] = wall_clock64(); } while (0)
+#define MSTAMP_PARAM , unsigned long long* stamp
+#define MSTAMP_ARG , stamp
+#else
+#define MSTAMP(e, k) do { } while (0)
+#define MSTAMP_IF(cond, e, k) do { } while (0)
+#define MSTAMP_PARAM
+#define MSTAMP_ARG
+#endif
+
 __device__ __forceinline__ unsigned long long carry_ed_word(const EnvDesc& ed, const int i) {
   switch (i) {
     case 0: return (unsigned long long)ed.k0;
@@ -671,7 +688,7 @@ __device__ __forceinline__ int carry_wait_wave(const AuvDev& d, const int e, con
 template <bool MULTI>
 __device__ __forceinline__ void roles_finish_wave_multi(const AuvDev& dk, const int f, const int lane, float* __restrict__ obs_out,
                                                         float* __restrict__ reward_out, uint8_t* __restrict__ done_out, const int step,
-                                                        const bool last_step, const unsigned long long tagmix, const unsigned long long tagmix_prev) {
+                                                        const bool last_step, const unsigned long long tagmix, const unsigned long long tagmix_prev MSTAMP_PARAM) {
   // (roles_finish_wave with the previous step's outcome from the carry record instead of the arrays, and its own outcome into
   // the record at the end; the arithmetic in between is the very same code)
   const __attribute__((address_space(4))) AuvDev* dc = (const __attribute__((address_space(4))) AuvDev*)dk.self;
@@ -798,6 +815,7 @@ __device__ __forceinline__ void roles_finish_wave_multi(const AuvDev& dk, const 
     }
     __builtin_amdgcn_s_sleep(ROLES_POLL_SLEEP);
   }
+  MSTAMP_IF(live && c == 0, e, 14);
   int do_reset = 0;
   double co[2] = {0.0, 0.0};
   if (live && c == 0) {
@@ -903,6 +921,9 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
   int role = auv_uniform(cohorts ? role_c : role_a), bi = auv_uniform(cohorts ? bi_c : bi_a);
   if (step >= n_steps) return;
   const unsigned long long tagmix = roles_tagmix(seq0 + (unsigned long long)step + 1ull), tagmix_prev = roles_tagmix(seq0 + (unsigned long long)step);
+#ifdef AUV_STAMPS_MULTI
+  unsigned long long* const stamp = d.stamps + (step == n_steps / 2 ? (size_t)0 : (size_t)16 * (size_t)d.n);
+#endif
   if (role == 0) {
     // ---- Vessel.step of eight environments ----
     if (bi >= nk) return;
@@ -914,6 +935,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     const int eg = d.e0 + (live ? er : ne - 1);
     int y, gave_up = 0;
     double y0 = 0.0;
+    MSTAMP_IF(live && c == 0, eg, 10);
     if (step == 0) {
       y = d.counters[eg].y + 1;
     } else {
@@ -942,6 +964,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     }
     const int aborted = gave_up | auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     double t = 0.0;
+    MSTAMP_IF(live && c == 0, eg, 11);
     if (!aborted) t = k1_group(d, actions, eg, lane, step == 0 ? nullptr : &y0, (first_slot + step) % n_slots);
     unsigned long long* pk = d.k1_pkt + 8 * (size_t)eg;
     const unsigned long long word = aborted ? (c == 6 ? (unsigned long long)ROLES_ABORT_COUNTER : 0ull)
@@ -949,6 +972,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     const unsigned long long mark = roles_mark(roles_group_xor(word) ^ tagmix);
     if (live && !(AUV_HOOK_FAULT(d) == 2 && eg == d.e0 && step == 0))
       __hip_atomic_store(pk + c, c < 7 ? word : mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    MSTAMP_IF(live && c == 0, eg, 12);
     return;
   }
   EnvPre pre;
@@ -960,14 +984,17 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     if (auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
     const Slice L = carve(smem, d);
     K2Pre kp;
+    MSTAMP(e, 0);
     if (step == 0) {
       ed = d.env_desc[e];
       pre.cnt = d.counters[e];
       pre.ed = &ed;
+      MSTAMP(e, 1);
       k2_movers<true>(d, e, lane, L, ed, 1);
       kp = k2_prefetch(d, e, lane, ed);
     } else {
       if (carry_wait_wave(d, e, lane, tagmix_prev, ed, pre.cnt)) return;
+      MSTAMP(e, 1);
       pre.ed = &ed;
       k2_movers<true, true>(d, e, lane, L, ed, 1);
       kp = k2_prefetch<true>(d, e, lane, ed);
@@ -980,36 +1007,50 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
         return;
       }
     }
+    MSTAMP(e, 2);
     int2 lim0 = make_int2(INT32_MIN, INT32_MIN);
     const int n_act = k2_front<true>(d, e, lane, L, 1, &pre, 1, &kp, true, &lim0);
+    MSTAMP(e, 3);
     k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
+    MSTAMP(e, 4);
     double term = 0.0;
     const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term, &lim0);
     pair_publish_lidar(d, e, lane, collision, term);
+    MSTAMP(e, 5);
   } else if (role == 2) {
     // ---- Vessel.navigate of one environment: the nearest-point search ----
     const int el = bi;
     if (el >= ne) return;
     const int e = auv_uniform(d.e0 + el);
+    MSTAMP(e, 6);
     if (step == 0) {
       ed = d.env_desc[e];
       pre.cnt = d.counters[e];
     } else if (carry_wait_wave(d, e, lane, tagmix_prev, ed, pre.cnt)) {
       return;
     }
+    MSTAMP(e, 7);
     pre.ed = &ed;
     if (roles_wait_state(d, e, lane, pre, tagmix)) return;
+    MSTAMP(e, 8);
     NavNear nr;
     int* list = (int*)smem;
     const NavSpec sp = nav_bounds(d, e, lane, list, pre.s[0], pre.s[1], &ed);
     nr = nav_nearest(d, e, lane, list, pre.s[0], pre.s[1], sp);
     roles_publish_search(d, e, lane, nr, tagmix);
+    MSTAMP(e, 9);
   } else {
     // ---- navigation tail + reward / done / auto-reset of eight environments ----
     const int f = bi;
     if (f >= nk) return;
     __builtin_amdgcn_s_setprio(2);
-    roles_finish_wave_multi<true>(d, f, lane, obs_out, reward_out, done_out, step, step == n_steps - 1, tagmix, tagmix_prev);
+#ifdef AUV_STAMPS_MULTI
+    const int fer = 8 * (8 * (f / 8) + lane / K1_GROUP) + (f % 8);
+    const bool fst = fer < ne && lane % K1_GROUP == 0;
+#endif
+    MSTAMP_IF(fst, d.e0 + fer, 13);
+    roles_finish_wave_multi<true>(d, f, lane, obs_out, reward_out, done_out, step, step == n_steps - 1, tagmix, tagmix_prev MSTAMP_ARG);
+    MSTAMP_IF(fst, d.e0 + fer, 15);
   }
 }
 
