@@ -76,7 +76,7 @@ def parse():
                          "bit-identical to T single-step launches).  1: one launch per step and chain.  -1 (default): 64 on ONE chain where the "
                          "loop is open (api pipelined, resident actions, no fresh worlds, no graph) and --steps >= 256, else 1")
     ap.add_argument("--multi-order", default="cohorts", choices=["cohorts", "steps"], help="--multi: workgroup order of a launch (include/auv_hip.h, auv_set_multi_order)")
-    ap.add_argument("--multi-lead", type=int, default=12)
+    ap.add_argument("--multi-lead", type=int, default=16)
     ap.add_argument("--multi-lag", type=int, default=30)
     ap.add_argument("--graph", type=int, default=0,
                     help="0 (default): eager launches; K > 0: K consecutive steps captured in ONE hipGraph over the action "

@@ -302,7 +302,7 @@ class BatchedAuvEnv:
                                    int(ring.shape[0]), int(first_slot), int(n_steps), C.c_void_p(self.obs.data_ptr()),
                                    C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr())), "auv_step_multi")
 
-    def set_multi_order(self, order: str = "cohorts", lead: int = 12, lag: int = 30):
+    def set_multi_order(self, order: str = "cohorts", lead: int = 16, lag: int = 30):
         """Workgroup order of step_multi's launches: "cohorts" (default: cohort-pipelined, see include/auv_hip.h) or "steps"."""
         _check(_LIB.auv_set_multi_order(self._h, {"steps": 0, "cohorts": 1}[order], int(lead), int(lag)), "auv_set_multi_order")
 

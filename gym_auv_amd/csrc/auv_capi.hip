@@ -111,7 +111,7 @@ struct auv_handle {
   std::vector<int32_t> chain_bounds;       // the slices of the captured chains
   int chain_steps = 1, graph_steps = 1;    // steps per replay of the captured chains / of the one graph
   unsigned long long multi_seq = 0;        // auv_step_multi: step numbers handed out so far (every mark of a step carries its number)
-  int multi_order = 1, multi_lead = 12, multi_lag = 30;   // auv_set_multi_order: workgroup order of a launch of several steps
+  int multi_order = 1, multi_lead = 16, multi_lag = 30;   // auv_set_multi_order: workgroup order of a launch of several steps
   // on-device generation (auv_generate_worlds): shape of the slot bank, 0 = packed upload
   int gen_worlds, gen_moving, gen_static, gen_grid;
   GenOut gen;

@@ -188,14 +188,16 @@ template <int K> __device__ __forceinline__ int k1_group_bcast32(const int x) {
 template <int K> __device__ __forceinline__ double k1_group_bcast(const double t) {
   return __hiloint2double(k1_group_bcast32<K>(__double2hiint(t)), k1_group_bcast32<K>(__double2loint(t)));
 }
-// `y_in` (nullable): component c of the state to start from, in the lane that owns it (else the STATE rows); `slot`: see k1_action
+// `y_in` (nullable): component c of the state to start from, in the lane that owns it (else the STATE rows); `slot`: see k1_action;
+// `a_in` (nullable): the action, fetched by the caller already (k1_action)
 __device__ __forceinline__ double k1_group(const AuvDev& d, const void* __restrict__ actions, const int e, const int lane,
-                                           const double* y_in = nullptr, const int slot = -1) {
+                                           const double* y_in = nullptr, const int slot = -1, const double2* a_in = nullptr) {
   const int c = lane % K1_GROUP, gbase = lane - c;
   const size_t n = (size_t)d.n;
   const bool own = c < 6;
   double a0, a1;
-  k1_action(d, actions, e, &a0, &a1, slot);
+  if (a_in) a0 = a_in->x, a1 = a_in->y;
+  else k1_action(d, actions, e, &a0, &a1, slot);
   if (isnan(a0) || isnan(a1)) a0 = a1 = 0.0;
   const double tu = auv_clip(a0, 0.0, 1.0) * d.cfg.thrust_max;
   const double tr = auv_clip(a1, -1.0, 1.0) * d.cfg.moment_max;

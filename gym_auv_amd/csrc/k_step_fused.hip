@@ -211,14 +211,19 @@ __device__ __forceinline__ unsigned long long roles_lane_word(const unsigned lon
 // `tagmix`: 0 for a launch of one step; a launch of several steps mixes the step's number into every mark (roles_tagmix), so
 // that a wave of step t + 1 that starts early cannot take step t's packet -- still up -- for its own
 __device__ __forceinline__ unsigned long long roles_tagmix(const unsigned long long tag) { return tag * 0xd6e8feb86659fd93ull; }
-__device__ __forceinline__ int roles_wait_state(const AuvDev& d, const int e, const int lane, EnvPre& pre, const unsigned long long tagmix = 0ull) {
+// `have_first`: the caller has requested the packet already (`v_first`: its lane's word), ahead of other work -- in a launch of
+// several steps the packet is usually there when the wave starts, and a wave that asks for it only HERE holds its slot for one more
+// trip to memory (~1 us of a 12 us sweep: tools/multi_stamps.py); a packet of another step fails the mark and is polled for as ever
+__device__ __forceinline__ int roles_wait_state(const AuvDev& d, const int e, const int lane, EnvPre& pre, const unsigned long long tagmix = 0ull,
+                                                const bool have_first = false, const unsigned long long v_first = 0ull) {
   const unsigned long long* pk = d.k1_pkt + 8 * (size_t)e;
   // (polling harder does not pay: with two requests in flight per wave the packet is noticed sooner, but the
   // traffic of 3500 polling waves slows the dynamics role down by more -- 102.3 M against 104.7 M env-steps/s;
   // keeping the early waves quiet until the dynamics are about due moved every workload by +-2 % in no pattern)
   unsigned long long v = 0;
   for (int polls = 0;; polls++) {
-    v = __hip_atomic_load(pk + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one 64-byte request per wave
+    if (have_first && polls == 0) v = v_first;
+    else v = __hip_atomic_load(pk + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one 64-byte request per wave
     const unsigned long long got = roles_lane_word(v, 7);
     if (got != 0ull) {
       unsigned long long x = roles_lane_word(v, 0);
@@ -936,6 +941,10 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     int y, gave_up = 0;
     double y0 = 0.0;
     MSTAMP_IF(live && c == 0, eg, 10);
+    // requested ahead of the wait for the carry record (this wave is on every environment's critical path): the flag and the action
+    const int ab_early = __hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double act0, act1;
+    k1_action(d, actions, eg, &act0, &act1, (first_slot + step) % n_slots);
     if (step == 0) {
       y = d.counters[eg].y + 1;
     } else {
@@ -962,10 +971,11 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
       y0 = __longlong_as_double((long long)v);
       y = (int)(unsigned)(roles_group_word(v, 6) >> 32) + 1;
     }
-    const int aborted = gave_up | auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int aborted = gave_up | auv_uniform(ab_early);
     double t = 0.0;
     MSTAMP_IF(live && c == 0, eg, 11);
-    if (!aborted) t = k1_group(d, actions, eg, lane, step == 0 ? nullptr : &y0, (first_slot + step) % n_slots);
+    const double2 act = make_double2(act0, act1);
+    if (!aborted) t = k1_group(d, actions, eg, lane, step == 0 ? nullptr : &y0, (first_slot + step) % n_slots, &act);
     unsigned long long* pk = d.k1_pkt + 8 * (size_t)eg;
     const unsigned long long word = aborted ? (c == 6 ? (unsigned long long)ROLES_ABORT_COUNTER : 0ull)
                                             : (c < 6 ? (unsigned long long)__double_as_longlong(t) : (c == 6 ? (unsigned long long)(unsigned)y : 0ull));
@@ -981,19 +991,24 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     // ---- _update + Vessel.perceive of one environment ----
     if (bi >= ne) return;
     const int e = auv_uniform(d.e0 + bi);
-    if (auv_uniform(__hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+    MSTAMP(e, 0);
+    // three requests in flight before the first wait: the abort flag, this step's state packet (dispatched `lead` cohorts behind
+    // its dynamics, the wave usually finds it there), the carry record
+    const int ab_early = __hip_atomic_load(d.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long pk_first = __hip_atomic_load(d.k1_pkt + 8 * (size_t)e + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const Slice L = carve(smem, d);
     K2Pre kp;
-    MSTAMP(e, 0);
     if (step == 0) {
       ed = d.env_desc[e];
       pre.cnt = d.counters[e];
       pre.ed = &ed;
+      if (auv_uniform(ab_early)) return;
       MSTAMP(e, 1);
       k2_movers<true>(d, e, lane, L, ed, 1);
       kp = k2_prefetch(d, e, lane, ed);
     } else {
       if (carry_wait_wave(d, e, lane, tagmix_prev, ed, pre.cnt)) return;
+      if (auv_uniform(ab_early)) return;
       MSTAMP(e, 1);
       pre.ed = &ed;
       k2_movers<true, true>(d, e, lane, L, ed, 1);
@@ -1001,7 +1016,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     }
     k2_stage_beams(d, lane, L);
     {
-      const int ws = roles_wait_state(d, e, lane, pre, tagmix);
+      const int ws = roles_wait_state(d, e, lane, pre, tagmix, true, pk_first);
       if (ws) {
         if (ws == 2 && ed.M > 0 && lane == 0) auv_st<true>(d.broken + e, (uint8_t)1);
         return;
@@ -1023,6 +1038,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     if (el >= ne) return;
     const int e = auv_uniform(d.e0 + el);
     MSTAMP(e, 6);
+    const unsigned long long pk_first = __hip_atomic_load(d.k1_pkt + 8 * (size_t)e + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (step == 0) {
       ed = d.env_desc[e];
       pre.cnt = d.counters[e];
@@ -1031,7 +1047,7 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     }
     MSTAMP(e, 7);
     pre.ed = &ed;
-    if (roles_wait_state(d, e, lane, pre, tagmix)) return;
+    if (roles_wait_state(d, e, lane, pre, tagmix, true, pk_first)) return;
     MSTAMP(e, 8);
     NavNear nr;
     int* list = (int*)smem;

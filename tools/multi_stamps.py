@@ -18,7 +18,7 @@ from gym_auv_amd.config import effective_reference_config
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "polygons50"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-lead = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+lead = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 lag = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 cfg = effective_reference_config(use_lidar=True)
 if wl == "mixed47":
