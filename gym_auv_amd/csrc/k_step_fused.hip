@@ -624,8 +624,8 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_roles(AuvD
 
 // Diagnostic build only (-DAUV_STAMPS_MULTI, tools/multi_stamps.py): wall-clock stamps of the waves of ONE step in the middle of a
 // multi-step launch (the other steps stamp into a dummy half of the array), 16 words per environment:
-//   sweep wave   0 has its slot  1 carry record here  2 state packet here  3 front done  4 pair sweep done  5 word published
-//   search wave  6 has its slot  7 carry record here  8 state packet here  9 record published
+//   sweep wave   0 role begins  1 the wave's first instruction  2 state packet here  3 all its stores acknowledged  4 pair sweep done  5 word published
+//   search wave  6 role begins  7 the wave's first instruction  8 state packet here  9 record published
 //   dynamics    10 has its slot 11 carry record here 12 packet stored      finish 13 has its slot 14 sweeps' words here 15 done
 #ifdef AUV_STAMPS_MULTI
 #define MSTAMP(e, k) do { if (lane == 0) stamp[(size_t)(e) * 16 + (k)] = wall_clock64(); } while (0)
@@ -891,6 +891,9 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
                                                                            const unsigned long long seq0, const int lead_dyn, const int lag_fin, const unsigned magic_c) {
   const AuvDev& d = dk;
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef AUV_STAMPS_MULTI
+  const unsigned long long t_entry = wall_clock64();      // the wave's first instruction
+#endif
   const int lane = threadIdx.x;
   const int ne = d.ne;
   const int nk = 8 * ((ne + 63) / 64), nb = 8 * ((ne + 7) / 8);
@@ -1003,13 +1006,11 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
       pre.cnt = d.counters[e];
       pre.ed = &ed;
       if (auv_uniform(ab_early)) return;
-      MSTAMP(e, 1);
       k2_movers<true>(d, e, lane, L, ed, 1);
       kp = k2_prefetch(d, e, lane, ed);
     } else {
       if (carry_wait_wave(d, e, lane, tagmix_prev, ed, pre.cnt)) return;
       if (auv_uniform(ab_early)) return;
-      MSTAMP(e, 1);
       pre.ed = &ed;
       k2_movers<true, true>(d, e, lane, L, ed, 1);
       kp = k2_prefetch<true>(d, e, lane, ed);
@@ -1025,13 +1026,17 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     MSTAMP(e, 2);
     int2 lim0 = make_int2(INT32_MIN, INT32_MIN);
     const int n_act = k2_front<true>(d, e, lane, L, 1, &pre, 1, &kp, true, &lim0);
-    MSTAMP(e, 3);
     k2_stage_and_pairs(d, L, lane, n_act, pre.s[2]);
     MSTAMP(e, 4);
     double term = 0.0;
     const int collision = k2_back<true>(d, e, lane, L, n_act, obs_out, &term, &lim0);
     pair_publish_lidar(d, e, lane, collision, term);
     MSTAMP(e, 5);
+#ifdef AUV_STAMPS_MULTI
+    if (lane == 0) stamp[(size_t)e * 16 + 1] = t_entry;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // every store of this wave has been acknowledged
+    MSTAMP(e, 3);
+#endif
   } else if (role == 2) {
     // ---- Vessel.navigate of one environment: the nearest-point search ----
     const int el = bi;
@@ -1045,7 +1050,9 @@ __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvD
     } else if (carry_wait_wave(d, e, lane, tagmix_prev, ed, pre.cnt)) {
       return;
     }
-    MSTAMP(e, 7);
+#ifdef AUV_STAMPS_MULTI
+    if (lane == 0) stamp[(size_t)e * 16 + 7] = t_entry;
+#endif
     pre.ed = &ed;
     if (roles_wait_state(d, e, lane, pre, tagmix, true, pk_first)) return;
     MSTAMP(e, 8);

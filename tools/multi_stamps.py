@@ -59,9 +59,10 @@ sw, se = st[:, 0:6], st[:, 6:10]
 dy = st[::1, 10:13]
 fi = st[:, 13:16]
 roles = {}
-roles["sweep"] = dict(waves=n, slot=q(sw[:, 5] - sw[:, 0]), wait_carry=q(sw[:, 1] - sw[:, 0]), front_before_state_and_wait=q(sw[:, 2] - sw[:, 1]),
-                      front=q(sw[:, 3] - sw[:, 2]), staging_and_pairs=q(sw[:, 4] - sw[:, 3]), back_and_publish=q(sw[:, 5] - sw[:, 4]))
-roles["search"] = dict(waves=n, slot=q(se[:, 3] - se[:, 0]), wait_carry=q(se[:, 1] - se[:, 0]), wait_state=q(se[:, 2] - se[:, 1]), search=q(se[:, 3] - se[:, 2]))
+roles["sweep"] = dict(waves=n, slot=q(sw[:, 3] - sw[:, 1]), first_instruction_to_role=q(sw[:, 0] - sw[:, 1]), until_state=q(sw[:, 2] - sw[:, 0]),
+                      front_and_pairs=q(sw[:, 4] - sw[:, 2]), back_and_publish=q(sw[:, 5] - sw[:, 4]), stores_acknowledged=q(sw[:, 3] - sw[:, 5]))
+roles["search"] = dict(waves=n, slot=q(se[:, 3] - se[:, 1]), first_instruction_to_role=q(se[:, 0] - se[:, 1]), until_state=q(se[:, 2] - se[:, 0]),
+                       search=q(se[:, 3] - se[:, 2]))
 roles["dynamics"] = dict(waves=n // 8, slot=q(dy[:, 2] - dy[:, 0]), wait_carry=q(dy[:, 1] - dy[:, 0]), integrate=q(dy[:, 2] - dy[:, 1]))
 roles["finish"] = dict(waves=n // 8, slot=q(fi[:, 2] - fi[:, 0]), until_sweeps_words=q(fi[:, 1] - fi[:, 0]), reward_and_carry=q(fi[:, 2] - fi[:, 1]))
 out["roles"] = roles
@@ -69,8 +70,6 @@ tot = sum(r["waves"] * r["slot"]["mean"] for r in roles.values())
 out["wave_us_per_step"] = round(tot, 0)
 out["slot_us_per_step"] = round(4096 * us_step, 0)
 out["share_of_slots"] = {k: round(r["waves"] * r["slot"]["mean"] / (4096 * us_step), 3) for k, r in roles.items()}
-out["waiting_share_of_slots"] = round((n * (roles["sweep"]["wait_carry"]["mean"] + roles["search"]["wait_carry"]["mean"] + roles["search"]["wait_state"]["mean"])
-                                       + n // 8 * (roles["dynamics"]["wait_carry"]["mean"])) / (4096 * us_step), 3)
 # the step's own timeline: from the first dynamics wave of the stamped step to its last finish wave
 out["step_span_us"] = round(float(fi[:, 2].max() - dy[:, 0].min()), 1)
 out["env_critical_path_us"] = q(fi[:, 2] - dy[:, 0])
