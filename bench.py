@@ -409,7 +409,8 @@ def main():
                 multi_T = 64 if r_multi > r_chains else 1
                 calibration = dict(one_chain_64_steps_per_launch=round(r_multi, 1), chains_one_step_per_launch=round(r_chains, 1), steps_each=192)
             else:
-                cands = sorted({T for T in (args.steps, args.steps // 2, 5) if 2 <= T <= min(64, n_pool) and args.steps % T == 0}, reverse=True)
+                divs = [T for T in range(min(64, n_pool, args.steps), 1, -1) if args.steps % T == 0]      # whole launches only
+                cands = sorted(set(divs[:2] + [T for T in (5,) if T in divs]), reverse=True)
                 rates = {T: trial(1, T, args.steps, 5) for T in cands}
                 rates[1] = trial(4 if want4 else 1, 1, args.steps, 5)
                 multi_T = max(rates, key=rates.get)
