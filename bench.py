@@ -818,7 +818,9 @@ def main():
     bound = max(legs, key=legs.get)
     if max(legs.values()) < 0.6:
         bound = "latency"      # neither leg saturated: the step is bound by dependent chains / occupancy, not by a pipe
-    roofline = dict(bound=bound, kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac,
+    # (achieved / peak / unit / frac are ALWAYS the HBM leg -- algorithmic bytes over measured time against 8 TB/s; `bound` names the
+    # larger of `legs`, or "latency" when neither reaches 0.6)
+    roofline = dict(bound=bound, kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_frac, frac_is_leg="hbm",
                     traffic=traffic, valu=valu, wait_frac=valu["wait_frac"] if valu else None, legs=legs,
                     step_bytes=int(step_bytes), concurrent_launches=sub if (pipelined or api == "multi") else 1, kernels=per_kernel,
                     lib_sha256=lib_sha)
