@@ -21,7 +21,7 @@ dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 headline = (workload, sub, T) == ("polygons50", 4, 1)       # the headline run keeps the plain names; other passes get a suffix
 for f in glob.glob(os.path.join(run, "bench_*.json")) + glob.glob(os.path.join(run, "*.txt")) + glob.glob(os.path.join(run, "pmc_*.json")) + \
-        [os.path.join(run, n) for n in ("kernel_stats.csv", "bench_2ranks_refused.out", "lib_sha256.txt")]:
+        [os.path.join(run, n) for n in ("kernel_stats.csv", "kernel_stats_driver_command.csv", "bench_2ranks_refused.out", "lib_sha256.txt")]:
     if os.path.exists(f) and os.path.getsize(f) > 0:
         if headline:
             shutil.copy(f, dst)

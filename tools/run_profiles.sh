@@ -81,6 +81,13 @@ python tools/trace_overlap.py $OUT/trace/*/*_kernel_trace.csv k_step_roles 4000 
 python tools/trace_overlap.py $OUT/trace/*/*_kernel_trace.csv k_step_multi 64 >> $OUT/kernel_trace_overlap.txt   # the timed loop when it runs 64 steps per launch
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace
+# the same for the driver's own command (20 steps: its calibration issues launches of several lengths; the summary lists k_step_multi per length)
+cd /tmp
+run bench_driver_command_under_rocprof $OUT/bench_driver_command_under_rocprof.json rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_drv -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --bank-cache /tmp/bank --cpu-baseline 0
+cd $ROOT
+python tools/trace_summary.py $OUT/trace_drv/*/*_kernel_trace.csv > $OUT/kernel_trace_summary_driver_command.txt
+cp $OUT/trace_drv/*/*_kernel_stats.csv $OUT/kernel_stats_driver_command.csv 2>/dev/null
+rm -rf $OUT/trace_drv
 head -6 $OUT/kernel_trace_summary.txt; head -12 $OUT/kernel_trace_overlap.txt
 # (SKIP_PMC=1: the counter passes go in a GPU call of their own -- tools/pmc_workload.sh <tag> polygons50 4 -- when one call cannot hold both)
 [ "${SKIP_PMC:-0}" = 1 ] || bash tools/pmc_workload.sh $TAG polygons50 4
