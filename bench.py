@@ -22,7 +22,9 @@ GPU -- one chain's sweeps run under another's dynamics chain and navigation tail
 bit for bit (tests/test_gpu_parity.py::test_sub_batches_bitwise).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline      the step's dominant kernel, k_step_roles.  `kernels[...]`: its launch duration by HIP events on its own
+  roofline      the step's dominant kernel: k_step_multi (T steps per launch: `avg_ms` = a run of back-to-back launches between one
+                pair of HIP events on the chain's stream / their number, `alone_ms` = one launch by itself) or k_step_roles (one
+                step per launch).  `kernels[...]`: its launch duration by HIP events on its own
                 stream in this process (with sub-batches: while the other chains run beside it; what a kernel trace's
                 average shows) and algorithmic bytes / that duration.  HBM leg (`achieved`, `frac`): with ONE chain exactly
                 that figure; with K concurrent chains the K launches of a step run at the same time, so the leg is the
@@ -73,8 +75,11 @@ def parse():
     ap.add_argument("--multi", type=int, default=-1,
                     help="T: the open-loop loop enqueues T consecutive steps of every chain as ONE launch per chain (auv_step_multi: an "
                          "environment's step t + 1 starts when ITS step t is through, no barrier over the slice, no launch turn-around; "
-                         "bit-identical to T single-step launches).  1: one launch per step and chain.  -1 (default): 64 on ONE chain where the "
-                         "loop is open (api pipelined, resident actions, no fresh worlds, no graph) and --steps >= 256, else 1")
+                         "bit-identical to T single-step launches).  1: one launch per step and chain.  -1 (default): where the loop is open (api "
+                         "pipelined, resident actions, no fresh worlds, no graph, --sub-batches 0) the shape is CALIBRATED before anything is "
+                         "timed, in windows like the timed one: >= 256 steps -- one chain x 64-step launches against chains of one-step "
+                         "launches; fewer -- one chain with the window as one / two launches or launches of 5 against the chains "
+                         "(config.shape_calibration holds every candidate's rate); else 1")
     ap.add_argument("--multi-order", default="cohorts", choices=["cohorts", "steps"], help="--multi: workgroup order of a launch (include/auv_hip.h, auv_set_multi_order)")
     ap.add_argument("--multi-lead", type=int, default=16)
     ap.add_argument("--multi-lag", type=int, default=30)
