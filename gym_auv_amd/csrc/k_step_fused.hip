@@ -885,11 +885,22 @@ __device__ __forceinline__ void roles_finish_wave_multi(const AuvDev& dk, const 
   }
 }
 
+// The descriptor is the kernel's FIRST argument: offset 0 of the argument segment.  Read through the segment pointer (laundered, so that
+// the compiler cannot prove the loads safe to speculate) its fields are fetched where a role uses them -- not every field any role
+// uses, in four or five dependent batches with scalar registers spilled in between, at the top of every wave (0.8 us of a 6 us search
+// wave: tools/multi_stamps.py).  k_step_multi: 176 -> 186 M env-steps/s at 64 steps per launch, 160 -> 171 M over the driver's 20-step
+// window; k_step_roles: 151 -> 150 M on four chains, so the one-step launch keeps the by-value reference
+// (profiles/r05/ab_descriptor_through_segment_pointer.jsonl).
+#define AUV_KERNARG_DESC(name)                                                                                                                       \
+  const __attribute__((address_space(4))) void* name##_kp_ = (const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr(); \
+  asm volatile("" : "+s"(name##_kp_));                                                                                                               \
+  const AuvDev& name = *(const AuvDev*)(const __attribute__((address_space(4))) AuvDev*)name##_kp_
+
 __global__ void __launch_bounds__(AUV_WAVE, AUV_K23_MIN_WAVES) k_step_multi(AuvDev dk, const void* __restrict__ actions, float* __restrict__ obs_out,
                                                                            float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
                                                                            const int n_steps, const int first_slot, const int n_slots,
                                                                            const unsigned long long seq0, const int lead_dyn, const int lag_fin, const unsigned magic_c) {
-  const AuvDev& d = dk;
+  AUV_KERNARG_DESC(d);
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef AUV_STAMPS_MULTI
   const unsigned long long t_entry = wall_clock64();      // the wave's first instruction
