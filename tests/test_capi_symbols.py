@@ -80,3 +80,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "auv_oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_multi_step_kernel_reads_its_descriptor_at_offset_zero_of_the_argument_segment():
+    """k_step_multi fetches the descriptor's fields through the kernel-argument segment pointer (AUV_KERNARG_DESC in
+    csrc/k_step_fused.hip): that is only the descriptor if `AuvDev dk` is the kernel's FIRST parameter."""
+    import re
+    src = open(os.path.join(ROOT, "gym_auv_amd", "csrc", "k_step_fused.hip")).read()
+    m = re.search(r"__global__ void __launch_bounds__\([^)]*\)\s*k_step_multi\(\s*([A-Za-z_0-9 ]+?)\s+(\w+)\s*,", src)
+    assert m and m.group(1).strip() == "AuvDev" and m.group(2) == "dk", m and m.groups()
+    body = src[m.end():]
+    assert "AUV_KERNARG_DESC(d);" in body[:body.index("\n}\n")]
